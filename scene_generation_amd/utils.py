@@ -1,0 +1,127 @@
+"""Host-side helpers of the training step (mirror of /root/reference/scene_generation/utils.py).
+
+* int_tuple / float_tuple / str_tuple / bool_flag : utils.py:22-40 (flag parsers).
+* LossManager : utils.py:43-59 API, but values stay lazy device scalars -- the reference calls
+  ``.item()`` inside add_loss (one device->host sync per loss, ~16 per step); here ``items()``
+  materialises them only when somebody prints.
+* VectorPool : utils.py:62-90 semantics (per-class replay pool, Python ``random.randint`` draws in the
+  same order) with the pool RESIDENT IN HBM: one small D2H copy of the class ids per query instead of
+  2*O syncs, index planning on the host, two HIP gather/scatter launches on the device.
+"""
+import random
+
+import torch
+
+
+def int_tuple(s):
+    return tuple(int(i) for i in s.split(','))
+
+
+def float_tuple(s):
+    return tuple(float(i) for i in s.split(','))
+
+
+def str_tuple(s):
+    return tuple(s.split(','))
+
+
+def bool_flag(s):
+    if s == '1':
+        return True
+    if s == '0':
+        return False
+    raise ValueError('Invalid value "%s" for bool flag (should be 0 or 1)' % s)
+
+
+class LossManager(object):
+    def __init__(self):
+        self.total_loss = None
+        self._lazy = {}
+
+    def add_loss(self, loss, name, weight=1.0, use_loss=True):
+        cur = loss * weight
+        if use_loss:
+            self.total_loss = cur if self.total_loss is None else self.total_loss + cur
+        self._lazy[name] = cur.detach()
+
+    @property
+    def all_losses(self):
+        """name -> python float (materialised on access; this is where the host sync happens)"""
+        return {k: (v.item() if isinstance(v, torch.Tensor) else float(v)) for k, v in self._lazy.items()}
+
+    def set_value(self, name, value):
+        self._lazy[name] = value.detach() if isinstance(value, torch.Tensor) else value
+
+    def items(self):
+        return self.all_losses.items()
+
+
+def plan_pool_query(classes, pool_len, pool_size, rng=random):
+    """Host-side index planning for VectorPool.query (utils.py:67-90), processing objects in order.
+
+    classes  : list[int] class id per object
+    pool_len : dict class -> current fill of that class's pool (MUTATED to the post-query fill)
+    Returns (src_kind, src_idx, slot) lists, one entry per object:
+      out[i]   = vectors[src_idx[i]]            if src_kind[i] == 0   (a row of THIS batch, j <= i)
+               = pool[class_i][src_idx[i]]      if src_kind[i] == 1   (content from BEFORE this query)
+      slot[i]  = pool slot of class_i that vectors[i] is stored to afterwards (always >= 0 here).
+    Later writes to the same (class, slot) win, exactly as the sequential reference loop.
+    """
+    src_kind, src_idx, slot = [], [], []
+    shadow = {}                                   # (class, slot) -> batch row currently stored there
+    for i, c in enumerate(classes):
+        n = pool_len.get(c, 0)
+        if n == 0:
+            src_kind.append(0)
+            src_idx.append(i)
+            slot.append(0)
+            shadow[(c, 0)] = i
+            pool_len[c] = 1
+        elif n < pool_size:
+            r = rng.randint(0, n - 1)
+            shadow[(c, n)] = i                    # append first (utils.py:79), then read slot r
+            pool_len[c] = n + 1
+            slot.append(n)
+            j = shadow.get((c, r))
+            src_kind.append(1 if j is None else 0)
+            src_idx.append(r if j is None else j)
+        else:
+            r = rng.randint(0, n - 1)
+            j = shadow.get((c, r))
+            src_kind.append(1 if j is None else 0)
+            src_idx.append(r if j is None else j)
+            shadow[(c, r)] = i
+            slot.append(r)
+    return src_kind, src_idx, slot
+
+
+class VectorPool:
+    def __init__(self, pool_size):
+        self.pool_size = pool_size
+        self.pool_len = {}                        # class -> fill (host)
+        self.pool = None                          # (num_classes_seen_capacity, pool_size, R) device tensor
+        self.capacity = 0
+
+    def _ensure(self, max_class, R, like):
+        if self.pool is None or max_class >= self.capacity or self.pool.size(2) != R:
+            cap = max(max_class + 1, self.capacity, 16)
+            new = torch.zeros(cap, self.pool_size, R, dtype=like.dtype, device=like.device)
+            if self.pool is not None and self.pool.size(2) == R:
+                new[:self.capacity] = self.pool
+            self.pool, self.capacity = new, cap
+
+    def query(self, objs, vectors, objs_host=None):
+        if self.pool_size == 0:
+            return vectors
+        from . import ops
+        classes = objs_host if objs_host is not None else objs.tolist()
+        vectors = vectors.detach()
+        self._ensure(max(classes), vectors.size(1), vectors)
+        kind, idx, slot = plan_pool_query(classes, self.pool_len, self.pool_size)
+        plan = torch.tensor([classes, kind, idx, slot], dtype=torch.int32).to(vectors.device, non_blocking=True)
+        return ops.vector_pool_exchange(self.pool, vectors, plan)
+
+    # host view used by tests / checkpoints
+    def vectors_of(self, cls):
+        n = self.pool_len.get(cls, 0)
+        return [] if n == 0 else list(self.pool[cls, :n].cpu())
