@@ -1,0 +1,204 @@
+/*
+ * sg2im_hip.h -- C ABI of libsg2im_hip.so: the hand-written gfx950 (MI355X / CDNA4) kernels behind the
+ * scene-graph -> image G+D training step.
+ *
+ * The reference (ashual/scene_generation) has no FFI: its hot path dispatches PyTorch ops.  Each entry
+ * point below replaces the op group a reference call site dispatches (cited per function, paths
+ * relative to /root/reference/scene_generation/).  The only caller is the Python host layer
+ * (scene_generation_amd/ops.py, ctypes); INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - caller owns every buffer (incl. workspace); no allocation, no host sync, no stream creation inside
+ *   - all pointers are DEVICE pointers unless the name ends in _host; tensors are dense row-major,
+ *     images NCHW fp32, indices int64 (graph/crop) or int32 (CSR / segment offsets / plans)
+ *   - `stream` is a hipStream_t passed as void*; every launch goes to that stream, in order
+ *   - return 0 = OK; <0 = argument error detected before launch; >0 = hipError_t from the launch
+ *     sg_last_error_string() describes the last non-zero return on the calling thread
+ *   - thread-safe for distinct streams (the only global state is the opt-in profiler, see sg_prof_*)
+ */
+#ifndef SG2IM_HIP_H
+#define SG2IM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sgStream;
+
+/* activation codes fused into epilogues */
+enum { SG_ACT_NONE = 0, SG_ACT_RELU = 1, SG_ACT_LEAKY = 2, SG_ACT_TANH = 3, SG_ACT_SIGMOID = 4 };
+/* scalar loss kinds (sg_loss_fwd / sg_loss_bwd) */
+enum { SG_LOSS_MSE_CONST = 0, SG_LOSS_MSE = 1, SG_LOSS_L1 = 2, SG_LOSS_BCE_LOGITS_CONST = 3 };
+
+int sg_version(void);
+const char* sg_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution family = implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain).
+ * Replaces nn.Conv2d / nn.ConvTranspose2d (+ the nn.ReflectionPad2d, Interpolate(x2, nearest) and
+ * torch.cat((layout, img), 1) feeding them) at generators.py:20-27,68-89, layers.py:160-180,251-270,
+ * discriminators.py:137-158,215-234 and trainer.py:246,250,328.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct sgConvDesc {
+  int32_t N;            /* images */
+  int32_t C1, C2;       /* input channels taken from x1 / x2 (channel concat folded into the gather; C2=0 if none) */
+  int32_t H, W;         /* stored input spatial size */
+  int32_t Cout;
+  int32_t KS;           /* square kernel: 1, 3, 4 or 7 */
+  int32_t stride;       /* 1 or 2 */
+  int32_t pad;
+  int32_t pad_reflect;  /* 0 zero padding, 1 reflection padding (nn.ReflectionPad2d folded in) */
+  int32_t upsample;     /* 1, or 2 = nearest x2 upsample of the input folded in (layers.py:304-314) */
+  int32_t OH, OW;       /* output spatial size */
+  int32_t out_pad;      /* conv-transpose only: output_padding */
+  int32_t x2_broadcast; /* 1: x2 is [N, C2] and is broadcast over H x W (the one-hot class map of discriminators.py:107-110) */
+} sgConvDesc;
+
+size_t sg_conv2d_ws_bytes(const sgConvDesc* d, int kind /*0 fwd, 1 dgrad, 2 wgrad*/);
+/* y[N,Cout,OH,OW] = act(conv(x) + bias) ; w [Cout, C1+C2, KS, KS] */
+int sg_conv2d_fwd(const sgConvDesc* d, const float* x1, const float* x2, const float* w, const float* bias,
+                  float* y, int act, float slope, sgStream stream);
+/* gx[N, c_end-c_begin, Hg, Wg]: gradient w.r.t. input channels [c_begin, c_end) of the *padded/upsampled*
+ * logical input: Hg = H*upsample + (pad_reflect ? 2*pad : 0).  Fold with sg_pad_upsample_bwd. */
+int sg_conv2d_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, int c_begin, int c_end,
+                    void* ws, size_t ws_bytes, sgStream stream);
+/* gw[Cout, C1+C2, KS, KS] (+ gb[Cout] if non-null) */
+int sg_conv2d_wgrad(const sgConvDesc* d, const float* gy, const float* x1, const float* x2, float* gw, float* gb,
+                    void* ws, size_t ws_bytes, sgStream stream);
+/* nn.ConvTranspose2d(k3,s2,p1,op1) : w [Cin, Cout, KS, KS]; desc.H,W = input size, OH,OW = output size */
+int sg_convT2d_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y,
+                   void* ws, size_t ws_bytes, sgStream stream);
+int sg_convT2d_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, sgStream stream);
+int sg_convT2d_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, float* gb,
+                     void* ws, size_t ws_bytes, sgStream stream);
+/* fold a dgrad taken w.r.t. the reflect-padded and/or x2-upsampled logical input back onto the stored
+ * input: gx[NC,H,W] = sum of gp[NC, H*up+2p, W*up+2p] over reflected / replicated positions */
+int sg_pad_upsample_bwd(const float* gp, float* gx, int NC, int H, int W, int pad, int upsample, sgStream stream);
+/* per-channel sum over (N, HW): bias gradients */
+int sg_channel_sum(const float* g, float* out, int N, int C, int HW, sgStream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense layers (nn.Linear inside build_mlp layers.py:215-231, generators.py:45, discriminators.py:23-27)
+ * ------------------------------------------------------------------------------------------- */
+int sg_linear_fwd(const float* x, const float* w, const float* b, float* y, int rows, int in_f, int out_f,
+                  int act, float slope, sgStream stream);                 /* y = act(x w^T + b) */
+int sg_linear_bwd_data(const float* gy, const float* w, float* gx, int rows, int in_f, int out_f, sgStream stream);
+int sg_linear_bwd_weight(const float* gy, const float* x, float* gw, float* gb, int rows, int in_f, int out_f,
+                         sgStream stream);
+/* gx = gy * act'(.) evaluated from the activation OUTPUT y (relu / leaky / tanh / sigmoid) */
+int sg_act_bwd(const float* y, const float* gy, float* gx, int64_t n, int act, float slope, sgStream stream);
+int sg_act_fwd(const float* x, float* y, int64_t n, int act, float slope, sgStream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Graph convolution (graph.py:58-122) + embeddings (model.py:131-132)
+ * ------------------------------------------------------------------------------------------- */
+/* destination-major CSR of the 2T (pass, t) entries: pass 0 = subject column, pass 1 = object column,
+ * entries of a row ordered (pass, t ascending) == the order CPU scatter_add applies them (graph.py:98-101).
+ * csr_off[O+1], csr_ent[2T] (t | pass<<30). */
+int sg_build_csr(const int64_t* edges /*T,2*/, int T, int O, int32_t* csr_off, int32_t* csr_ent, sgStream stream);
+/* out[t] = [obj[s_t], pred[t], obj[o_t]]  (graph.py:79-84) */
+int sg_gather_concat_fwd(const float* obj, const float* pred, const int64_t* edges, float* out,
+                         int T, int Do, int Dp, sgStream stream);
+/* dst[i, :] = (sum over CSR entries e of row i of src[t_e, col_off[pass_e] : +width]) / (avg ? max(deg_i,1) : 1)
+ * forward pool: src=new_t, col_off={0, H+Dout}; gather backward: src=g_cur_t, col_off={0, Do+Dp}. Bit-exact
+ * w.r.t. sequential CPU scatter_add (deterministic, no atomics). */
+int sg_segment_sum(const float* src, int src_ld, int col_off0, int col_off1, int width, const int32_t* csr_off,
+                   const int32_t* csr_ent, float* dst, int O, int avg, sgStream stream);
+/* g_new_t[t] = [g_pooled[s_t]/cnt_s, g_new_p[t], g_pooled[o_t]/cnt_o]  (dual of the pool, graph.py:89-116) */
+int sg_pool_bwd(const float* g_pooled, const float* g_new_p, const int64_t* edges, const int32_t* csr_off,
+                float* g_new_t, int T, int H, int Dout, int avg, sgStream stream);
+int sg_embedding_fwd(const float* table, const int64_t* idx, float* out, int n, int dim, sgStream stream);
+int sg_embedding_bwd(const float* g, const int64_t* idx, float* g_table, int n, int num_rows, int dim, sgStream stream);
+/* strided 2-D copy: dst[r, dst_off : dst_off+width] = src[r, src_off : src_off+width] (concat / split glue) */
+int sg_copy_cols(const float* src, int src_ld, int src_off, float* dst, int dst_ld, int dst_off, int rows, int width,
+                 sgStream stream);
+int sg_one_hot(const int64_t* idx, float* out, int n, int classes, int ld, int col_off, sgStream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Normalisation / pooling (nn.InstanceNorm2d, nn.BatchNorm2d, nn.AvgPool2d(3,2,1,count_include_pad=False),
+ * GlobalAvgPool layers.py:82-85)
+ * ------------------------------------------------------------------------------------------- */
+/* y = act((x-mean)*rstd) [+ skip]; biased variance per (n,c) plane, eps inside sqrt (layers.py:296) */
+int sg_instnorm_fwd(const float* x, const float* skip, float* y, float* mean, float* rstd, int NC, int HW, float eps,
+                    int act, float slope, sgStream stream);
+int sg_instnorm_bwd(const float* x, const float* gy, const float* mean, const float* rstd, float* gx, int NC, int HW,
+                    int act, float slope, sgStream stream);
+/* training: batch stats (biased var) + running-stat update (unbiased var, momentum) + num_batches_tracked++ */
+int sg_batchnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
+                     float* save_rstd, float* running_mean, float* running_var, int64_t* num_batches, int N, int C,
+                     int HW, float eps, float momentum, int training, int act, float slope, sgStream stream);
+/* beta is needed to rebuild the pre-activation gamma*z+beta for the fused activation mask */
+int sg_batchnorm_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
+                     const float* save_rstd, float* gx, float* ggamma, float* gbeta, int N, int C, int HW, int act,
+                     float slope, sgStream stream);
+int sg_avgpool3s2_fwd(const float* x, float* y, int NC, int H, int W, int OH, int OW, sgStream stream);
+int sg_avgpool3s2_bwd(const float* gy, float* gx, int NC, int H, int W, int OH, int OW, sgStream stream);
+int sg_gap_fwd(const float* x, float* y, int NC, int HW, sgStream stream);
+int sg_gap_bwd(const float* gy, float* gx, int NC, int HW, sgStream stream);
+int sg_upsample2_fwd(const float* x, float* y, int NC, int H, int W, sgStream stream);   /* nearest x2 */
+int sg_reflect_pad_fwd(const float* x, float* y, int NC, int H, int W, int pad, sgStream stream);
+int sg_concat_channels(const float* a, const float* b, float* out, int N, int Ca, int Cb, int HW, sgStream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout scatter and bilinear crops (layout.py:64-155, bilinear.py:67-130)
+ * ------------------------------------------------------------------------------------------- */
+/* seg_off[N+1] from a sorted, gap-free obj_to_img */
+int sg_segment_offsets(const int64_t* obj_to_img, int O, int N, int32_t* seg_off, sgStream stream);
+/* out[n,d,h,w] = sum_{o in image n, ascending} vecs[o,d] * bilinear(mask_o, box_o)(h,w)   (align_corners=False,
+ * zeros padding); masks int64 0/1 (gt) or fp32 (predicted); never materialises (O,D,H,W). */
+int sg_masks_to_layout_fwd(const float* vecs, const float* boxes, const void* masks, int masks_i64,
+                           const int32_t* seg_off, float* out, int N, int O, int D, int M, int H, int W, int avg,
+                           int max_per_image /* hint: objects per image the LDS tile is provisioned for; 0 = default */,
+                           sgStream stream);
+/* g_vecs[o, d] for d in [d_begin, D) (columns below d_begin are zero-filled) */
+int sg_masks_to_layout_bwd_vecs(const float* gout, const float* boxes, const void* masks, int masks_i64,
+                                const int64_t* obj_to_img, const int32_t* seg_off, float* g_vecs, int N, int O, int D,
+                                int M, int H, int W, int avg, int d_begin, sgStream stream);
+int sg_crop_bbox_fwd(const float* feats, const float* boxes, const int64_t* box_to_feat, float* out, int N, int C, int H,
+                     int W, int B, int HH, int WW, sgStream stream);
+/* g_feats must be zero-filled by the caller; accumulated with fp32 atomics (order not deterministic) */
+int sg_crop_bbox_bwd(const float* gout, const float* boxes, const int64_t* box_to_feat, float* g_feats, int N, int C,
+                     int H, int W, int B, int HH, int WW, sgStream stream);
+/* VectorPool.query on device (utils.py:62-90): plan = int32[4][O] rows {class, src_kind, src_idx, slot}
+ * out[i] = src_kind ? pool[class][src_idx] : vectors[src_idx]; then pool[class][slot] = vectors[i] (slot>=0) */
+int sg_vector_pool_exchange(float* pool, const float* vectors, const int32_t* plan, float* out, int O, int R,
+                            int pool_size, sgStream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Losses (losses.py:26-90,135-175; trainer.py:215,331-340; discriminators.py:35) and Adam (trainer.py:60,80,106,133)
+ * ------------------------------------------------------------------------------------------- */
+size_t sg_loss_ws_bytes(int64_t n);
+/* out[0] (+)= scale * sum_i l(a_i, b_i or target); deterministic two-stage reduction */
+int sg_loss_fwd(int kind, const float* a, const float* b, float target, int64_t n, float scale, float* out,
+                int accumulate, void* ws, size_t ws_bytes, sgStream stream);
+/* ga_i = gout[0] * scale * dl/da_i */
+int sg_loss_bwd(int kind, const float* a, const float* b, float target, int64_t n, float scale, const float* gout,
+                float* ga, sgStream stream);
+/* mean over rows of -log softmax(logits)[target]; per-row loss kept in row_loss[rows] */
+int sg_cross_entropy_fwd(const float* logits, const int64_t* target, int rows, int classes, float* row_loss,
+                         float* out, sgStream stream);
+int sg_cross_entropy_bwd(const float* logits, const int64_t* target, int rows, int classes, const float* gout,
+                         float* glogits, sgStream stream);
+/* torch.optim.Adam step (no weight decay / amsgrad) over one flat fp32 buffer */
+int sg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float bias_corr1, float bias_corr2_sqrt, sgStream stream);
+int sg_fill(float* p, float value, int64_t n, sgStream stream);
+int sg_scale(float* p, float alpha, int64_t n, sgStream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Opt-in per-kernel timing with HIP events on the launch stream (bench.py roofline leg).
+ * ------------------------------------------------------------------------------------------- */
+int sg_prof_enable(int on);
+int sg_prof_reset(void);
+int sg_prof_num_kinds(void);
+const char* sg_prof_kind_name(int kind);
+/* synchronises the recorded events; totals since the last reset */
+int sg_prof_read(int kind, double* total_ms, int64_t* launches, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SG2IM_HIP_H */

@@ -1,0 +1,75 @@
+// Shared helpers for the gfx950 kernels of libsg2im_hip.so (see include/sg2im_hip.h for the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sg2im_hip.h"
+
+#define SG_WAVE 64
+
+void sg_set_error(const char* fmt, ...);
+
+#define SG_ARG_CHECK(cond, ...)                 \
+  do {                                          \
+    if (!(cond)) {                              \
+      sg_set_error(__VA_ARGS__);                \
+      return -1;                                \
+    }                                           \
+  } while (0)
+
+#define SG_LAUNCH_CHECK(name)                                               \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) {                                                \
+      sg_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return (int)e__;                                                      \
+    }                                                                       \
+  } while (0)
+
+// ---- profiler kinds (bench.py roofline leg) -------------------------------------------------
+enum {
+  SG_K_CONV_FWD = 0, SG_K_CONV_DGRAD, SG_K_CONV_WGRAD, SG_K_LINEAR, SG_K_LAYOUT_FWD, SG_K_LAYOUT_BWD,
+  SG_K_INSTNORM, SG_K_BATCHNORM, SG_K_ADAM, SG_K_SEGSUM, SG_K_CROP, SG_K_OTHER, SG_K_COUNT
+};
+extern int g_sg_prof_on;
+void sg_prof_begin(int kind, hipStream_t s);
+void sg_prof_end(int kind, hipStream_t s, double flops, double bytes);
+
+struct SgProfScope {
+  int kind; hipStream_t s; double flops, bytes; bool on;
+  SgProfScope(int k, hipStream_t st, double f, double b) : kind(k), s(st), flops(f), bytes(b), on(g_sg_prof_on != 0) {
+    if (on) sg_prof_begin(kind, s);
+  }
+  ~SgProfScope() { if (on) sg_prof_end(kind, s, flops, bytes); }
+};
+
+static inline int sg_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float sg_apply_act(float v, int act, float slope) {
+  switch (act) {
+    case SG_ACT_RELU: return v > 0.f ? v : 0.f;
+    case SG_ACT_LEAKY: return v > 0.f ? v : v * slope;
+    case SG_ACT_TANH: return tanhf(v);
+    case SG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    default: return v;
+  }
+}
+
+// wave64 reductions via cross-lane shuffles (no LDS)
+__device__ __forceinline__ float sg_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block reduction of up to 1024 threads; result valid in every thread. `red` = >=16 floats of LDS.
+__device__ __forceinline__ float sg_block_sum(float v, float* red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = sg_wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];   // fixed order => deterministic
+  return t;
+}

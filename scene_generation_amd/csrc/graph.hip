@@ -1,0 +1,223 @@
+// GraphTripleConv indexing kernels (graph.py:79-116) + embeddings (model.py:131-132): coalesced row
+// gathers and a deterministic destination-major segmented sum (no atomics) whose accumulation order
+// equals the CPU scatter_add order of the reference (s-pass then o-pass, t ascending) => bit-exact pool.
+#include "common.h"
+
+namespace {
+
+constexpr int PASS_SHIFT = 30;
+
+__global__ void csr_count_kernel(const int64_t* __restrict__ edges, int T, int O, int32_t* __restrict__ cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= O) return;
+  int c = 0;
+  for (int t = 0; t < T; ++t) {
+    c += (edges[2 * t] == i);
+    c += (edges[2 * t + 1] == i);
+  }
+  cnt[i + 1] = c;
+}
+
+// single wave exclusive scan: off[0]=0, off[i+1] = sum_{j<=i} cnt[j+1]  (in place on off[1..O])
+__global__ void csr_scan_kernel(int32_t* __restrict__ off, int O) {
+  const int lane = threadIdx.x;
+  int carry = 0;
+  if (lane == 0) off[0] = 0;
+  for (int base = 0; base < O; base += 64) {
+    const int i = base + lane;
+    int v = i < O ? off[i + 1] : 0;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int u = __shfl_up(v, d, 64);
+      if (lane >= d) v += u;
+    }
+    if (i < O) off[i + 1] = v + carry;
+    carry += __shfl(v, 63, 64);
+  }
+}
+
+__global__ void csr_fill_kernel(const int64_t* __restrict__ edges, int T, int O, const int32_t* __restrict__ off,
+                                int32_t* __restrict__ ent) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= O) return;
+  int w = off[i];
+  for (int t = 0; t < T; ++t)
+    if (edges[2 * t] == i) ent[w++] = t;
+  for (int t = 0; t < T; ++t)
+    if (edges[2 * t + 1] == i) ent[w++] = t | (1 << PASS_SHIFT);
+}
+
+__global__ void gather_concat_kernel(const float* __restrict__ obj, const float* __restrict__ pred,
+                                     const int64_t* __restrict__ edges, float* __restrict__ out, int T, int Do, int Dp) {
+  const int t = blockIdx.x;
+  const int64_t s = edges[2 * t], o = edges[2 * t + 1];
+  const int width = 2 * Do + Dp;
+  float* dst = out + (size_t)t * width;
+  const float* so = obj + (size_t)s * Do;
+  const float* oo = obj + (size_t)o * Do;
+  const float* pp = pred + (size_t)t * Dp;
+  for (int c = threadIdx.x; c < width; c += blockDim.x) {
+    float v;
+    if (c < Do) v = so[c];
+    else if (c < Do + Dp) v = pp[c - Do];
+    else v = oo[c - Do - Dp];
+    dst[c] = v;
+  }
+}
+
+__global__ void segment_sum_kernel(const float* __restrict__ src, int src_ld, int col0, int col1, int width,
+                                   const int32_t* __restrict__ off, const int32_t* __restrict__ ent,
+                                   float* __restrict__ dst, int avg) {
+  const int i = blockIdx.x;
+  const int beg = off[i], end = off[i + 1];
+  const float denom = (float)(end - beg > 1 ? end - beg : 1);
+  for (int c = threadIdx.x; c < width; c += blockDim.x) {
+    float acc = 0.f;
+    for (int e = beg; e < end; ++e) {
+      const int v = ent[e];
+      const int t = v & ((1 << PASS_SHIFT) - 1);
+      const int col = (v >> PASS_SHIFT) ? col1 : col0;
+      acc += src[(size_t)t * src_ld + col + c];      // sequential fp32 adds, fixed order
+    }
+    dst[(size_t)i * width + c] = avg ? acc / denom : acc;
+  }
+}
+
+__global__ void pool_bwd_kernel(const float* __restrict__ gp, const float* __restrict__ gnp,
+                                const int64_t* __restrict__ edges, const int32_t* __restrict__ off,
+                                float* __restrict__ out, int H, int Dout, int avg) {
+  const int t = blockIdx.x;
+  const int64_t s = edges[2 * t], o = edges[2 * t + 1];
+  float ds = 1.f, dobj = 1.f;
+  if (avg) {
+    const int cs = off[s + 1] - off[s], co = off[o + 1] - off[o];
+    ds = (float)(cs > 1 ? cs : 1);
+    dobj = (float)(co > 1 ? co : 1);
+  }
+  const int width = 2 * H + Dout;
+  float* dst = out + (size_t)t * width;
+  for (int c = threadIdx.x; c < width; c += blockDim.x) {
+    float v;
+    if (c < H) v = gp[(size_t)s * H + c] / ds;
+    else if (c < H + Dout) v = gnp ? gnp[(size_t)t * Dout + (c - H)] : 0.f;
+    else v = gp[(size_t)o * H + (c - H - Dout)] / dobj;
+    dst[c] = v;
+  }
+}
+
+__global__ void embedding_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx,
+                                     float* __restrict__ out, int dim) {
+  const int i = blockIdx.x;
+  const float* src = table + (size_t)idx[i] * dim;
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) out[(size_t)i * dim + c] = src[c];
+}
+
+// one block per table row; rows of g accumulated in ascending i (== CPU index_add order)
+__global__ void embedding_bwd_kernel(const float* __restrict__ g, const int64_t* __restrict__ idx,
+                                     float* __restrict__ gt, int n, int dim) {
+  const int row = blockIdx.x;
+  for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+    float acc = 0.f;
+    for (int i = 0; i < n; ++i)
+      if (idx[i] == row) acc += g[(size_t)i * dim + c];
+    gt[(size_t)row * dim + c] = acc;
+  }
+}
+
+__global__ void copy_cols_kernel(const float* __restrict__ src, int src_ld, int src_off, float* __restrict__ dst,
+                                 int dst_ld, int dst_off, int rows, int width) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * width) return;
+  const int r = i / width, c = i - (size_t)r * width;
+  dst[(size_t)r * dst_ld + dst_off + c] = src[(size_t)r * src_ld + src_off + c];
+}
+
+__global__ void one_hot_kernel(const int64_t* __restrict__ idx, float* __restrict__ out, int n, int classes, int ld,
+                               int col_off) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n * classes) return;
+  const int r = i / classes, c = i - (size_t)r * classes;
+  out[(size_t)r * ld + col_off + c] = (idx[r] == c) ? 1.f : 0.f;
+}
+
+inline int row_threads(int width) { int t = ((width + 63) / 64) * 64; return t > 256 ? 256 : (t < 64 ? 64 : t); }
+
+}  // namespace
+
+extern "C" int sg_build_csr(const int64_t* edges, int T, int O, int32_t* csr_off, int32_t* csr_ent, sgStream stream) {
+  SG_ARG_CHECK(edges && csr_off && csr_ent && T >= 0 && O > 0, "sg_build_csr: bad arguments");
+  SG_ARG_CHECK(T < (1 << PASS_SHIFT), "sg_build_csr: too many triples");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(csr_count_kernel, dim3(sg_cdiv(O, 64)), dim3(64), 0, s, edges, T, O, csr_off);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(64), 0, s, csr_off, O);
+  hipLaunchKernelGGL(csr_fill_kernel, dim3(sg_cdiv(O, 64)), dim3(64), 0, s, edges, T, O, csr_off, csr_ent);
+  SG_LAUNCH_CHECK("sg_build_csr");
+  return 0;
+}
+
+extern "C" int sg_gather_concat_fwd(const float* obj, const float* pred, const int64_t* edges, float* out, int T, int Do,
+                                    int Dp, sgStream stream) {
+  SG_ARG_CHECK(obj && pred && edges && out && T >= 0 && Do > 0 && Dp > 0, "sg_gather_concat_fwd: bad arguments");
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(gather_concat_kernel, dim3(T), dim3(row_threads(2 * Do + Dp)), 0, (hipStream_t)stream, obj, pred,
+                     edges, out, T, Do, Dp);
+  SG_LAUNCH_CHECK("sg_gather_concat_fwd");
+  return 0;
+}
+
+extern "C" int sg_segment_sum(const float* src, int src_ld, int col_off0, int col_off1, int width, const int32_t* csr_off,
+                              const int32_t* csr_ent, float* dst, int O, int avg, sgStream stream) {
+  SG_ARG_CHECK(src && csr_off && csr_ent && dst && O > 0 && width > 0, "sg_segment_sum: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  SgProfScope prof(SG_K_SEGSUM, s, 0, 0);
+  hipLaunchKernelGGL(segment_sum_kernel, dim3(O), dim3(row_threads(width)), 0, s, src, src_ld, col_off0, col_off1, width,
+                     csr_off, csr_ent, dst, avg);
+  SG_LAUNCH_CHECK("sg_segment_sum");
+  return 0;
+}
+
+extern "C" int sg_pool_bwd(const float* g_pooled, const float* g_new_p, const int64_t* edges, const int32_t* csr_off,
+                           float* g_new_t, int T, int H, int Dout, int avg, sgStream stream) {
+  SG_ARG_CHECK(g_pooled && edges && csr_off && g_new_t && T >= 0, "sg_pool_bwd: bad arguments");
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(T), dim3(row_threads(2 * H + Dout)), 0, (hipStream_t)stream, g_pooled, g_new_p,
+                     edges, csr_off, g_new_t, H, Dout, avg);
+  SG_LAUNCH_CHECK("sg_pool_bwd");
+  return 0;
+}
+
+extern "C" int sg_embedding_fwd(const float* table, const int64_t* idx, float* out, int n, int dim, sgStream stream) {
+  SG_ARG_CHECK(table && idx && out && n >= 0 && dim > 0, "sg_embedding_fwd: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(n), dim3(row_threads(dim)), 0, (hipStream_t)stream, table, idx, out, dim);
+  SG_LAUNCH_CHECK("sg_embedding_fwd");
+  return 0;
+}
+
+extern "C" int sg_embedding_bwd(const float* g, const int64_t* idx, float* g_table, int n, int num_rows, int dim,
+                                sgStream stream) {
+  SG_ARG_CHECK(g && idx && g_table && num_rows > 0 && dim > 0, "sg_embedding_bwd: bad arguments");
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(num_rows), dim3(row_threads(dim)), 0, (hipStream_t)stream, g, idx, g_table,
+                     n, dim);
+  SG_LAUNCH_CHECK("sg_embedding_bwd");
+  return 0;
+}
+
+extern "C" int sg_copy_cols(const float* src, int src_ld, int src_off, float* dst, int dst_ld, int dst_off, int rows,
+                            int width, sgStream stream) {
+  SG_ARG_CHECK(src && dst && rows >= 0 && width > 0, "sg_copy_cols: bad arguments");
+  if (rows == 0) return 0;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(sg_cdiv((size_t)rows * width, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     src_ld, src_off, dst, dst_ld, dst_off, rows, width);
+  SG_LAUNCH_CHECK("sg_copy_cols");
+  return 0;
+}
+
+extern "C" int sg_one_hot(const int64_t* idx, float* out, int n, int classes, int ld, int col_off, sgStream stream) {
+  SG_ARG_CHECK(idx && out && n >= 0 && classes > 0, "sg_one_hot: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(one_hot_kernel, dim3(sg_cdiv((size_t)n * classes, 256)), dim3(256), 0, (hipStream_t)stream, idx, out, n,
+                     classes, ld, col_off);
+  SG_LAUNCH_CHECK("sg_one_hot");
+  return 0;
+}

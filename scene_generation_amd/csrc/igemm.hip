@@ -1,0 +1,695 @@
+// Implicit-GEMM family on v_mfma_f32_32x32x2_f32 (exact fp32; gfx950 f32 MFMA peak 157.3 TFLOP/s).
+//
+// One kernel template  C[M,N] = sum_k A[m,k] * B[k,n]  with pluggable operand loaders + epilogues:
+//   conv2d fwd      : A = W [Cout][Cin*KS*KS] (k-contiguous), B = im2col gather of x (never materialised)
+//   conv2d dgrad    : A = W^T [Cin][Cout*KS*KS],              B = transposed gather of gy
+//   convT  fwd/dgrad: the two above with roles swapped
+//   conv   wgrad    : A = gy [img][Cout][pix] (k = img*pix),  B = gather of x, N = Cin*KS*KS, split-K slabs
+//   linear fwd/bwd  : plain strided operands
+// Data flow per workgroup (256 threads = 4 wave64, one per SIMD): global -> registers (next tile, in
+// flight during the MFMAs) -> LDS [BK][BM+4] / [BK][BN+4] (k-major, +4 pad: conflict-free b32 fragment
+// reads, <=2-way on writes) -> one VGPR per operand per MFMA.  Reflection padding, nearest x2 upsampling
+// and the (layout, image) channel concat are folded into the gather index, so none is materialised.
+// Replaces the cuDNN/ATen conv + addmm kernels the reference dispatches (see include/sg2im_hip.h).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 16;
+
+template <int BM_, int BN_, int WGM_>
+struct TileCfg {
+  static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = 4 / WGM_;
+  static constexpr int WM = BM / WGM, WN = BN / WGN;
+  static constexpr int TM = WM / 32, TN = WN / 32;
+  static constexpr int LDA = BM + 4, LDB = BN + 4;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Operand loaders.  Each keeps its per-thread staging registers; load() issues the global reads for
+// the k-tile [k0, k0+BK) (zero-filled outside [.., kend) and outside the matrix), store() writes them
+// to the LDS tile laid out [BK][BX+4].
+// ------------------------------------------------------------------------------------------------
+
+// rows of length K contiguous in memory: elem(x, k) = base[x*ld + k]
+template <int BX>
+struct LoadKContig {
+  const float* base; int ld; int X; int vec;      // vec: ld%4==0 && base 16B aligned
+  static constexpr int PASSES = BX >= 64 ? BX / 64 : 1;
+  float r[PASSES * 4];
+  int x0_, xr_, kq_;
+  __device__ __forceinline__ void init(int x0, int tid) { x0_ = x0; xr_ = tid >> 2; kq_ = (tid & 3) * 4; }
+  __device__ __forceinline__ void load(int k0, int kend) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int xl = xr_ + p * 64;
+      const int x = x0_ + xl, k = k0 + kq_;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (xl < BX && x < X) {
+        const float* src = base + (size_t)x * ld + k;
+        if (vec && k + 3 < kend) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          if (k + 0 < kend) v.x = src[0];
+          if (k + 1 < kend) v.y = src[1];
+          if (k + 2 < kend) v.z = src[2];
+          if (k + 3 < kend) v.w = src[3];
+        }
+      }
+      r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
+    }
+  }
+  __device__ __forceinline__ void store(float* T) const {
+    constexpr int LD = BX + 4;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int xl = xr_ + p * 64;
+      if (xl < BX) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) T[(kq_ + i) * LD + xl] = r[p * 4 + i];
+      }
+    }
+  }
+};
+
+// the M/N index contiguous in memory: elem(x, k) = base[k*ld + x]
+template <int BX>
+struct LoadXContig {
+  const float* base; int ld; int X;
+  static constexpr int ROWS = BX * BK / 256;
+  float r[ROWS];
+  int x_, xl_, kr_;
+  __device__ __forceinline__ void init(int x0, int tid) { xl_ = tid % BX; x_ = x0 + xl_; kr_ = (tid / BX) * ROWS; }
+  __device__ __forceinline__ void load(int k0, int kend) {
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const int k = k0 + kr_ + i;
+      r[i] = (x_ < X && k < kend) ? base[(size_t)k * ld + x_] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void store(float* T) const {
+    constexpr int LD = BX + 4;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) T[(kr_ + i) * LD + xl_] = r[i];
+  }
+};
+
+// geometry of a gathered (im2col-style) operand
+struct Gather {
+  const float* src1; const float* src2;  // channel-concatenated sources (src2 may be null)
+  int C1, C2;                            // channels per source
+  int SH, SW;                            // stored spatial size
+  int LH, LW;                            // logical size (= SH<<ushift)
+  int ushift;                            // 1: nearest x2 upsample folded in
+  int PH, PW;                            // pixel grid the OTHER index runs over (output grid)
+  int stride, sshift, pad, reflect;
+  int bcast2;                            // src2 is [img][C2], broadcast over the spatial grid
+};
+
+template <int MODE>
+__device__ __forceinline__ float gather_fetch(const Gather& g, int img, int ah, int aw, int c, int kh, int kw) {
+  if (MODE == 0) {            // source position = out*stride - pad + tap   (conv-style)
+    int ih = ah + kh, iw = aw + kw;
+    if (g.reflect) {
+      ih = ih < 0 ? -ih : ih; ih = ih >= g.LH ? 2 * g.LH - 2 - ih : ih;
+      iw = iw < 0 ? -iw : iw; iw = iw >= g.LW ? 2 * g.LW - 2 - iw : iw;
+    } else if ((unsigned)ih >= (unsigned)g.LH || (unsigned)iw >= (unsigned)g.LW) {
+      return 0.f;
+    }
+    ih >>= g.ushift; iw >>= g.ushift;
+    if (c < g.C1) return g.src1[((size_t)(img * g.C1 + c) * g.SH + ih) * g.SW + iw];
+    if (g.bcast2) return g.src2[(size_t)img * g.C2 + (c - g.C1)];
+    return g.src2[((size_t)(img * g.C2 + (c - g.C1)) * g.SH + ih) * g.SW + iw];
+  } else {                    // source position = (out + pad - tap)/stride if divisible (transposed conv)
+    int th = ah - kh, tw = aw - kw;
+    if ((th | tw) < 0) return 0.f;
+    const int smask = g.stride - 1;
+    if ((th | tw) & smask) return 0.f;
+    th >>= g.sshift; tw >>= g.sshift;
+    if (th >= g.SH || tw >= g.SW) return 0.f;
+    return g.src1[((size_t)(img * g.C1 + c) * g.SH + th) * g.SW + tw];
+  }
+}
+
+// B operand of conv fwd / dgrad: k = (c, kh, kw), n = (img, ph, pw).  One pixel per thread, ROWS taps.
+template <int BN, int KS, int MODE>
+struct LoadGatherKN {
+  Gather g; int Npix;
+  static constexpr int ROWS = BN * BK / 256;
+  float r[ROWS];
+  int nl_, kr_, img_, ah_, aw_, ok_;
+  __device__ __forceinline__ void init(int n0, int tid) {
+    nl_ = tid % BN; kr_ = (tid / BN) * ROWS;
+    const int n = n0 + nl_;
+    ok_ = n < Npix;
+    const int nn = ok_ ? n : 0;
+    const int phw = g.PH * g.PW;
+    img_ = nn / phw;
+    const int pix = nn - img_ * phw;
+    const int ph = pix / g.PW, pw = pix - ph * g.PW;
+    if (MODE == 0) { ah_ = ph * g.stride - g.pad; aw_ = pw * g.stride - g.pad; }
+    else { ah_ = ph + g.pad; aw_ = pw + g.pad; }
+  }
+  __device__ __forceinline__ void load(int k0, int kend) {
+    int k = k0 + kr_;
+    int c = k / (KS * KS);
+    int rr = k - c * (KS * KS);
+    int kh = rr / KS, kw = rr - kh * KS;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      float v = 0.f;
+      if (ok_ && k + i < kend) v = gather_fetch<MODE>(g, img_, ah_, aw_, c, kh, kw);
+      r[i] = v;
+      if (++kw == KS) { kw = 0; if (++kh == KS) { kh = 0; ++c; } }
+    }
+  }
+  __device__ __forceinline__ void store(float* T) const {
+    constexpr int LD = BN + 4;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) T[(kr_ + i) * LD + nl_] = r[i];
+  }
+};
+
+// A operand of wgrad: elem(m, k) = base[(img*Mtot + m)*PQ + pix], k = img*PQ + pix.  Lanes run along k.
+template <int BM>
+struct LoadPixK {
+  const float* base; int M, Mtot, PQ;
+  static constexpr int ROWS = BM / 16;
+  float r[ROWS];
+  int m0_, mr_, kl_;
+  __device__ __forceinline__ void init(int m0, int tid) { m0_ = m0; kl_ = tid & 15; mr_ = tid >> 4; }
+  __device__ __forceinline__ void load(int k0, int kend) {
+    const int k = k0 + kl_;
+    const bool kok = k < kend;
+    const int kk = kok ? k : 0;
+    const int img = kk / PQ, pix = kk - img * PQ;
+    const float* p = base + (size_t)img * Mtot * PQ + pix;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const int m = m0_ + mr_ + 16 * i;
+      r[i] = (kok && m < M) ? p[(size_t)m * PQ] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void store(float* T) const {
+    constexpr int LD = BM + 4;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) T[kl_ * LD + mr_ + 16 * i] = r[i];
+  }
+};
+
+// B operand of wgrad: k = (img, ph, pw) over the gy grid, n = (c, kh, kw).  Lanes run along k (pixels).
+template <int BN, int KS>
+struct LoadGatherNK {
+  Gather g; int Ncols;
+  static constexpr int COLS = BN / 16;
+  float r[COLS];
+  int kl_, nr_;
+  int c_[COLS]; int khw_[COLS];
+  __device__ __forceinline__ void init(int n0, int tid) {
+    kl_ = tid & 15; nr_ = tid >> 4;
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) {
+      const int n = n0 + nr_ + 16 * j;
+      if (n < Ncols) {
+        const int c = n / (KS * KS);
+        const int rr = n - c * (KS * KS);
+        const int kh = rr / KS;
+        c_[j] = c; khw_[j] = (kh << 8) | (rr - kh * KS);
+      } else { c_[j] = -1; khw_[j] = 0; }
+    }
+  }
+  __device__ __forceinline__ void load(int k0, int kend) {
+    const int k = k0 + kl_;
+    const bool kok = k < kend;
+    const int kk = kok ? k : 0;
+    const int phw = g.PH * g.PW;
+    const int img = kk / phw, pix = kk - img * phw;
+    const int ph = pix / g.PW, pw = pix - ph * g.PW;
+    const int ah = ph * g.stride - g.pad, aw = pw * g.stride - g.pad;
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) {
+      float v = 0.f;
+      if (kok && c_[j] >= 0) v = gather_fetch<0>(g, img, ah, aw, c_[j], khw_[j] >> 8, khw_[j] & 255);
+      r[j] = v;
+    }
+  }
+  __device__ __forceinline__ void store(float* T) const {
+    constexpr int LD = BN + 4;
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) T[kl_ * LD + nr_ + 16 * j] = r[j];
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Epilogues.  Accumulator register r of a 32x32 tile <-> row (r&3)+8*(r>>2)+4*(lane>>5), col lane&31.
+// ------------------------------------------------------------------------------------------------
+struct EpNCHW {     // out[img][m_off+m][pix], n = img*PHW + pix ; bias per row m
+  float* out; const float* bias; int PHW, Mtot, M, Npix, act; float slope;
+  template <int TM, int TN>
+  __device__ __forceinline__ void store(f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int z) const {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nbase + j * 32 + (lane & 31);
+      if (n >= Npix) continue;
+      const int img = n / PHW, pix = n - img * PHW;
+      float* o = out + (size_t)img * Mtot * PHW + pix;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < M) {
+            float v = acc[i][j][r];
+            if (bias) v += bias[m];
+            o[(size_t)m * PHW] = sg_apply_act(v, act, slope);
+          }
+        }
+      }
+    }
+  }
+};
+
+struct EpRowMajor {  // out[z][m*ldc + n] ; bias per column n
+  float* out; const float* bias; int M, N, ldc, act; float slope; size_t zstride;
+  template <int TM, int TN>
+  __device__ __forceinline__ void store(f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int z) const {
+    float* o = out + (size_t)z * zstride;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nbase + j * 32 + (lane & 31);
+      if (n >= N) continue;
+      const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < M) o[(size_t)m * ldc + n] = sg_apply_act(acc[i][j][r] + b, act, slope);
+        }
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// The kernel
+// ------------------------------------------------------------------------------------------------
+template <class CFG, class AL, class BL, class EP>
+__global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int kchunk) {
+  constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, LDA = CFG::LDA, LDB = CFG::LDB;
+  __shared__ float As[2][BK * LDA];
+  __shared__ float Bs[2][BK * LDB];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm0 = (wid / CFG::WGN) * CFG::WM, wn0 = (wid % CFG::WGN) * CFG::WN;
+
+  // XCD-aware, bijective tile remap: consecutive tiles (same weight rows, overlapping gathers) share an L2
+  const int tiles_n = (N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  }
+  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  const int kbeg = blockIdx.z * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+
+  al.init(m0, tid);
+  bl.init(n0, tid);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  al.load(kbeg, kend);
+  bl.load(kbeg, kend);
+  al.store(As[0]);
+  bl.store(Bs[0]);
+  __syncthreads();
+
+  const int lr = lane & 31, lk = lane >> 5;
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
+    if (more) { al.load(k0 + BK, kend); bl.load(k0 + BK, kend); }
+    const float* A_ = As[buf];
+    const float* B_ = Bs[buf];
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = A_[(ks + lk) * LDA + wm0 + i * 32 + lr];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = B_[(ks + lk) * LDB + wn0 + j * 32 + lr];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) { al.store(As[buf ^ 1]); bl.store(Bs[buf ^ 1]); }
+    __syncthreads();
+    buf ^= 1;
+  }
+  ep.store(acc, m0 + wm0, n0 + wn0, lane, blockIdx.z);
+}
+
+using Cfg128 = TileCfg<128, 128, 2>;
+using Cfg64 = TileCfg<64, 64, 2>;
+using Cfg32 = TileCfg<32, 128, 1>;
+
+inline int pick_tile(int M, int N) {
+  if (M <= 32) return 2;
+  const long t128 = (long)sg_cdiv(M, 128) * sg_cdiv(N, 128);
+  if (M >= 96 && t128 >= 384) return 0;
+  return 1;
+}
+
+template <class CFG, class AL, class BL, class EP>
+int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int splits, hipStream_t s) {
+  const int tiles = sg_cdiv(M, CFG::BM) * sg_cdiv(N, CFG::BN);
+  int kchunk = K;
+  if (splits > 1) kchunk = sg_cdiv(sg_cdiv(K, splits), BK) * BK;
+  dim3 grid(tiles, 1, splits > 1 ? sg_cdiv(K, kchunk) : 1);
+  hipLaunchKernelGGL((igemm_kernel<CFG, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, N, K, kchunk);
+  return 0;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// sum split-K slabs: out[i] = sum_z ws[z*n + i]   (fixed order => deterministic)
+__global__ void slab_reduce_kernel(const float* ws, float* out, size_t n, int S) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = 0.f;
+  for (int z = 0; z < S; ++z) v += ws[(size_t)z * n + i];
+  out[i] = v;
+}
+
+// Wt[b][a][r] = W[a][b][r]
+__global__ void permute_w_kernel(const float* W, float* Wt, int A, int B, int R) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)A * B * R;
+  if (i >= n) return;
+  const int r = i % R;
+  const size_t ab = i / R;
+  const int a = ab % A;
+  const int b = ab / A;
+  Wt[i] = W[((size_t)a * B + b) * R + r];
+}
+
+Gather make_gather(const float* s1, const float* s2, int C1, int C2, int SH, int SW, int ups, int PH, int PW,
+                   int stride, int pad, int reflect) {
+  Gather g;
+  g.src1 = s1; g.src2 = s2; g.C1 = C1; g.C2 = C2; g.SH = SH; g.SW = SW;
+  g.ushift = ups == 2 ? 1 : 0; g.LH = SH << g.ushift; g.LW = SW << g.ushift;
+  g.PH = PH; g.PW = PW; g.stride = stride; g.sshift = stride == 2 ? 1 : 0; g.pad = pad; g.reflect = reflect;
+  g.bcast2 = 0;
+  return g;
+}
+
+// ---- conv-shaped GEMM: K = (c, taps), N = pixels -------------------------------------------------
+template <int KS, int MODE>
+int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* bias, float* out, int Mtot, int act,
+           float slope, hipStream_t s) {
+  const int Npix = NB * g.PH * g.PW;
+  EpNCHW ep{out, bias, g.PH * g.PW, Mtot, M, Npix, act, slope};
+  const int vec = (K % 4 == 0) && aligned16(A);
+  switch (pick_tile(M, Npix)) {
+    case 0: {
+      LoadKContig<128> al{A, K, M, vec};
+      LoadGatherKN<128, KS, MODE> bl{g, Npix};
+      return launch_cfg<Cfg128>(al, bl, ep, M, Npix, K, 1, s);
+    }
+    case 1: {
+      LoadKContig<64> al{A, K, M, vec};
+      LoadGatherKN<64, KS, MODE> bl{g, Npix};
+      return launch_cfg<Cfg64>(al, bl, ep, M, Npix, K, 1, s);
+    }
+    default: {
+      LoadKContig<32> al{A, K, M, vec};
+      LoadGatherKN<128, KS, MODE> bl{g, Npix};
+      return launch_cfg<Cfg32>(al, bl, ep, M, Npix, K, 1, s);
+    }
+  }
+}
+
+template <int MODE>
+int run_kn_ks(int KS, const float* A, int M, int K, const Gather& g, int NB, const float* bias, float* out, int Mtot,
+              int act, float slope, hipStream_t s) {
+  switch (KS) {
+    case 1: return run_kn<1, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, s);
+    case 3: return run_kn<3, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, s);
+    case 4: return run_kn<4, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, s);
+    case 7: return run_kn<7, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, s);
+  }
+  return -1;
+}
+
+// ---- wgrad-shaped GEMM: K = (img, pix), N = (c, taps) --------------------------------------------
+inline int wgrad_splits(int M, int Ncols, int Kpix) {
+  const long tiles = (long)sg_cdiv(M, M <= 32 ? 32 : 64) * sg_cdiv(Ncols, M <= 32 ? 128 : 64);
+  int s = (int)((768 + tiles - 1) / tiles);
+  const int maxs = Kpix / (BK * 8) > 0 ? Kpix / (BK * 8) : 1;
+  if (s > maxs) s = maxs;
+  if (s > 64) s = 64;
+  return s < 1 ? 1 : s;
+}
+
+template <int KS>
+int run_nk(const float* A, int M, int Mtot, const Gather& g, int NB, float* out, void* ws, size_t ws_bytes,
+           hipStream_t s) {
+  const int PQ = g.PH * g.PW;
+  const int Kpix = NB * PQ;
+  const int Ncols = (g.C1 + g.C2) * KS * KS;
+  int splits = wgrad_splits(M, Ncols, Kpix);
+  const size_t mn = (size_t)M * Ncols;
+  if (splits > 1 && ws_bytes < mn * sizeof(float) * (size_t)splits) splits = (int)(ws_bytes / (mn * sizeof(float)));
+  if (splits < 2) splits = 1;
+  int kchunk = sg_cdiv(sg_cdiv(Kpix, splits), BK) * BK;
+  splits = sg_cdiv(Kpix, kchunk);
+  float* dst = splits > 1 ? reinterpret_cast<float*>(ws) : out;
+  EpRowMajor ep{dst, nullptr, M, Ncols, Ncols, SG_ACT_NONE, 0.f, mn};
+  if (M <= 32) {
+    LoadPixK<32> al{A, M, Mtot, PQ};
+    LoadGatherNK<128, KS> bl{g, Ncols};
+    launch_cfg<Cfg32>(al, bl, ep, M, Ncols, Kpix, splits, s);
+  } else if ((long)sg_cdiv(M, 128) * sg_cdiv(Ncols, 128) >= 384) {
+    LoadPixK<128> al{A, M, Mtot, PQ};
+    LoadGatherNK<128, KS> bl{g, Ncols};
+    launch_cfg<Cfg128>(al, bl, ep, M, Ncols, Kpix, splits, s);
+  } else {
+    LoadPixK<64> al{A, M, Mtot, PQ};
+    LoadGatherNK<64, KS> bl{g, Ncols};
+    launch_cfg<Cfg64>(al, bl, ep, M, Ncols, Kpix, splits, s);
+  }
+  if (splits > 1) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(sg_cdiv(mn, 256)), dim3(256), 0, s, (const float*)ws, out, mn,
+                       splits);
+  }
+  return 0;
+}
+
+int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, float* out, void* ws, size_t ws_bytes,
+              hipStream_t s) {
+  switch (KS) {
+    case 1: return run_nk<1>(A, M, Mtot, g, NB, out, ws, ws_bytes, s);
+    case 3: return run_nk<3>(A, M, Mtot, g, NB, out, ws, ws_bytes, s);
+    case 4: return run_nk<4>(A, M, Mtot, g, NB, out, ws, ws_bytes, s);
+    case 7: return run_nk<7>(A, M, Mtot, g, NB, out, ws, ws_bytes, s);
+  }
+  return -1;
+}
+
+int check_desc(const sgConvDesc* d, const char* who) {
+  SG_ARG_CHECK(d != nullptr, "%s: null desc", who);
+  SG_ARG_CHECK(d->KS == 1 || d->KS == 3 || d->KS == 4 || d->KS == 7, "%s: kernel size %d unsupported", who, d->KS);
+  SG_ARG_CHECK(d->stride == 1 || d->stride == 2, "%s: stride %d unsupported", who, d->stride);
+  SG_ARG_CHECK(d->upsample == 1 || d->upsample == 2, "%s: upsample %d unsupported", who, d->upsample);
+  SG_ARG_CHECK(d->N > 0 && d->C1 > 0 && d->C2 >= 0 && d->Cout > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0,
+               "%s: non-positive dimension", who);
+  SG_ARG_CHECK(!d->pad_reflect || d->pad < d->H * d->upsample, "%s: reflect pad too large", who);
+  return 0;
+}
+
+inline size_t wgrad_ws(int M, int Ncols, int Kpix) {
+  return (size_t)wgrad_splits(M, Ncols, Kpix) * (size_t)M * Ncols * sizeof(float);
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" size_t sg_conv2d_ws_bytes(const sgConvDesc* d, int kind) {
+  if (!d) return 0;
+  const size_t wbytes = (size_t)d->Cout * (d->C1 + d->C2) * d->KS * d->KS * sizeof(float);
+  if (kind == 0) return wbytes;                    // convT fwd: transposed weights
+  if (kind == 1) return wbytes;                    // conv dgrad: transposed weights
+  const int M = d->Cout > (d->C1 + d->C2) ? d->Cout : (d->C1 + d->C2);
+  const int Kp = d->N * (d->OH * d->OW > d->H * d->W ? d->OH * d->OW : d->H * d->W);
+  size_t a = wgrad_ws(d->Cout, (d->C1 + d->C2) * d->KS * d->KS, d->N * d->OH * d->OW);
+  size_t b = wgrad_ws(d->C1 + d->C2, d->Cout * d->KS * d->KS, d->N * d->H * d->W);
+  (void)M; (void)Kp;
+  return a > b ? a : b;
+}
+
+extern "C" int sg_conv2d_fwd(const sgConvDesc* d, const float* x1, const float* x2, const float* w, const float* bias,
+                             float* y, int act, float slope, sgStream stream) {
+  if (check_desc(d, "sg_conv2d_fwd")) return -1;
+  SG_ARG_CHECK(x1 && w && y, "sg_conv2d_fwd: null pointer");
+  SG_ARG_CHECK(d->C2 == 0 || x2, "sg_conv2d_fwd: C2>0 but x2 null");
+  hipStream_t s = (hipStream_t)stream;
+  const int Cin = d->C1 + d->C2, K = Cin * d->KS * d->KS;
+  Gather g = make_gather(x1, x2, d->C1, d->C2, d->H, d->W, d->upsample, d->OH, d->OW, d->stride, d->pad, d->pad_reflect);
+  g.bcast2 = d->x2_broadcast;
+  SgProfScope prof(SG_K_CONV_FWD, s, 2.0 * d->Cout * K * (double)d->N * d->OH * d->OW, 0);
+  int rc = run_kn_ks<0>(d->KS, w, d->Cout, K, g, d->N, bias, y, d->Cout, act, slope, s);
+  SG_LAUNCH_CHECK("sg_conv2d_fwd");
+  return rc;
+}
+
+extern "C" int sg_conv2d_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, int c_begin, int c_end,
+                               void* ws, size_t ws_bytes, sgStream stream) {
+  if (check_desc(d, "sg_conv2d_dgrad")) return -1;
+  const int Cin = d->C1 + d->C2, R = d->KS * d->KS;
+  SG_ARG_CHECK(gy && w && gx && ws, "sg_conv2d_dgrad: null pointer");
+  SG_ARG_CHECK(0 <= c_begin && c_begin < c_end && c_end <= Cin, "sg_conv2d_dgrad: bad channel range [%d,%d)", c_begin, c_end);
+  SG_ARG_CHECK(ws_bytes >= (size_t)d->Cout * Cin * R * sizeof(float), "sg_conv2d_dgrad: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* wt = reinterpret_cast<float*>(ws);      // [Cin][Cout][R]
+  const size_t nw = (size_t)d->Cout * Cin * R;
+  hipLaunchKernelGGL(permute_w_kernel, dim3(sg_cdiv(nw, 256)), dim3(256), 0, s, w, wt, d->Cout, Cin, R);
+  // gradient w.r.t. the logical (upsampled, reflect-padded) input grid
+  const int GH = d->H * d->upsample + (d->pad_reflect ? 2 * d->pad : 0);
+  const int GW = d->W * d->upsample + (d->pad_reflect ? 2 * d->pad : 0);
+  const int pad = d->pad_reflect ? 0 : d->pad;
+  Gather g = make_gather(gy, nullptr, d->Cout, 0, d->OH, d->OW, 1, GH, GW, d->stride, pad, 0);
+  const int M = c_end - c_begin, K = d->Cout * R;
+  SgProfScope prof(SG_K_CONV_DGRAD, s, 2.0 * M * K * (double)d->N * GH * GW / (d->stride * d->stride), 0);
+  int rc = run_kn_ks<1>(d->KS, wt + (size_t)c_begin * K, M, K, g, d->N, nullptr, gx, M, SG_ACT_NONE, 0.f, s);
+  SG_LAUNCH_CHECK("sg_conv2d_dgrad");
+  return rc;
+}
+
+extern "C" int sg_conv2d_wgrad(const sgConvDesc* d, const float* gy, const float* x1, const float* x2, float* gw,
+                               float* gb, void* ws, size_t ws_bytes, sgStream stream) {
+  if (check_desc(d, "sg_conv2d_wgrad")) return -1;
+  SG_ARG_CHECK(gy && x1 && gw, "sg_conv2d_wgrad: null pointer");
+  SG_ARG_CHECK(d->C2 == 0 || x2, "sg_conv2d_wgrad: C2>0 but x2 null");
+  hipStream_t s = (hipStream_t)stream;
+  Gather g = make_gather(x1, x2, d->C1, d->C2, d->H, d->W, d->upsample, d->OH, d->OW, d->stride, d->pad, d->pad_reflect);
+  g.bcast2 = d->x2_broadcast;
+  const double flops = 2.0 * d->Cout * (double)(d->C1 + d->C2) * d->KS * d->KS * d->N * d->OH * d->OW;
+  {
+    SgProfScope prof(SG_K_CONV_WGRAD, s, flops, 0);
+    run_nk_ks(d->KS, gy, d->Cout, d->Cout, g, d->N, gw, ws, ws ? ws_bytes : 0, s);
+  }
+  SG_LAUNCH_CHECK("sg_conv2d_wgrad");
+  if (gb) return sg_channel_sum(gy, gb, d->N, d->Cout, d->OH * d->OW, stream);
+  return 0;
+}
+
+// ConvTranspose2d: y[n,co,oh,ow] = b + sum_{ci,kh,kw} w[ci,co,kh,kw] x[n,ci,(oh+p-kh)/s,(ow+p-kw)/s]
+extern "C" int sg_convT2d_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y,
+                              void* ws, size_t ws_bytes, sgStream stream) {
+  if (check_desc(d, "sg_convT2d_fwd")) return -1;
+  SG_ARG_CHECK(x && w && y && ws, "sg_convT2d_fwd: null pointer");
+  const int Cin = d->C1, R = d->KS * d->KS;
+  SG_ARG_CHECK(d->C2 == 0 && d->upsample == 1 && !d->pad_reflect, "sg_convT2d_fwd: unsupported desc");
+  SG_ARG_CHECK(ws_bytes >= (size_t)d->Cout * Cin * R * sizeof(float), "sg_convT2d_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* wt = reinterpret_cast<float*>(ws);      // [Cout][Cin][R]
+  const size_t nw = (size_t)d->Cout * Cin * R;
+  hipLaunchKernelGGL(permute_w_kernel, dim3(sg_cdiv(nw, 256)), dim3(256), 0, s, w, wt, Cin, d->Cout, R);
+  Gather g = make_gather(x, nullptr, Cin, 0, d->H, d->W, 1, d->OH, d->OW, d->stride, d->pad, 0);
+  SgProfScope prof(SG_K_CONV_FWD, s, 2.0 * d->Cout * Cin * R * (double)d->N * d->H * d->W, 0);
+  int rc = run_kn_ks<1>(d->KS, wt, d->Cout, Cin * R, g, d->N, bias, y, d->Cout, SG_ACT_NONE, 0.f, s);
+  SG_LAUNCH_CHECK("sg_convT2d_fwd");
+  return rc;
+}
+
+// gx[n,ci,ih,iw] = sum_{co,kh,kw} w[ci,co,kh,kw] gy[n,co,ih*s-p+kh,iw*s-p+kw]   (a plain strided conv over gy)
+extern "C" int sg_convT2d_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, sgStream stream) {
+  if (check_desc(d, "sg_convT2d_dgrad")) return -1;
+  SG_ARG_CHECK(gy && w && gx, "sg_convT2d_dgrad: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int R = d->KS * d->KS;
+  Gather g = make_gather(gy, nullptr, d->Cout, 0, d->OH, d->OW, 1, d->H, d->W, d->stride, d->pad, 0);
+  SgProfScope prof(SG_K_CONV_DGRAD, s, 2.0 * d->Cout * d->C1 * R * (double)d->N * d->H * d->W, 0);
+  int rc = run_kn_ks<0>(d->KS, w, d->C1, d->Cout * R, g, d->N, nullptr, gx, d->C1, SG_ACT_NONE, 0.f, s);
+  SG_LAUNCH_CHECK("sg_convT2d_dgrad");
+  return rc;
+}
+
+// gw[ci,co,kh,kw] = sum_{n,ih,iw} x[n,ci,ih,iw] gy[n,co,ih*s-p+kh,iw*s-p+kw]
+extern "C" int sg_convT2d_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, float* gb, void* ws,
+                                size_t ws_bytes, sgStream stream) {
+  if (check_desc(d, "sg_convT2d_wgrad")) return -1;
+  SG_ARG_CHECK(gy && x && gw, "sg_convT2d_wgrad: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  Gather g = make_gather(gy, nullptr, d->Cout, 0, d->OH, d->OW, 1, d->H, d->W, d->stride, d->pad, 0);
+  {
+    SgProfScope prof(SG_K_CONV_WGRAD, s, 2.0 * d->Cout * (double)d->C1 * d->KS * d->KS * d->N * d->H * d->W, 0);
+    run_nk_ks(d->KS, x, d->C1, d->C1, g, d->N, gw, ws, ws ? ws_bytes : 0, s);
+  }
+  SG_LAUNCH_CHECK("sg_convT2d_wgrad");
+  if (gb) return sg_channel_sum(gy, gb, d->N, d->Cout, d->OH * d->OW, stream);
+  return 0;
+}
+
+// ---- dense layers --------------------------------------------------------------------------------
+namespace {
+template <class AL64, class BL64, class AL32, class BL128>
+int run_dense(const AL64& a64, const BL64& b64, const AL32& a32, const BL128& b128, const EpRowMajor& ep, int M, int N,
+              int K, hipStream_t s) {
+  if (M <= 32) return launch_cfg<Cfg32>(a32, b128, ep, M, N, K, 1, s);
+  return launch_cfg<Cfg64>(a64, b64, ep, M, N, K, 1, s);
+}
+}  // namespace
+
+extern "C" int sg_linear_fwd(const float* x, const float* w, const float* b, float* y, int rows, int in_f, int out_f,
+                             int act, float slope, sgStream stream) {
+  SG_ARG_CHECK(x && w && y && rows > 0 && in_f > 0 && out_f > 0, "sg_linear_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  EpRowMajor ep{y, b, rows, out_f, out_f, act, slope, 0};
+  const int va = (in_f % 4 == 0) && aligned16(x), vb = (in_f % 4 == 0) && aligned16(w);
+  SgProfScope prof(SG_K_LINEAR, s, 2.0 * rows * (double)in_f * out_f, 0);
+  run_dense(LoadKContig<64>{x, in_f, rows, va}, LoadKContig<64>{w, in_f, out_f, vb}, LoadKContig<32>{x, in_f, rows, va},
+            LoadKContig<128>{w, in_f, out_f, vb}, ep, rows, out_f, in_f, s);
+  SG_LAUNCH_CHECK("sg_linear_fwd");
+  return 0;
+}
+
+extern "C" int sg_linear_bwd_data(const float* gy, const float* w, float* gx, int rows, int in_f, int out_f,
+                                  sgStream stream) {
+  SG_ARG_CHECK(gy && w && gx && rows > 0 && in_f > 0 && out_f > 0, "sg_linear_bwd_data: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  EpRowMajor ep{gx, nullptr, rows, in_f, in_f, SG_ACT_NONE, 0.f, 0};
+  const int va = (out_f % 4 == 0) && aligned16(gy);
+  SgProfScope prof(SG_K_LINEAR, s, 2.0 * rows * (double)in_f * out_f, 0);
+  run_dense(LoadKContig<64>{gy, out_f, rows, va}, LoadXContig<64>{w, in_f, in_f}, LoadKContig<32>{gy, out_f, rows, va},
+            LoadXContig<128>{w, in_f, in_f}, ep, rows, in_f, out_f, s);
+  SG_LAUNCH_CHECK("sg_linear_bwd_data");
+  return 0;
+}
+
+extern "C" int sg_linear_bwd_weight(const float* gy, const float* x, float* gw, float* gb, int rows, int in_f,
+                                    int out_f, sgStream stream) {
+  SG_ARG_CHECK(gy && x && gw && rows > 0 && in_f > 0 && out_f > 0, "sg_linear_bwd_weight: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  EpRowMajor ep{gw, nullptr, out_f, in_f, in_f, SG_ACT_NONE, 0.f, 0};
+  {
+    SgProfScope prof(SG_K_LINEAR, s, 2.0 * rows * (double)in_f * out_f, 0);
+    run_dense(LoadXContig<64>{gy, out_f, out_f}, LoadXContig<64>{x, in_f, in_f}, LoadXContig<32>{gy, out_f, out_f},
+              LoadXContig<128>{x, in_f, in_f}, ep, out_f, in_f, rows, s);
+  }
+  SG_LAUNCH_CHECK("sg_linear_bwd_weight");
+  if (gb) return sg_channel_sum(gy, gb, rows, out_f, 1, stream);   // column sums of gy[rows][out_f]
+  return 0;
+}

@@ -1,0 +1,379 @@
+// Layout scatter + bilinear crops (HBM-bound).
+//
+// masks_to_layout (layout.py:64-93,96-128,131-155): the reference materialises vecs (x) masks as an
+// (O, D, M, M) tensor, grid_samples it to (O, D, H, W) (3.85 GB at N=32/128^2) and sums per image in a
+// Python loop.  Here each workgroup owns one image x one tile of pixels: it samples every object's
+// mask ONCE per pixel into LDS (S_o[h,w], the factored form of SURVEY appendix D.2), then streams the
+// D output channels out as float4 rows, out[n,d,px] = sum_o vecs[o,d] * S_o[px]  (ascending o).
+// Algorithmic traffic = the 4*N*D*H*W output bytes.
+//
+// crop_bbox_batch (bilinear.py:67-130): one gather kernel indexed by box_to_feat -- no per-image
+// nonzero()/expand/cat/inverse-permutation.
+#include "common.h"
+
+namespace {
+
+// torch.linspace(0,1,n)[j] as ATen evaluates it (symmetric halves)
+__device__ __forceinline__ float lin01(int j, int n) {
+  if (n == 1) return 0.f;
+  const float step = 1.f / (float)(n - 1);
+  return j < n / 2 ? step * (float)j : 1.f - step * (float)(n - 1 - j);
+}
+// torch.linspace(1,0,n)[j]
+__device__ __forceinline__ float lin10(int j, int n) {
+  if (n == 1) return 1.f;
+  const float step = -1.f / (float)(n - 1);
+  return j < n / 2 ? 1.f + step * (float)j : 0.f - step * (float)(n - 1 - j);
+}
+
+struct Tap { int i0, i1; float w0, w1; };
+
+// align_corners=False un-normalisation + bilinear taps with zeros padding
+__device__ __forceinline__ Tap make_tap(float g, int size) {
+  Tap t;
+  const float p = ((g + 1.f) * (float)size - 1.f) * 0.5f;
+  if (!(fabsf(p) < 1e8f)) {              // NaN / inf (degenerate box): propagate NaN like grid_sample
+    t.i0 = t.i1 = 0;
+    t.w0 = t.w1 = (p != p) ? p : 0.f;    // inf coordinate => fully outside => 0
+    return t;
+  }
+  const float f = floorf(p);
+  const int i0 = (int)f;
+  t.w1 = p - f;
+  t.w0 = (f + 1.f) - p;
+  t.i0 = i0; t.i1 = i0 + 1;
+  if (t.i0 < 0 || t.i0 >= size) { t.w0 = 0.f; t.i0 = 0; }
+  if (t.i1 < 0 || t.i1 >= size) { t.w1 = 0.f; t.i1 = 0; }
+  return t;
+}
+
+template <bool I64>
+__device__ __forceinline__ float mask_at(const void* masks, size_t o, int M, int y, int x) {
+  if (I64) return (float)reinterpret_cast<const int64_t*>(masks)[(o * M + y) * M + x];
+  return reinterpret_cast<const float*>(masks)[(o * M + y) * M + x];
+}
+
+template <bool I64>
+__device__ __forceinline__ float sample_mask(const void* masks, size_t o, int M, const Tap& ty, const Tap& tx) {
+  // same tap order as grid_sample: nw, ne, sw, se
+  float v = mask_at<I64>(masks, o, M, ty.i0, tx.i0) * (ty.w0 * tx.w0);
+  v += mask_at<I64>(masks, o, M, ty.i0, tx.i1) * (ty.w0 * tx.w1);
+  v += mask_at<I64>(masks, o, M, ty.i1, tx.i0) * (ty.w1 * tx.w0);
+  v += mask_at<I64>(masks, o, M, ty.i1, tx.i1) * (ty.w1 * tx.w1);
+  return v;
+}
+
+__device__ __forceinline__ float box_coord(float lin, float lo, float hi) {   // layout.py:111-126
+  return ((lin - lo) / (hi - lo)) * 2.f - 1.f;
+}
+
+__global__ void segment_offsets_kernel(const int64_t* __restrict__ o2i, int O, int N, int32_t* __restrict__ off) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > O) return;
+  if (i == 0) { for (int n = 0; n <= (O > 0 ? (int)o2i[0] : N); ++n) off[n] = 0; }
+  if (i == O) { for (int n = (O > 0 ? (int)o2i[O - 1] + 1 : 0); n <= N; ++n) off[n] = O; return; }
+  if (i > 0) {
+    const int a = (int)o2i[i - 1], b = (int)o2i[i];
+    for (int n = a + 1; n <= b; ++n) off[n] = i;
+  }
+}
+
+// PXT pixels per workgroup tile, VEC pixels per thread (VEC=4 needs W%4==0).  LDS holds `cap` objects; images
+// with more objects are processed in chunks of `cap` (read-modify-write of the tile for chunks after the first).
+template <bool I64, int VEC>
+__global__ void __launch_bounds__(256) layout_fwd_kernel(const float* __restrict__ vecs, const float* __restrict__ boxes,
+                                                        const void* __restrict__ masks, const int32_t* __restrict__ seg,
+                                                        float* __restrict__ out, int D, int M, int H, int W, int avg,
+                                                        int cap) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int PXT = 256 * VEC;
+  const int n = blockIdx.y;
+  const int o_beg = seg[n], cnt = seg[n + 1] - o_beg;
+  float* S = lds;                       // [cap][PXT]
+  float* V = lds + (size_t)cap * PXT;   // [cap][D]
+  const int tid = threadIdx.x;
+  const int HW = H * W;
+  const int px0 = blockIdx.x * PXT + tid * VEC;
+  const bool live = px0 < HW;
+  const int h = live ? px0 / W : 0, w0 = live ? px0 - h * W : 0;
+  const float Y = lin01(h, H);
+  const float denom = (float)(cnt > 1 ? cnt : 1);
+  float* op = out + (size_t)n * D * HW + (live ? px0 : 0);
+
+  if (cnt == 0) {                       // image without objects: all-zero layout
+    if (live)
+      for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+          if (w0 + v < W) op[(size_t)d * HW + v] = 0.f;
+    return;
+  }
+  for (int c0 = 0; c0 < cnt; c0 += cap) {
+    const int nc = min(cap, cnt - c0);
+    __syncthreads();
+    for (int i = tid; i < nc * D; i += 256) V[i] = vecs[(size_t)(o_beg + c0) * D + i];
+    for (int j = 0; j < nc; ++j) {
+      const size_t o = (size_t)(o_beg + c0 + j);
+      const float x0 = boxes[o * 4 + 0], y0 = boxes[o * 4 + 1], x1 = boxes[o * 4 + 2], y1 = boxes[o * 4 + 3];
+      const Tap ty = make_tap(box_coord(Y, y0, y1), M);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float sv = 0.f;
+        if (live && w0 + v < W) {
+          const Tap tx = make_tap(box_coord(lin01(w0 + v, W), x0, x1), M);
+          sv = sample_mask<I64>(masks, o, M, ty, tx);
+        }
+        S[(size_t)j * PXT + tid * VEC + v] = sv;
+      }
+    }
+    __syncthreads();
+    if (!live) continue;
+    const bool first = c0 == 0, last = c0 + cap >= cnt;
+    for (int d = 0; d < D; ++d) {
+      float acc[VEC];
+      if (first) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+      } else if (VEC == 4) {
+        const float4 r = *reinterpret_cast<const float4*>(op + (size_t)d * HW);
+        acc[0] = r.x; acc[1] = r.y; acc[2] = r.z; acc[3] = r.w;
+      } else {
+        acc[0] = op[(size_t)d * HW];
+      }
+      for (int j = 0; j < nc; ++j) {
+        const float c = V[j * D + d];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float term = c * S[(size_t)j * PXT + tid * VEC + v];
+          acc[v] = (first && j == 0) ? term : acc[v] + term;   // ascending o, same association as the reference sum
+        }
+      }
+      if (avg && last) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = acc[v] / denom;
+      }
+      if (VEC == 4) *reinterpret_cast<float4*>(op + (size_t)d * HW) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      else op[(size_t)d * HW] = acc[0];
+    }
+  }
+}
+
+// g_vecs[o,d] = sum_{h,w} gout[n,d,h,w] * S_o[h,w] : one workgroup per (d, image), S recomputed, block reduce
+template <bool I64>
+__global__ void __launch_bounds__(256) layout_bwd_vecs_kernel(const float* __restrict__ gout, const float* __restrict__ boxes,
+                                                             const void* __restrict__ masks, const int32_t* __restrict__ seg,
+                                                             float* __restrict__ gv, int D, int M, int H, int W, int avg,
+                                                             int d_begin) {
+  __shared__ float red[16];
+  constexpr int OC = 8;
+  const int n = blockIdx.y, d = d_begin + blockIdx.x;
+  const int o_beg = seg[n], cnt = seg[n + 1] - o_beg;
+  const int HW = H * W;
+  const float* gp = gout + ((size_t)n * D + d) * HW;
+  const float denom = avg ? (float)(cnt > 1 ? cnt : 1) : 1.f;
+  for (int c0 = 0; c0 < cnt; c0 += OC) {
+    float acc[OC];
+#pragma unroll
+    for (int j = 0; j < OC; ++j) acc[j] = 0.f;
+    for (int px = threadIdx.x; px < HW; px += 256) {
+      const int h = px / W, w = px - h * W;
+      const float g = gp[px];
+      const float Y = lin01(h, H), X = lin01(w, W);
+#pragma unroll
+      for (int j = 0; j < OC; ++j) {
+        if (c0 + j < cnt) {
+          const size_t o = (size_t)(o_beg + c0 + j);
+          const Tap ty = make_tap(box_coord(Y, boxes[o * 4 + 1], boxes[o * 4 + 3]), M);
+          const Tap tx = make_tap(box_coord(X, boxes[o * 4 + 0], boxes[o * 4 + 2]), M);
+          acc[j] += g * sample_mask<I64>(masks, o, M, ty, tx);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < OC; ++j) {
+      if (c0 + j < cnt) {                      // uniform across the block
+        const float t = sg_block_sum(acc[j], red);
+        if (threadIdx.x == 0) gv[(size_t)(o_beg + c0 + j) * D + d] = t / denom;
+      }
+    }
+  }
+}
+
+__global__ void zero_cols_kernel(float* __restrict__ p, int rows, int ld, int width) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * width) return;
+  const int r = i / width, c = i - (size_t)r * width;
+  p[(size_t)r * ld + c] = 0.f;
+}
+
+// ---------------- crops ---------------------------------------------------------------------------
+__device__ __forceinline__ void crop_taps(const float* __restrict__ boxes, int b, int y, int x, int HH, int WW, int H, int W,
+                                          Tap& ty, Tap& tx) {
+  const float x0 = 2.f * boxes[b * 4 + 0] - 1.f, y0 = 2.f * boxes[b * 4 + 1] - 1.f;
+  const float x1 = 2.f * boxes[b * 4 + 2] - 1.f, y1 = 2.f * boxes[b * 4 + 3] - 1.f;
+  const float gx = lin10(x, WW) * x0 + lin01(x, WW) * x1;     // bilinear.py:266-274
+  const float gy = lin10(y, HH) * y0 + lin01(y, HH) * y1;
+  tx = make_tap(gx, W);
+  ty = make_tap(gy, H);
+}
+
+__global__ void crop_fwd_kernel(const float* __restrict__ feats, const float* __restrict__ boxes,
+                                const int64_t* __restrict__ b2f, float* __restrict__ out, int C, int H, int W, int B, int HH,
+                                int WW) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * HH * WW) return;
+  const int x = i % WW;
+  const int y = (i / WW) % HH;
+  const int b = i / ((size_t)WW * HH);
+  Tap ty, tx;
+  crop_taps(boxes, b, y, x, HH, WW, H, W, ty, tx);
+  const float* fp = feats + (size_t)b2f[b] * C * H * W;
+  float* op = out + (size_t)b * C * HH * WW + (size_t)y * WW + x;
+  for (int c = 0; c < C; ++c) {
+    const float* f = fp + (size_t)c * H * W;
+    float v = f[ty.i0 * W + tx.i0] * (ty.w0 * tx.w0);
+    v += f[ty.i0 * W + tx.i1] * (ty.w0 * tx.w1);
+    v += f[ty.i1 * W + tx.i0] * (ty.w1 * tx.w0);
+    v += f[ty.i1 * W + tx.i1] * (ty.w1 * tx.w1);
+    op[(size_t)c * HH * WW] = v;
+  }
+}
+
+__global__ void crop_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ boxes,
+                                const int64_t* __restrict__ b2f, float* __restrict__ gf, int C, int H, int W, int B, int HH,
+                                int WW) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * HH * WW) return;
+  const int x = i % WW;
+  const int y = (i / WW) % HH;
+  const int b = i / ((size_t)WW * HH);
+  Tap ty, tx;
+  crop_taps(boxes, b, y, x, HH, WW, H, W, ty, tx);
+  float* fp = gf + (size_t)b2f[b] * C * H * W;
+  const float* gp = gout + (size_t)b * C * HH * WW + (size_t)y * WW + x;
+  for (int c = 0; c < C; ++c) {
+    float* f = fp + (size_t)c * H * W;
+    const float g = gp[(size_t)c * HH * WW];
+    const float w00 = ty.w0 * tx.w0, w01 = ty.w0 * tx.w1, w10 = ty.w1 * tx.w0, w11 = ty.w1 * tx.w1;
+    if (w00 != 0.f) atomicAdd(f + ty.i0 * W + tx.i0, g * w00);
+    if (w01 != 0.f) atomicAdd(f + ty.i0 * W + tx.i1, g * w01);
+    if (w10 != 0.f) atomicAdd(f + ty.i1 * W + tx.i0, g * w10);
+    if (w11 != 0.f) atomicAdd(f + ty.i1 * W + tx.i1, g * w11);
+  }
+}
+
+// ---------------- VectorPool -----------------------------------------------------------------------
+__global__ void pool_gather_kernel(const float* __restrict__ pool, const float* __restrict__ vec,
+                                   const int32_t* __restrict__ plan, float* __restrict__ out, int O, int R, int P) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)O * R) return;
+  const int o = i / R, r = i - (size_t)o * R;
+  const int cls = plan[o], kind = plan[O + o], idx = plan[2 * O + o];
+  out[i] = kind ? pool[((size_t)cls * P + idx) * R + r] : vec[(size_t)idx * R + r];
+}
+
+__global__ void pool_scatter_kernel(float* __restrict__ pool, const float* __restrict__ vec,
+                                    const int32_t* __restrict__ plan, int O, int R, int P) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)O * R) return;
+  const int o = i / R, r = i - (size_t)o * R;
+  const int cls = plan[o], slot = plan[3 * O + o];
+  if (slot >= 0) pool[((size_t)cls * P + slot) * R + r] = vec[i];
+}
+
+}  // namespace
+
+extern "C" int sg_segment_offsets(const int64_t* obj_to_img, int O, int N, int32_t* seg_off, sgStream stream) {
+  SG_ARG_CHECK(obj_to_img && seg_off && O >= 0 && N > 0, "sg_segment_offsets: bad arguments");
+  hipLaunchKernelGGL(segment_offsets_kernel, dim3(sg_cdiv(O + 1, 256)), dim3(256), 0, (hipStream_t)stream, obj_to_img, O, N,
+                     seg_off);
+  SG_LAUNCH_CHECK("sg_segment_offsets");
+  return 0;
+}
+
+extern "C" int sg_masks_to_layout_fwd(const float* vecs, const float* boxes, const void* masks, int masks_i64,
+                                      const int32_t* seg_off, float* out, int N, int O, int D, int M, int H, int W, int avg,
+                                      int max_per_image, sgStream stream) {
+  SG_ARG_CHECK(vecs && boxes && masks && seg_off && out && N > 0 && O > 0 && D > 0 && M > 0 && H > 0 && W > 0,
+               "sg_masks_to_layout_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  // LDS is provisioned for `cap` objects per image (the caller's hint, clamped to what fits); denser images are
+  // still correct (chunked), only slower.  ~60 KB/workgroup keeps two workgroups per CU.
+  const int use_vec = (W % 4 == 0) ? 4 : 1;
+  const size_t per_obj = (size_t)(256 * use_vec + D) * sizeof(float);
+  const size_t budget = 160 * 1024 - 1024;
+  int cap = max_per_image > 0 ? max_per_image : 12;
+  if (cap > O) cap = O;
+  const int max_fit = (int)(budget / per_obj);
+  SG_ARG_CHECK(max_fit >= 1, "sg_masks_to_layout_fwd: D=%d too large for LDS", D);
+  if (cap > max_fit) cap = max_fit;
+  const size_t lds_bytes = (size_t)cap * per_obj;
+  SgProfScope prof(SG_K_LAYOUT_FWD, s, 0, 4.0 * N * D * (double)H * W + 4.0 * O * D + (masks_i64 ? 8.0 : 4.0) * O * M * M);
+  const dim3 grid(sg_cdiv(H * W, 256 * use_vec), N);
+#define LAUNCH_LAYOUT(I64, VEC)                                                                                         \
+  do {                                                                                                                 \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&layout_fwd_kernel<I64, VEC>),                                    \
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                                    \
+    hipLaunchKernelGGL((layout_fwd_kernel<I64, VEC>), grid, dim3(256), lds_bytes, s, vecs, boxes, masks, seg_off, out, \
+                       D, M, H, W, avg, cap);                                                                           \
+  } while (0)
+  if (masks_i64) { if (use_vec == 4) LAUNCH_LAYOUT(true, 4); else LAUNCH_LAYOUT(true, 1); }
+  else { if (use_vec == 4) LAUNCH_LAYOUT(false, 4); else LAUNCH_LAYOUT(false, 1); }
+#undef LAUNCH_LAYOUT
+  SG_LAUNCH_CHECK("sg_masks_to_layout_fwd");
+  return 0;
+}
+
+extern "C" int sg_masks_to_layout_bwd_vecs(const float* gout, const float* boxes, const void* masks, int masks_i64,
+                                           const int64_t* obj_to_img, const int32_t* seg_off, float* g_vecs, int N, int O,
+                                           int D, int M, int H, int W, int avg, int d_begin, sgStream stream) {
+  SG_ARG_CHECK(gout && boxes && masks && seg_off && g_vecs && N > 0 && O > 0 && D > 0 && d_begin >= 0 && d_begin < D,
+               "sg_masks_to_layout_bwd_vecs: bad arguments");
+  (void)obj_to_img;
+  hipStream_t s = (hipStream_t)stream;
+  if (d_begin > 0)
+    hipLaunchKernelGGL(zero_cols_kernel, dim3(sg_cdiv((size_t)O * d_begin, 256)), dim3(256), 0, s, g_vecs, O, D, d_begin);
+  SgProfScope prof(SG_K_LAYOUT_BWD, s, 0, 4.0 * N * (D - d_begin) * (double)H * W);
+  const dim3 grid(D - d_begin, N);
+  if (masks_i64) hipLaunchKernelGGL(layout_bwd_vecs_kernel<true>, grid, dim3(256), 0, s, gout, boxes, masks, seg_off, g_vecs, D, M, H, W, avg, d_begin);
+  else hipLaunchKernelGGL(layout_bwd_vecs_kernel<false>, grid, dim3(256), 0, s, gout, boxes, masks, seg_off, g_vecs, D, M, H, W, avg, d_begin);
+  SG_LAUNCH_CHECK("sg_masks_to_layout_bwd_vecs");
+  return 0;
+}
+
+extern "C" int sg_crop_bbox_fwd(const float* feats, const float* boxes, const int64_t* box_to_feat, float* out, int N, int C,
+                                int H, int W, int B, int HH, int WW, sgStream stream) {
+  SG_ARG_CHECK(feats && boxes && box_to_feat && out && N > 0 && C > 0 && B >= 0 && HH > 0 && WW > 0,
+               "sg_crop_bbox_fwd: bad arguments");
+  if (B == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  SgProfScope prof(SG_K_CROP, s, 0, 4.0 * B * C * (double)HH * WW + 4.0 * N * C * (double)H * W);
+  hipLaunchKernelGGL(crop_fwd_kernel, dim3(sg_cdiv((size_t)B * HH * WW, 256)), dim3(256), 0, s, feats, boxes, box_to_feat, out,
+                     C, H, W, B, HH, WW);
+  SG_LAUNCH_CHECK("sg_crop_bbox_fwd");
+  return 0;
+}
+
+extern "C" int sg_crop_bbox_bwd(const float* gout, const float* boxes, const int64_t* box_to_feat, float* g_feats, int N, int C,
+                                int H, int W, int B, int HH, int WW, sgStream stream) {
+  SG_ARG_CHECK(gout && boxes && box_to_feat && g_feats && N > 0 && C > 0 && B >= 0, "sg_crop_bbox_bwd: bad arguments");
+  if (B == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  SgProfScope prof(SG_K_CROP, s, 0, 4.0 * B * C * (double)HH * WW * 5);
+  hipLaunchKernelGGL(crop_bwd_kernel, dim3(sg_cdiv((size_t)B * HH * WW, 256)), dim3(256), 0, s, gout, boxes, box_to_feat,
+                     g_feats, C, H, W, B, HH, WW);
+  SG_LAUNCH_CHECK("sg_crop_bbox_bwd");
+  return 0;
+}
+
+extern "C" int sg_vector_pool_exchange(float* pool, const float* vectors, const int32_t* plan, float* out, int O, int R,
+                                       int pool_size, sgStream stream) {
+  SG_ARG_CHECK(pool && vectors && plan && out && O >= 0 && R > 0 && pool_size > 0, "sg_vector_pool_exchange: bad arguments");
+  if (O == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(sg_cdiv((size_t)O * R, 256));
+  hipLaunchKernelGGL(pool_gather_kernel, grid, dim3(256), 0, s, (const float*)pool, vectors, plan, out, O, R, pool_size);
+  hipLaunchKernelGGL(pool_scatter_kernel, grid, dim3(256), 0, s, pool, vectors, plan, O, R, pool_size);
+  SG_LAUNCH_CHECK("sg_vector_pool_exchange");
+  return 0;
+}

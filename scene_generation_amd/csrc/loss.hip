@@ -1,0 +1,187 @@
+// Scalar losses (deterministic two-stage wave-shuffle reductions, no host sync), cross-entropy and the
+// fused flat-buffer Adam step.  Replaces nn.MSELoss / nn.L1Loss / bce_loss / F.cross_entropy reductions
+// (losses.py:26-44,135-175; trainer.py:215,331-340; discriminators.py:35) and torch.optim.Adam
+// (trainer.py:60,80,106,133).
+#include "common.h"
+
+namespace {
+
+constexpr int LOSS_BLOCKS = 512;
+
+__device__ __forceinline__ float loss_term(int kind, float a, float b, float t) {
+  switch (kind) {
+    case SG_LOSS_MSE_CONST: { const float d = a - t; return d * d; }
+    case SG_LOSS_MSE: { const float d = a - b; return d * d; }
+    case SG_LOSS_L1: return fabsf(a - b);
+    default: return fmaxf(a, 0.f) - a * t + logf(1.f + expf(-fabsf(a)));   // losses.py:42-44
+  }
+}
+
+__device__ __forceinline__ float loss_grad(int kind, float a, float b, float t) {
+  switch (kind) {
+    case SG_LOSS_MSE_CONST: return 2.f * (a - t);
+    case SG_LOSS_MSE: return 2.f * (a - b);
+    case SG_LOSS_L1: { const float d = a - b; return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+    default: {
+      // d/da [max(a,0) - a t + log(1+exp(-|a|))]
+      const float e = expf(-fabsf(a));
+      const float sgn = a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f);
+      return (a > 0.f ? 1.f : 0.f) - t - sgn * e / (1.f + e);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) loss_partial_kernel(int kind, const float* __restrict__ a, const float* __restrict__ b,
+                                                          float target, size_t n, float* __restrict__ part) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    s += loss_term(kind, a[i], b ? b[i] : 0.f, target);
+  s = sg_block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) loss_final_kernel(const float* __restrict__ part, int nb, float scale,
+                                                        float* __restrict__ out, int accumulate) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+  s = sg_block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + s * scale;
+}
+
+__global__ void loss_bwd_kernel(int kind, const float* __restrict__ a, const float* __restrict__ b, float target, size_t n,
+                                float scale, const float* __restrict__ gout, float* __restrict__ ga) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ga[i] = gout[0] * scale * loss_grad(kind, a[i], b ? b[i] : 0.f, target);
+}
+
+// one wave per row
+__global__ void __launch_bounds__(256) ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                    int rows, int classes, float* __restrict__ row_loss) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* x = logits + (size_t)row * classes;
+  float m = -INFINITY;
+  for (int c = lane; c < classes; c += 64) m = fmaxf(m, x[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float s = 0.f;
+  for (int c = lane; c < classes; c += 64) s += expf(x[c] - m);
+  s = sg_wave_sum(s);
+  if (lane == 0) row_loss[row] = (m + logf(s)) - x[target[row]];
+}
+
+__global__ void __launch_bounds__(256) ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                    int rows, int classes, const float* __restrict__ gout,
+                                                    float* __restrict__ gl) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* x = logits + (size_t)row * classes;
+  float m = -INFINITY;
+  for (int c = lane; c < classes; c += 64) m = fmaxf(m, x[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float s = 0.f;
+  for (int c = lane; c < classes; c += 64) s += expf(x[c] - m);
+  s = sg_wave_sum(s);
+  const float g = gout[0] / (float)rows;
+  const int t = (int)target[row];
+  for (int c = lane; c < classes; c += 64) gl[(size_t)row * classes + c] = g * (expf(x[c] - m) / s - (c == t ? 1.f : 0.f));
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t n, float step_size, float beta1, float beta2, float eps, float bc2_sqrt) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i];
+  const float mi = m[i] + (1.f - beta1) * (gi - m[i]);        // exp_avg.lerp_(grad, 1-beta1)
+  const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;    // mul_(beta2).addcmul_(g, g, 1-beta2)
+  m[i] = mi; v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = p[i] - step_size * (mi / denom);                      // addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__global__ void fill_kernel(float* __restrict__ p, float value, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = value;
+}
+
+__global__ void scale_kernel(float* __restrict__ p, float a, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] *= a;
+}
+
+}  // namespace
+
+extern "C" size_t sg_loss_ws_bytes(int64_t n) { (void)n; return LOSS_BLOCKS * sizeof(float); }
+
+extern "C" int sg_loss_fwd(int kind, const float* a, const float* b, float target, int64_t n, float scale, float* out,
+                           int accumulate, void* ws, size_t ws_bytes, sgStream stream) {
+  SG_ARG_CHECK(a && out && ws && n > 0 && kind >= 0 && kind <= 3, "sg_loss_fwd: bad arguments");
+  SG_ARG_CHECK((kind != SG_LOSS_MSE && kind != SG_LOSS_L1) || b, "sg_loss_fwd: pair loss needs b");
+  SG_ARG_CHECK(ws_bytes >= LOSS_BLOCKS * sizeof(float), "sg_loss_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  int nb = sg_cdiv(n, 256 * 8);
+  nb = nb < 1 ? 1 : (nb > LOSS_BLOCKS ? LOSS_BLOCKS : nb);
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(256), 0, s, kind, a, b, target, (size_t)n, (float*)ws);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, nb, scale, out, accumulate);
+  SG_LAUNCH_CHECK("sg_loss_fwd");
+  return 0;
+}
+
+extern "C" int sg_loss_bwd(int kind, const float* a, const float* b, float target, int64_t n, float scale, const float* gout,
+                           float* ga, sgStream stream) {
+  SG_ARG_CHECK(a && gout && ga && n > 0 && kind >= 0 && kind <= 3, "sg_loss_bwd: bad arguments");
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, kind, a, b, target, (size_t)n,
+                     scale, gout, ga);
+  SG_LAUNCH_CHECK("sg_loss_bwd");
+  return 0;
+}
+
+extern "C" int sg_cross_entropy_fwd(const float* logits, const int64_t* target, int rows, int classes, float* row_loss,
+                                    float* out, sgStream stream) {
+  SG_ARG_CHECK(logits && target && row_loss && out && rows > 0 && classes > 0, "sg_cross_entropy_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(sg_cdiv(rows, 4)), dim3(256), 0, s, logits, target, rows, classes, row_loss);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, (const float*)row_loss, rows, 1.f / (float)rows, out, 0);
+  SG_LAUNCH_CHECK("sg_cross_entropy_fwd");
+  return 0;
+}
+
+extern "C" int sg_cross_entropy_bwd(const float* logits, const int64_t* target, int rows, int classes, const float* gout,
+                                    float* glogits, sgStream stream) {
+  SG_ARG_CHECK(logits && target && gout && glogits && rows > 0 && classes > 0, "sg_cross_entropy_bwd: bad arguments");
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(sg_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, target, rows, classes,
+                     gout, glogits);
+  SG_LAUNCH_CHECK("sg_cross_entropy_bwd");
+  return 0;
+}
+
+extern "C" int sg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                            float eps, float bias_corr1, float bias_corr2_sqrt, sgStream stream) {
+  SG_ARG_CHECK(p && g && m && v && n > 0 && bias_corr1 > 0.f && bias_corr2_sqrt > 0.f, "sg_adam_step: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  SgProfScope prof(SG_K_ADAM, s, 0, 28.0 * (double)n);
+  hipLaunchKernelGGL(adam_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, s, p, g, m, v, (size_t)n, lr / bias_corr1, beta1, beta2,
+                     eps, bias_corr2_sqrt);
+  SG_LAUNCH_CHECK("sg_adam_step");
+  return 0;
+}
+
+extern "C" int sg_fill(float* p, float value, int64_t n, sgStream stream) {
+  SG_ARG_CHECK(p && n >= 0, "sg_fill: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(fill_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, value, (size_t)n);
+  SG_LAUNCH_CHECK("sg_fill");
+  return 0;
+}
+
+extern "C" int sg_scale(float* p, float alpha, int64_t n, sgStream stream) {
+  SG_ARG_CHECK(p && n >= 0, "sg_scale: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(scale_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, alpha, (size_t)n);
+  SG_LAUNCH_CHECK("sg_scale");
+  return 0;
+}

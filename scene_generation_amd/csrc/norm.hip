@@ -1,0 +1,460 @@
+// HBM-bound normalisation / pooling / elementwise kernels (wave64 shuffle reductions, float4 streams).
+// Replaces nn.InstanceNorm2d (layers.py:296), nn.BatchNorm2d (generators.py:22, layers.py:23-31),
+// nn.AvgPool2d(3,2,1,count_include_pad=False) (discriminators.py:100,186), GlobalAvgPool (layers.py:82-85)
+// and the activation modules fused behind them.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float act_grad_from_pre(float pre, int act, float slope) {
+  switch (act) {
+    case SG_ACT_RELU: return pre > 0.f ? 1.f : 0.f;
+    case SG_ACT_LEAKY: return pre > 0.f ? 1.f : slope;
+    default: return 1.f;
+  }
+}
+
+// ---------------- InstanceNorm: one wave per plane (small planes) or one block per plane -----------
+template <bool WAVE>
+__global__ void __launch_bounds__(256) instnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ skip,
+                                                          float* __restrict__ y, float* __restrict__ mean_o,
+                                                          float* __restrict__ rstd_o, int NC, int HW, float eps, int act,
+                                                          float slope) {
+  __shared__ float red[16];
+  const int lane = threadIdx.x & 63;
+  const int plane = WAVE ? blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x;
+  if (WAVE && plane >= NC) return;
+  const int t0 = WAVE ? lane : threadIdx.x, nt = WAVE ? 64 : blockDim.x;
+  const float* xp = x + (size_t)plane * HW;
+  float s = 0.f;
+  for (int i = t0; i < HW; i += nt) s += xp[i];
+  s = WAVE ? sg_wave_sum(s) : sg_block_sum(s, red);
+  const float mean = s / (float)HW;
+  float q = 0.f;
+  for (int i = t0; i < HW; i += nt) { const float d = xp[i] - mean; q += d * d; }
+  q = WAVE ? sg_wave_sum(q) : sg_block_sum(q, red);
+  const float rstd = 1.f / sqrtf(q / (float)HW + eps);
+  if (t0 == 0) { mean_o[plane] = mean; rstd_o[plane] = rstd; }
+  float* yp = y + (size_t)plane * HW;
+  const float* sp = skip ? skip + (size_t)plane * HW : nullptr;
+  for (int i = t0; i < HW; i += nt) {
+    float v = sg_apply_act((xp[i] - mean) * rstd, act, slope);
+    if (sp) v += sp[i];
+    yp[i] = v;
+  }
+}
+
+template <bool WAVE>
+__global__ void __launch_bounds__(256) instnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                          const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                          float* __restrict__ gx, int NC, int HW, int act, float slope) {
+  __shared__ float red[16];
+  const int lane = threadIdx.x & 63;
+  const int plane = WAVE ? blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x;
+  if (WAVE && plane >= NC) return;
+  const int t0 = WAVE ? lane : threadIdx.x, nt = WAVE ? 64 : blockDim.x;
+  const float* xp = x + (size_t)plane * HW;
+  const float* gp = gy + (size_t)plane * HW;
+  const float mean = mean_i[plane], rstd = rstd_i[plane];
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = t0; i < HW; i += nt) {
+    const float z = (xp[i] - mean) * rstd;
+    const float g = gp[i] * act_grad_from_pre(z, act, slope);
+    s1 += g; s2 += g * z;
+  }
+  if (WAVE) { s1 = sg_wave_sum(s1); s2 = sg_wave_sum(s2); }
+  else { s1 = sg_block_sum(s1, red); s2 = sg_block_sum(s2, red); }
+  const float inv = 1.f / (float)HW;
+  const float m1 = s1 * inv, m2 = s2 * inv;
+  float* op = gx + (size_t)plane * HW;
+  for (int i = t0; i < HW; i += nt) {
+    const float z = (xp[i] - mean) * rstd;
+    const float g = gp[i] * act_grad_from_pre(z, act, slope);
+    op[i] = rstd * (g - m1 - z * m2);
+  }
+}
+
+// ---------------- BatchNorm2d: one block per channel ---------------------------------------------
+__global__ void __launch_bounds__(512) batchnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ y,
+                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                                           float* __restrict__ rmean, float* __restrict__ rvar,
+                                                           int64_t* __restrict__ nbt, int N, int C, int HW, float eps,
+                                                           float momentum, int training, int act, float slope) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const int cnt = N * HW;
+  float mean, rstd;
+  if (training) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+      const int n = i / HW, p = i - n * HW;
+      s += x[((size_t)n * C + c) * HW + p];
+    }
+    s = sg_block_sum(s, red);
+    mean = s / (float)cnt;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+      const int n = i / HW, p = i - n * HW;
+      const float d = x[((size_t)n * C + c) * HW + p] - mean;
+      q += d * d;
+    }
+    q = sg_block_sum(q, red);
+    const float var = q / (float)cnt;
+    rstd = 1.f / sqrtf(var + eps);
+    if (threadIdx.x == 0) {
+      save_mean[c] = mean; save_rstd[c] = rstd;
+      if (rmean) {
+        const float unb = cnt > 1 ? q / (float)(cnt - 1) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+      }
+      if (nbt && c == 0) nbt[0] += 1;
+    }
+  } else {
+    mean = rmean[c];
+    rstd = 1.f / sqrtf(rvar[c] + eps);
+    if (threadIdx.x == 0) { save_mean[c] = mean; save_rstd[c] = rstd; }
+  }
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    const int n = i / HW, p = i - n * HW;
+    const size_t off = ((size_t)n * C + c) * HW + p;
+    y[off] = sg_apply_act((x[off] - mean) * rstd * ga + be, act, slope);
+  }
+}
+
+__global__ void __launch_bounds__(512) batchnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ save_mean,
+                                                           const float* __restrict__ save_rstd, float* __restrict__ gx,
+                                                           float* __restrict__ ggamma, float* __restrict__ gbeta, int N,
+                                                           int C, int HW, int act, float slope) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const int cnt = N * HW;
+  const float mean = save_mean[c], rstd = save_rstd[c];
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    const int n = i / HW, p = i - n * HW;
+    const size_t off = ((size_t)n * C + c) * HW + p;
+    const float z = (x[off] - mean) * rstd;
+    const float g = gy[off] * act_grad_from_pre(z * ga + be, act, slope);
+    s1 += g; s2 += g * z;
+  }
+  s1 = sg_block_sum(s1, red);
+  s2 = sg_block_sum(s2, red);
+  if (threadIdx.x == 0) { if (gbeta) gbeta[c] = s1; if (ggamma) ggamma[c] = s2; }
+  const float inv = 1.f / (float)cnt;
+  const float m1 = s1 * inv, m2 = s2 * inv;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    const int n = i / HW, p = i - n * HW;
+    const size_t off = ((size_t)n * C + c) * HW + p;
+    const float z = (x[off] - mean) * rstd;
+    const float g = gy[off] * act_grad_from_pre(z * ga + be, act, slope);
+    gx[off] = ga * rstd * (g - m1 - z * m2);
+  }
+}
+
+__global__ void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int N, int C, int HW) {
+  __shared__ float red[16];
+  const int c = blockIdx.x;
+  const int cnt = N * HW;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+    const int n = i / HW, p = i - n * HW;
+    s += g[((size_t)n * C + c) * HW + p];
+  }
+  s = sg_block_sum(s, red);
+  if (threadIdx.x == 0) out[c] = s;
+}
+
+// ---------------- pooling --------------------------------------------------------------------------
+__global__ void avgpool3s2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int NC, int H, int W, int OH,
+                                      int OW) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)NC * OH * OW;
+  if (i >= total) return;
+  const int ow = i % OW;
+  const int oh = (i / OW) % OH;
+  const size_t nc = i / ((size_t)OW * OH);
+  const float* xp = x + nc * H * W;
+  float s = 0.f;
+  int cnt = 0;
+  for (int kh = 0; kh < 3; ++kh) {
+    const int ih = oh * 2 - 1 + kh;
+    if (ih < 0 || ih >= H) continue;
+    for (int kw = 0; kw < 3; ++kw) {
+      const int iw = ow * 2 - 1 + kw;
+      if (iw < 0 || iw >= W) continue;
+      s += xp[ih * W + iw];
+      ++cnt;
+    }
+  }
+  y[i] = s / (float)cnt;
+}
+
+__device__ __forceinline__ int pool_cnt(int o, int L) {   // valid taps of window o along one axis
+  const int lo = o * 2 - 1 < 0 ? 0 : o * 2 - 1, hi = o * 2 + 1 >= L ? L - 1 : o * 2 + 1;
+  return hi - lo + 1;
+}
+
+__global__ void avgpool3s2_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int NC, int H, int W, int OH,
+                                      int OW) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)NC * H * W;
+  if (i >= total) return;
+  const int iw = i % W;
+  const int ih = (i / W) % H;
+  const size_t nc = i / ((size_t)W * H);
+  const float* gp = gy + nc * OH * OW;
+  float s = 0.f;
+  for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh) {
+    if (oh >= OH) continue;
+    for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow) {
+      if (ow >= OW) continue;
+      s += gp[oh * OW + ow] / (float)(pool_cnt(oh, H) * pool_cnt(ow, W));
+    }
+  }
+  gx[i] = s;
+}
+
+__global__ void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int NC, int HW) {
+  const int plane = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (plane >= NC) return;
+  const float* xp = x + (size_t)plane * HW;
+  float s = 0.f;
+  for (int i = lane; i < HW; i += 64) s += xp[i];
+  s = sg_wave_sum(s);
+  if (lane == 0) y[plane] = s / (float)HW;
+}
+
+__global__ void gap_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, size_t total, int HW) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) gx[i] = gy[i / HW] / (float)HW;
+}
+
+// ---------------- elementwise / layout glue ---------------------------------------------------------
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act, float slope) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = sg_apply_act(x[i], act, slope);
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gx, size_t n,
+                               int act, float slope) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float o = y[i];
+  float d = 1.f;
+  switch (act) {
+    case SG_ACT_RELU: d = o > 0.f ? 1.f : 0.f; break;
+    case SG_ACT_LEAKY: d = o > 0.f ? 1.f : slope; break;   // slope>0: sign(output)==sign(input)
+    case SG_ACT_TANH: d = 1.f - o * o; break;
+    case SG_ACT_SIGMOID: d = o * (1.f - o); break;
+    default: break;
+  }
+  gx[i] = gy[i] * d;
+}
+
+__global__ void upsample2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int H, int W) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ow = i % (2 * W);
+  const int oh = (i / (2 * W)) % (2 * H);
+  const size_t nc = i / ((size_t)4 * W * H);
+  y[i] = x[nc * H * W + (size_t)(oh >> 1) * W + (ow >> 1)];
+}
+
+__global__ void reflect_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int H, int W,
+                                       int pad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int PW = W + 2 * pad, PH = H + 2 * pad;
+  const int ow = i % PW;
+  const int oh = (i / PW) % PH;
+  const size_t nc = i / ((size_t)PW * PH);
+  int ih = oh - pad, iw = ow - pad;
+  ih = ih < 0 ? -ih : (ih >= H ? 2 * H - 2 - ih : ih);
+  iw = iw < 0 ? -iw : (iw >= W ? 2 * W - 2 - iw : iw);
+  y[i] = x[nc * H * W + (size_t)ih * W + iw];
+}
+
+// candidates (<=3) of padded-grid coordinates that reflect onto logical coordinate l (0<=l<L, pad p)
+__device__ __forceinline__ int reflect_sources(int l, int L, int p, int (&a)[3]) {
+  int n = 0;
+  a[n++] = l + p;
+  if (l >= 1 && l <= p) a[n++] = p - l;
+  if (l <= L - 2 && l >= L - 1 - p) a[n++] = p + 2 * L - 2 - l;
+  return n;
+}
+
+__global__ void pad_upsample_bwd_kernel(const float* __restrict__ gp, float* __restrict__ gx, size_t total, int H, int W,
+                                        int pad, int ups) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int w = i % W;
+  const int h = (i / W) % H;
+  const size_t nc = i / ((size_t)W * H);
+  const int LH = H * ups, LW = W * ups, PH = LH + 2 * pad, PW = LW + 2 * pad;
+  const float* g = gp + nc * PH * PW;
+  float s = 0.f;
+  for (int dh = 0; dh < ups; ++dh) {
+    int ah[3];
+    const int nh = reflect_sources(h * ups + dh, LH, pad, ah);
+    for (int dw = 0; dw < ups; ++dw) {
+      int aw[3];
+      const int nw = reflect_sources(w * ups + dw, LW, pad, aw);
+      for (int a = 0; a < nh; ++a)
+        for (int b = 0; b < nw; ++b) s += g[(size_t)ah[a] * PW + aw[b]];
+    }
+  }
+  gx[i] = s;
+}
+
+__global__ void concat_channels_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                       size_t total, int Ca, int Cb, int HW) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int p = i % HW;
+  const int c = (i / HW) % (Ca + Cb);
+  const size_t n = i / ((size_t)HW * (Ca + Cb));
+  out[i] = c < Ca ? a[(n * Ca + c) * HW + p] : b[(n * Cb + (c - Ca)) * HW + p];
+}
+
+inline dim3 grid1d(size_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
+
+}  // namespace
+
+extern "C" int sg_instnorm_fwd(const float* x, const float* skip, float* y, float* mean, float* rstd, int NC, int HW,
+                               float eps, int act, float slope, sgStream stream) {
+  SG_ARG_CHECK(x && y && mean && rstd && NC > 0 && HW > 0, "sg_instnorm_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  SgProfScope prof(SG_K_INSTNORM, s, 0, (double)NC * HW * 4.0 * (skip ? 5 : 4));
+  if (HW <= 1024) hipLaunchKernelGGL(instnorm_fwd_kernel<true>, dim3(sg_cdiv(NC, 4)), dim3(256), 0, s, x, skip, y, mean, rstd, NC, HW, eps, act, slope);
+  else hipLaunchKernelGGL(instnorm_fwd_kernel<false>, dim3(NC), dim3(256), 0, s, x, skip, y, mean, rstd, NC, HW, eps, act, slope);
+  SG_LAUNCH_CHECK("sg_instnorm_fwd");
+  return 0;
+}
+
+extern "C" int sg_instnorm_bwd(const float* x, const float* gy, const float* mean, const float* rstd, float* gx, int NC,
+                               int HW, int act, float slope, sgStream stream) {
+  SG_ARG_CHECK(x && gy && mean && rstd && gx && NC > 0 && HW > 0, "sg_instnorm_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  SgProfScope prof(SG_K_INSTNORM, s, 0, (double)NC * HW * 4.0 * 5);
+  if (HW <= 1024) hipLaunchKernelGGL(instnorm_bwd_kernel<true>, dim3(sg_cdiv(NC, 4)), dim3(256), 0, s, x, gy, mean, rstd, gx, NC, HW, act, slope);
+  else hipLaunchKernelGGL(instnorm_bwd_kernel<false>, dim3(NC), dim3(256), 0, s, x, gy, mean, rstd, gx, NC, HW, act, slope);
+  SG_LAUNCH_CHECK("sg_instnorm_bwd");
+  return 0;
+}
+
+extern "C" int sg_batchnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
+                                float* save_rstd, float* running_mean, float* running_var, int64_t* num_batches, int N,
+                                int C, int HW, float eps, float momentum, int training, int act, float slope,
+                                sgStream stream) {
+  SG_ARG_CHECK(x && y && save_mean && save_rstd && N > 0 && C > 0 && HW > 0, "sg_batchnorm_fwd: bad arguments");
+  SG_ARG_CHECK(training || (running_mean && running_var), "sg_batchnorm_fwd: eval mode needs running stats");
+  hipStream_t s = (hipStream_t)stream;
+  SgProfScope prof(SG_K_BATCHNORM, s, 0, (double)N * C * HW * 16.0);
+  hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3(C), dim3(512), 0, s, x, gamma, beta, y, save_mean, save_rstd,
+                     running_mean, running_var, num_batches, N, C, HW, eps, momentum, training, act, slope);
+  SG_LAUNCH_CHECK("sg_batchnorm_fwd");
+  return 0;
+}
+
+extern "C" int sg_batchnorm_bwd(const float* x, const float* gy, const float* gamma, const float* beta,
+                                const float* save_mean, const float* save_rstd, float* gx, float* ggamma, float* gbeta,
+                                int N, int C, int HW, int act, float slope, sgStream stream) {
+  SG_ARG_CHECK(x && gy && save_mean && save_rstd && gx && N > 0 && C > 0 && HW > 0, "sg_batchnorm_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  SgProfScope prof(SG_K_BATCHNORM, s, 0, (double)N * C * HW * 20.0);
+  hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(C), dim3(512), 0, s, x, gy, gamma, beta, save_mean, save_rstd, gx,
+                     ggamma, gbeta, N, C, HW, act, slope);
+  SG_LAUNCH_CHECK("sg_batchnorm_bwd");
+  return 0;
+}
+
+extern "C" int sg_channel_sum(const float* g, float* out, int N, int C, int HW, sgStream stream) {
+  SG_ARG_CHECK(g && out && N > 0 && C > 0 && HW > 0, "sg_channel_sum: bad arguments");
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, g, out, N, C, HW);
+  SG_LAUNCH_CHECK("sg_channel_sum");
+  return 0;
+}
+
+extern "C" int sg_avgpool3s2_fwd(const float* x, float* y, int NC, int H, int W, int OH, int OW, sgStream stream) {
+  SG_ARG_CHECK(x && y && OH == (H + 2 - 3) / 2 + 1 && OW == (W + 2 - 3) / 2 + 1, "sg_avgpool3s2_fwd: bad arguments");
+  hipLaunchKernelGGL(avgpool3s2_fwd_kernel, grid1d((size_t)NC * OH * OW), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, OH, OW);
+  SG_LAUNCH_CHECK("sg_avgpool3s2_fwd");
+  return 0;
+}
+
+extern "C" int sg_avgpool3s2_bwd(const float* gy, float* gx, int NC, int H, int W, int OH, int OW, sgStream stream) {
+  SG_ARG_CHECK(gy && gx, "sg_avgpool3s2_bwd: bad arguments");
+  hipLaunchKernelGGL(avgpool3s2_bwd_kernel, grid1d((size_t)NC * H * W), dim3(256), 0, (hipStream_t)stream, gy, gx, NC, H, W, OH, OW);
+  SG_LAUNCH_CHECK("sg_avgpool3s2_bwd");
+  return 0;
+}
+
+extern "C" int sg_gap_fwd(const float* x, float* y, int NC, int HW, sgStream stream) {
+  SG_ARG_CHECK(x && y && NC > 0 && HW > 0, "sg_gap_fwd: bad arguments");
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3(sg_cdiv(NC, 4)), dim3(256), 0, (hipStream_t)stream, x, y, NC, HW);
+  SG_LAUNCH_CHECK("sg_gap_fwd");
+  return 0;
+}
+
+extern "C" int sg_gap_bwd(const float* gy, float* gx, int NC, int HW, sgStream stream) {
+  SG_ARG_CHECK(gy && gx && NC > 0 && HW > 0, "sg_gap_bwd: bad arguments");
+  hipLaunchKernelGGL(gap_bwd_kernel, grid1d((size_t)NC * HW), dim3(256), 0, (hipStream_t)stream, gy, gx, (size_t)NC * HW, HW);
+  SG_LAUNCH_CHECK("sg_gap_bwd");
+  return 0;
+}
+
+extern "C" int sg_act_fwd(const float* x, float* y, int64_t n, int act, float slope, sgStream stream) {
+  SG_ARG_CHECK(x && y && n >= 0, "sg_act_fwd: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(act_fwd_kernel, grid1d((size_t)n), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)n, act, slope);
+  SG_LAUNCH_CHECK("sg_act_fwd");
+  return 0;
+}
+
+extern "C" int sg_act_bwd(const float* y, const float* gy, float* gx, int64_t n, int act, float slope, sgStream stream) {
+  SG_ARG_CHECK(y && gy && gx && n >= 0, "sg_act_bwd: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(act_bwd_kernel, grid1d((size_t)n), dim3(256), 0, (hipStream_t)stream, y, gy, gx, (size_t)n, act, slope);
+  SG_LAUNCH_CHECK("sg_act_bwd");
+  return 0;
+}
+
+extern "C" int sg_upsample2_fwd(const float* x, float* y, int NC, int H, int W, sgStream stream) {
+  SG_ARG_CHECK(x && y, "sg_upsample2_fwd: bad arguments");
+  const size_t total = (size_t)NC * 4 * H * W;
+  hipLaunchKernelGGL(upsample2_fwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, x, y, total, H, W);
+  SG_LAUNCH_CHECK("sg_upsample2_fwd");
+  return 0;
+}
+
+extern "C" int sg_reflect_pad_fwd(const float* x, float* y, int NC, int H, int W, int pad, sgStream stream) {
+  SG_ARG_CHECK(x && y && pad < H && pad < W, "sg_reflect_pad_fwd: bad arguments");
+  const size_t total = (size_t)NC * (H + 2 * pad) * (W + 2 * pad);
+  hipLaunchKernelGGL(reflect_pad_fwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, x, y, total, H, W, pad);
+  SG_LAUNCH_CHECK("sg_reflect_pad_fwd");
+  return 0;
+}
+
+extern "C" int sg_pad_upsample_bwd(const float* gp, float* gx, int NC, int H, int W, int pad, int upsample,
+                                   sgStream stream) {
+  SG_ARG_CHECK(gp && gx && (upsample == 1 || upsample == 2) && pad >= 0, "sg_pad_upsample_bwd: bad arguments");
+  const size_t total = (size_t)NC * H * W;
+  hipLaunchKernelGGL(pad_upsample_bwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, gp, gx, total, H, W, pad, upsample);
+  SG_LAUNCH_CHECK("sg_pad_upsample_bwd");
+  return 0;
+}
+
+extern "C" int sg_concat_channels(const float* a, const float* b, float* out, int N, int Ca, int Cb, int HW,
+                                  sgStream stream) {
+  SG_ARG_CHECK(a && b && out, "sg_concat_channels: bad arguments");
+  const size_t total = (size_t)N * (Ca + Cb) * HW;
+  hipLaunchKernelGGL(concat_channels_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, a, b, out, total, Ca, Cb, HW);
+  SG_LAUNCH_CHECK("sg_concat_channels");
+  return 0;
+}

@@ -1,0 +1,84 @@
+// Error string + opt-in HIP-event profiler (include/sg2im_hip.h: sg_last_error_string, sg_prof_*).
+#include "common.h"
+#include <stdarg.h>
+#include <mutex>
+#include <vector>
+
+static thread_local char t_err[512] = "ok";
+
+void sg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(t_err, sizeof(t_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* sg_last_error_string(void) { return t_err; }
+extern "C" int sg_version(void) { return 100; }
+
+int g_sg_prof_on = 0;
+
+namespace {
+struct Rec { int kind; hipEvent_t e0, e1; double flops, bytes; };
+std::mutex g_mu;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_free;
+hipEvent_t g_open[SG_K_COUNT];
+double g_ms[SG_K_COUNT], g_flops[SG_K_COUNT], g_bytes[SG_K_COUNT];
+int64_t g_cnt[SG_K_COUNT];
+const char* kNames[SG_K_COUNT] = {"conv_fwd", "conv_dgrad", "conv_wgrad", "linear", "layout_fwd", "layout_bwd",
+                                  "instnorm", "batchnorm", "adam", "segsum", "crop", "other"};
+
+hipEvent_t get_event() {
+  if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+void drain() {   // caller holds g_mu
+  for (auto& r : g_recs) {
+    hipEventSynchronize(r.e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, r.e0, r.e1);
+    g_ms[r.kind] += ms; g_flops[r.kind] += r.flops; g_bytes[r.kind] += r.bytes; g_cnt[r.kind] += 1;
+    g_free.push_back(r.e0); g_free.push_back(r.e1);
+  }
+  g_recs.clear();
+}
+}  // namespace
+
+void sg_prof_begin(int kind, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipEvent_t e = get_event();
+  hipEventRecord(e, s);
+  g_open[kind] = e;
+}
+
+void sg_prof_end(int kind, hipStream_t s, double flops, double bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipEvent_t e = get_event();
+  hipEventRecord(e, s);
+  g_recs.push_back(Rec{kind, g_open[kind], e, flops, bytes});
+  if (g_recs.size() > 8192) drain();
+}
+
+extern "C" int sg_prof_enable(int on) { g_sg_prof_on = on; return 0; }
+extern "C" int sg_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  drain();
+  for (int i = 0; i < SG_K_COUNT; ++i) { g_ms[i] = g_flops[i] = g_bytes[i] = 0; g_cnt[i] = 0; }
+  return 0;
+}
+extern "C" int sg_prof_num_kinds(void) { return SG_K_COUNT; }
+extern "C" const char* sg_prof_kind_name(int kind) { return (kind >= 0 && kind < SG_K_COUNT) ? kNames[kind] : "?"; }
+extern "C" int sg_prof_read(int kind, double* total_ms, int64_t* launches, double* flops, double* bytes) {
+  if (kind < 0 || kind >= SG_K_COUNT) { sg_set_error("sg_prof_read: bad kind %d", kind); return -1; }
+  std::lock_guard<std::mutex> lk(g_mu);
+  drain();
+  if (total_ms) *total_ms = g_ms[kind];
+  if (launches) *launches = g_cnt[kind];
+  if (flops) *flops = g_flops[kind];
+  if (bytes) *bytes = g_bytes[kind];
+  return 0;
+}

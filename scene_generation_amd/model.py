@@ -1,0 +1,135 @@
+"""Scene graph -> image generator (surface of /root/reference/scene_generation/model.py:12-172, training branch).
+
+Differences from the reference are confined to how the work is issued:
+  * every operator is a HIP launch (scene_generation_amd.ops); no ``.item()``/``.nonzero()`` host syncs except
+    the single small D2H copy of the class ids inside VectorPool.query (utils.py)
+  * ``gt_layout``/``wrong_layout`` tell the layout kernel that the first ``num_objs`` channels are the constant
+    one-hot block, so its backward only touches the ``rep_size`` appearance channels (model.py:165-168)
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .bilinear import crop_bbox_batch
+from .generators import mask_net, AppearanceEncoder, define_G
+from .graph import GraphTripleConv, GraphTripleConvNet
+from .layers import build_mlp, Embedding, Linear
+from .layout import masks_to_layout
+from .utils import VectorPool
+
+
+class Model(nn.Module):
+    def __init__(self, vocab, image_size=(64, 64), embedding_dim=128, gconv_dim=128, gconv_hidden_dim=512,
+                 gconv_pooling='avg', gconv_num_layers=5, mask_size=32, mlp_normalization='none',
+                 appearance_normalization='', activation='', n_downsample_global=4, box_dim=128,
+                 use_attributes=False, box_noise_dim=64, mask_noise_dim=64, pool_size=100, rep_size=32,
+                 ngf=64, n_blocks_global=9):
+        super().__init__()
+        self.vocab = vocab
+        self.image_size = image_size
+        self.use_attributes = use_attributes
+        self.box_noise_dim = box_noise_dim
+        self.mask_noise_dim = mask_noise_dim
+        self.object_size = 64
+        self.fake_pool = VectorPool(pool_size)
+
+        self.num_objs = len(vocab['object_to_idx'])
+        self.num_preds = len(vocab['pred_idx_to_name'])
+        self.obj_embeddings = Embedding(self.num_objs, embedding_dim)
+        self.pred_embeddings = Embedding(self.num_preds, embedding_dim)
+
+        attributes_dim = vocab['num_attributes'] if use_attributes else 0
+        if gconv_num_layers == 0:
+            self.gconv = Linear(embedding_dim, gconv_dim)
+        elif gconv_num_layers > 0:
+            self.gconv = GraphTripleConv(input_dim=embedding_dim, attributes_dim=attributes_dim, output_dim=gconv_dim,
+                                         hidden_dim=gconv_hidden_dim, pooling=gconv_pooling,
+                                         mlp_normalization=mlp_normalization)
+        self.gconv_net = None
+        if gconv_num_layers > 1:
+            self.gconv_net = GraphTripleConvNet(input_dim=gconv_dim, hidden_dim=gconv_hidden_dim,
+                                                pooling=gconv_pooling, num_layers=gconv_num_layers - 1,
+                                                mlp_normalization=mlp_normalization)
+
+        self.box_dim = box_dim
+        self.box_net = build_mlp([self.box_dim, gconv_hidden_dim, 4], batch_norm=mlp_normalization)
+
+        self.g_mask_dim = gconv_dim + mask_noise_dim
+        self.mask_net = mask_net(self.g_mask_dim, mask_size)
+
+        self.repr_input = self.g_mask_dim
+        self.repr_net = build_mlp([self.repr_input, 64, rep_size], batch_norm=mlp_normalization)
+
+        self.image_encoder = AppearanceEncoder(vocab=vocab, arch='C4-64-2,C4-128-2,C4-256-2',
+                                               normalization=appearance_normalization, activation=activation,
+                                               padding='valid', vecs_size=self.g_mask_dim)
+
+        self.layout_to_image = define_G(self.num_objs + rep_size, 3, ngf, n_downsample_global, n_blocks_global,
+                                        'instance')
+        # hooks that are not part of the reference surface
+        self.noise_override = None          # (1, mask_noise_dim) row used instead of torch.randn (parity tests)
+        self.layout_objects_hint = 0        # objects/image the layout kernel provisions LDS for (0 = default 12)
+        self.objs_host = None               # optional host copy of ``objs`` (skips VectorPool's D2H copy)
+
+    def forward(self, gt_imgs, objs, triples, obj_to_img, boxes_gt=None, masks_gt=None, attributes=None,
+                test_mode=False, use_gt_box=False, features=None):
+        if test_mode:
+            raise NotImplementedError('Model.forward(test_mode=True) (model.py:111-117) is SURVEY 8f rank 1 (next)')
+        O = objs.size(0)
+        N = gt_imgs.size(0)
+        obj_vecs, pred_vecs = self.scene_graph_to_vectors(objs, triples, attributes)
+        box_vecs, mask_vecs, scene_layout_vecs, wrong_layout_vecs = \
+            self.create_components_vecs(gt_imgs, boxes_gt, obj_to_img, objs, obj_vecs, features)
+
+        boxes_pred = self.box_net(box_vecs)
+
+        mask_scores = self.mask_net(mask_vecs.view(O, -1, 1, 1))
+        masks_pred = ops.activation(mask_scores.squeeze(1), ops.ACT_SIGMOID)
+
+        H, W = self.image_size
+        kw = dict(num_images=N, validate=False, max_per_image=self.layout_objects_hint)
+        gt_layout = masks_to_layout(scene_layout_vecs, boxes_gt, masks_gt, obj_to_img, H, W, test_mode=False,
+                                    grad_from_channel=self.num_objs, **kw)
+        # pred_layout feeds no loss (train.py:203,219); back-propagating through its masks raises loudly
+        pred_layout = masks_to_layout(scene_layout_vecs, boxes_gt, masks_pred, obj_to_img, H, W,
+                                      test_mode=False, grad_from_channel=self.num_objs, **kw)
+        wrong_layout = masks_to_layout(wrong_layout_vecs, boxes_gt, masks_gt, obj_to_img, H, W, test_mode=False,
+                                       grad_from_channel=self.num_objs, **kw)
+        imgs_pred = self.layout_to_image(gt_layout)
+        return imgs_pred, boxes_pred, masks_pred, gt_layout, pred_layout, wrong_layout
+
+    def scene_graph_to_vectors(self, objs, triples, attributes):
+        s, p, o = triples[:, 0], triples[:, 1], triples[:, 2]
+        edges = torch.stack([s, o], dim=1)                   # index plumbing (T x 2 int64)
+        obj_vecs = self.obj_embeddings(objs)
+        pred_vecs = self.pred_embeddings(p.contiguous())
+        if self.use_attributes:
+            obj_vecs = ops.concat_cols(obj_vecs, attributes)
+        if isinstance(self.gconv, Linear):
+            obj_vecs = self.gconv(obj_vecs)
+        else:
+            obj_vecs, pred_vecs = self.gconv(obj_vecs, pred_vecs, edges)
+        if self.gconv_net is not None:
+            obj_vecs, pred_vecs = self.gconv_net(obj_vecs, pred_vecs, edges)
+        return obj_vecs, pred_vecs
+
+    def create_components_vecs(self, imgs, boxes, obj_to_img, objs, obj_vecs, features):
+        if features is not None:
+            raise NotImplementedError('inference-time feature injection (model.py:158-163) is SURVEY 8f (next)')
+        O = objs.size(0)
+        box_vecs = obj_vecs
+        if self.noise_override is not None:
+            noise = self.noise_override.to(obj_vecs.device, obj_vecs.dtype).view(1, self.mask_noise_dim)
+        else:                                                # ONE noise row per batch (model.py:149-151)
+            noise = torch.randn((1, self.mask_noise_dim), dtype=obj_vecs.dtype, device=obj_vecs.device)
+        mask_vecs = ops.concat_cols(obj_vecs, noise.expand(O, self.mask_noise_dim))
+
+        crops = crop_bbox_batch(imgs, boxes, obj_to_img, self.object_size)
+        obj_repr = self.repr_net(self.image_encoder(crops))
+
+        one_hot_obj = ops.one_hot(objs, self.num_objs)
+        layout_vecs = ops.concat_cols(one_hot_obj, obj_repr)
+
+        wrong_objs_rep = self.fake_pool.query(objs, obj_repr, objs_host=self.objs_host)
+        wrong_layout_vecs = ops.concat_cols(one_hot_obj, wrong_objs_rep)
+        return box_vecs, mask_vecs, layout_vecs, wrong_layout_vecs

@@ -1,0 +1,818 @@
+"""Autograd operators over the C ABI of libsg2im_hip.so (include/sg2im_hip.h).
+
+PyTorch-ROCm is used here as plumbing only: device allocation (torch.empty), the autograd tape and
+the current HIP stream.  Every forward/backward below is one or a few hand-written gfx950 kernel
+launches through ctypes; there is no eager/CPU fallback -- a CPU tensor raises.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _hip
+from ._hip import sgConvDesc
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+LOSS_MSE_CONST, LOSS_MSE, LOSS_L1, LOSS_BCE_CONST = 0, 1, 2, 3
+
+_ws_cache = {}
+
+
+def _L():
+    return _hip.lib()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _dev(t, name='tensor'):
+    if not t.is_cuda:
+        raise RuntimeError('scene_generation_amd: %s is on %s -- the MI355X HIP path has no CPU fallback'
+                           % (name, t.device))
+    return t
+
+
+def _f32(t, name='tensor'):
+    _dev(t, name)
+    if t.dtype != torch.float32:
+        raise TypeError('%s must be float32, got %s' % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _i64(t, name='index'):
+    _dev(t, name)
+    if t.dtype != torch.int64:
+        raise TypeError('%s must be int64, got %s' % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def workspace(nbytes, device):
+    """Per-device scratch, grown on demand.  Safe to share: every consumer is ordered on the current stream."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _call(name, *args):
+    rc = getattr(_L(), name)(*args)
+    if rc != 0:
+        raise RuntimeError('%s failed (rc=%d): %s' % (name, rc, _hip.last_error()))
+
+
+# =============================================================================================
+# convolution family
+# =============================================================================================
+
+def conv_out_size(size, k, stride, pad, upsample=1):
+    return (size * upsample + 2 * pad - k) // stride + 1
+
+
+def _conv_desc(N, C1, C2, H, W, Cout, KS, stride, pad, reflect, upsample, OH, OW, out_pad=0, x2_broadcast=0):
+    return sgConvDesc(N, C1, C2, H, W, Cout, KS, stride, pad, 1 if reflect else 0, upsample, OH, OW, out_pad,
+                      x2_broadcast)
+
+
+class Conv2dFn(Function):
+    """act(conv2d([x1 ‖ x2]) + bias) with reflection padding / nearest-x2 upsampling / channel concat folded
+    into the implicit-GEMM gather (nn.Conv2d call sites: generators.py:20-27,68-89; layers.py:160-180,251-270;
+    discriminators.py:137-158,215-234)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, stride, pad, reflect, upsample, act, slope):
+        x1 = _f32(x1, 'conv input')
+        x2 = None if x2 is None else _f32(x2, 'conv input 2')
+        weight = _f32(weight, 'conv weight')
+        N, C1, H, W = x1.shape
+        C2 = 0 if x2 is None else x2.size(1)
+        Cout, Cin, KS, KS2 = weight.shape
+        assert KS == KS2 and Cin == C1 + C2, 'conv weight %s does not match input channels %d' % (tuple(weight.shape), C1 + C2)
+        OH, OW = conv_out_size(H, KS, stride, pad, upsample), conv_out_size(W, KS, stride, pad, upsample)
+        bcast = 1 if (x2 is not None and x2.dim() == 2) else 0      # [N, C2] broadcast over H x W
+        d = _conv_desc(N, C1, C2, H, W, Cout, KS, stride, pad, reflect, upsample, OH, OW, 0, bcast)
+        y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=x1.device)
+        _call('sg_conv2d_fwd', ctypes.byref(d), _p(x1), _p(x2), _p(weight), _p(bias), _p(y), act, slope, _stream())
+        ctx.desc = d
+        ctx.cfg = (act, slope, bias is not None)
+        ctx.save_for_backward(x1, x2, weight, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x1, x2, weight, y = ctx.saved_tensors
+        d = ctx.desc
+        act, slope, has_bias = ctx.cfg
+        gy = _f32(gy)
+        s = _stream()
+        if act != ACT_NONE:
+            g2 = torch.empty_like(gy)
+            _call('sg_act_bwd', _p(y), _p(gy), _p(g2), gy.numel(), act, slope, s)
+            gy = g2
+        need_x1, need_x2, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and x2 is not None, ctx.needs_input_grad[2]
+        if need_x2 and d.x2_broadcast:
+            raise NotImplementedError('gradient w.r.t. a broadcast second conv source (the constant one-hot map)')
+        need_b = has_bias and ctx.needs_input_grad[3]
+        gx1 = gx2 = gw = gb = None
+        dev = gy.device
+        if need_x1 or need_x2:
+            wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 1)
+            ws = workspace(wsb, dev)
+            fold = d.pad_reflect or d.upsample == 2
+            GH = d.H * d.upsample + (2 * d.pad if d.pad_reflect else 0)
+            GW = d.W * d.upsample + (2 * d.pad if d.pad_reflect else 0)
+
+            def dgrad(c0, c1):
+                g = torch.empty(d.N, c1 - c0, GH, GW, dtype=torch.float32, device=dev)
+                _call('sg_conv2d_dgrad', ctypes.byref(d), _p(gy), _p(weight), _p(g), c0, c1, _p(ws), wsb, s)
+                if fold:
+                    out = torch.empty(d.N, c1 - c0, d.H, d.W, dtype=torch.float32, device=dev)
+                    _call('sg_pad_upsample_bwd', _p(g), _p(out), d.N * (c1 - c0), d.H, d.W,
+                          d.pad if d.pad_reflect else 0, d.upsample, s)
+                    return out
+                return g
+            if need_x1:
+                gx1 = dgrad(0, d.C1)
+            if need_x2:
+                gx2 = dgrad(d.C1, d.C1 + d.C2)
+        if need_w or need_b:
+            if need_w:
+                wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 2)
+                ws = workspace(wsb, dev)
+                gw = torch.empty_like(weight)
+                gb = torch.empty(d.Cout, dtype=torch.float32, device=dev) if need_b else None
+                _call('sg_conv2d_wgrad', ctypes.byref(d), _p(gy), _p(x1), _p(x2), _p(gw), _p(gb), _p(ws), wsb, s)
+            else:
+                gb = torch.empty(d.Cout, dtype=torch.float32, device=dev)
+                _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, s)
+        return gx1, gx2, gw, gb, None, None, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, upsample=1, act=ACT_NONE, slope=0.0, x2=None):
+    return Conv2dFn.apply(x, x2, weight, bias, stride, pad, reflect, upsample, act, float(slope))
+
+
+class ConvTranspose2dFn(Function):
+    """nn.ConvTranspose2d(k3, s2, p1, output_padding=1) of the generator's up path (generators.py:83-87)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, out_pad):
+        x = _f32(x, 'convT input')
+        weight = _f32(weight, 'convT weight')
+        N, Cin, H, W = x.shape
+        Cin2, Cout, KS, _ = weight.shape
+        assert Cin == Cin2
+        OH = (H - 1) * stride - 2 * pad + KS + out_pad
+        OW = (W - 1) * stride - 2 * pad + KS + out_pad
+        d = _conv_desc(N, Cin, 0, H, W, Cout, KS, stride, pad, False, 1, OH, OW, out_pad)
+        y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=x.device)
+        wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 0)
+        ws = workspace(wsb, x.device)
+        _call('sg_convT2d_fwd', ctypes.byref(d), _p(x), _p(weight), _p(bias), _p(y), _p(ws), wsb, _stream())
+        ctx.desc = d
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        d = ctx.desc
+        gy = _f32(gy)
+        s = _stream()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _call('sg_convT2d_dgrad', ctypes.byref(d), _p(gy), _p(weight), _p(gx), s)
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 2)
+            ws = workspace(wsb, gy.device)
+            gw = torch.empty_like(weight)
+            gb = torch.empty(d.Cout, dtype=torch.float32, device=gy.device) if need_b else None
+            _call('sg_convT2d_wgrad', ctypes.byref(d), _p(gy), _p(x), _p(gw), _p(gb), _p(ws), wsb, s)
+        elif need_b:
+            gb = torch.empty(d.Cout, dtype=torch.float32, device=gy.device)
+            _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, s)
+        return gx, gw, gb, None, None, None
+
+
+def conv_transpose2d(x, weight, bias=None, stride=2, pad=1, out_pad=1):
+    return ConvTranspose2dFn.apply(x, weight, bias, stride, pad, out_pad)
+
+
+# =============================================================================================
+# dense layers
+# =============================================================================================
+
+class LinearFn(Function):
+    """act(x W^T + b): nn.Linear (+ the ReLU build_mlp appends, layers.py:215-231)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, slope):
+        x = _f32(x, 'linear input')
+        weight = _f32(weight, 'linear weight')
+        rows, in_f = x.shape
+        out_f = weight.size(0)
+        assert weight.size(1) == in_f
+        y = torch.empty(rows, out_f, dtype=torch.float32, device=x.device)
+        if rows > 0:
+            _call('sg_linear_fwd', _p(x), _p(weight), _p(bias), _p(y), rows, in_f, out_f, act, slope, _stream())
+        ctx.cfg = (act, slope, bias is not None)
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        act, slope, has_bias = ctx.cfg
+        gy = _f32(gy)
+        rows, in_f = x.shape
+        out_f = weight.size(0)
+        s = _stream()
+        if rows == 0:
+            return (torch.zeros_like(x), torch.zeros_like(weight),
+                    torch.zeros(out_f, device=x.device) if has_bias else None, None, None)
+        if act != ACT_NONE:
+            g2 = torch.empty_like(gy)
+            _call('sg_act_bwd', _p(y), _p(gy), _p(g2), gy.numel(), act, slope, s)
+            gy = g2
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _call('sg_linear_bwd_data', _p(gy), _p(weight), _p(gx), rows, in_f, out_f, s)
+        need_b = has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty_like(weight)
+            gb = torch.empty(out_f, dtype=torch.float32, device=x.device) if need_b else None
+            _call('sg_linear_bwd_weight', _p(gy), _p(x), _p(gw), _p(gb), rows, in_f, out_f, s)
+        elif need_b:
+            gb = torch.empty(out_f, dtype=torch.float32, device=x.device)
+            _call('sg_channel_sum', _p(gy), _p(gb), rows, out_f, 1, s)
+        return gx, gw, gb, None, None
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, slope=0.0):
+    return LinearFn.apply(x, weight, bias, act, float(slope))
+
+
+class ActFn(Function):
+    @staticmethod
+    def forward(ctx, x, act, slope):
+        x = _f32(x)
+        y = torch.empty_like(x)
+        _call('sg_act_fwd', _p(x), _p(y), x.numel(), act, slope, _stream())
+        ctx.cfg = (act, slope)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, = ctx.saved_tensors
+        gy = _f32(gy)
+        gx = torch.empty_like(gy)
+        _call('sg_act_bwd', _p(y), _p(gy), _p(gx), gy.numel(), ctx.cfg[0], ctx.cfg[1], _stream())
+        return gx, None, None
+
+
+def activation(x, act, slope=0.0):
+    return ActFn.apply(x, act, float(slope))
+
+
+# =============================================================================================
+# normalisation / pooling
+# =============================================================================================
+
+class InstanceNormFn(Function):
+    """act(InstanceNorm2d(x)) [+ skip]  (affine=False, eps 1e-5: layers.py:296)."""
+
+    @staticmethod
+    def forward(ctx, x, skip, eps, act, slope):
+        x = _f32(x, 'instance-norm input')
+        skip = None if skip is None else _f32(skip)
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(N * C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        _call('sg_instnorm_fwd', _p(x), _p(skip), _p(y), _p(mean), _p(rstd), N * C, H * W, eps, act, slope, _stream())
+        ctx.cfg = (act, slope, skip is not None)
+        ctx.save_for_backward(x, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, mean, rstd = ctx.saved_tensors
+        act, slope, has_skip = ctx.cfg
+        gy = _f32(gy)
+        N, C, H, W = x.shape
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _call('sg_instnorm_bwd', _p(x), _p(gy), _p(mean), _p(rstd), _p(gx), N * C, H * W, act, slope, _stream())
+        return gx, (gy if has_skip and ctx.needs_input_grad[1] else None), None, None, None
+
+
+def instance_norm(x, skip=None, eps=1e-5, act=ACT_NONE, slope=0.0):
+    return InstanceNormFn.apply(x, skip, float(eps), act, float(slope))
+
+
+class BatchNormFn(Function):
+    """act(BatchNorm(x)) over (N, HW) per channel, training or eval mode (generators.py:22; layers.py:23-31)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, nbt, training, momentum, eps, act, slope):
+        x = _f32(x, 'batch-norm input')
+        shp = x.shape
+        N, C = shp[0], shp[1]
+        HW = x.numel() // (N * C) if x.numel() else 1
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        _call('sg_batchnorm_fwd', _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(rmean), _p(rvar), _p(nbt),
+              N, C, HW, eps, momentum, 1 if training else 0, act, slope, _stream())
+        ctx.cfg = (N, C, HW, act, slope)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        N, C, HW, act, slope = ctx.cfg
+        gy = _f32(gy)
+        gx = torch.empty_like(x)
+        gg = torch.empty(C, dtype=torch.float32, device=x.device) if gamma is not None else None
+        gb = torch.empty(C, dtype=torch.float32, device=x.device) if beta is not None else None
+        _call('sg_batchnorm_bwd', _p(x), _p(gy), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(gx), _p(gg), _p(gb), N, C, HW,
+              act, slope, _stream())
+        return gx, gg, gb, None, None, None, None, None, None, None, None
+
+
+def batch_norm(x, gamma, beta, rmean, rvar, nbt, training, momentum=0.1, eps=1e-5, act=ACT_NONE, slope=0.0):
+    return BatchNormFn.apply(x, gamma, beta, rmean, rvar, nbt, training, float(momentum), float(eps), act, float(slope))
+
+
+class AvgPool3s2Fn(Function):
+    """nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False) (discriminators.py:100,186)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32(x)
+        N, C, H, W = x.shape
+        OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        y = torch.empty(N, C, OH, OW, dtype=torch.float32, device=x.device)
+        _call('sg_avgpool3s2_fwd', _p(x), _p(y), N * C, H, W, OH, OW, _stream())
+        ctx.shape = (N, C, H, W, OH, OW)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W, OH, OW = ctx.shape
+        gy = _f32(gy)
+        gx = torch.empty(N, C, H, W, dtype=torch.float32, device=gy.device)
+        _call('sg_avgpool3s2_bwd', _p(gy), _p(gx), N * C, H, W, OH, OW, _stream())
+        return gx
+
+
+def avgpool3s2(x):
+    return AvgPool3s2Fn.apply(x)
+
+
+class GapFn(Function):
+    """GlobalAvgPool (layers.py:82-85)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32(x)
+        N, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (N * C)
+        y = torch.empty(N, C, dtype=torch.float32, device=x.device)
+        _call('sg_gap_fwd', _p(x), _p(y), N * C, HW, _stream())
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        shp = ctx.shape
+        gy = _f32(gy)
+        gx = torch.empty(shp, dtype=torch.float32, device=gy.device)
+        NC = shp[0] * shp[1]
+        _call('sg_gap_bwd', _p(gy), _p(gx), NC, gx.numel() // NC, _stream())
+        return gx
+
+
+def global_avg_pool(x):
+    return GapFn.apply(x)
+
+
+class Upsample2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32(x)
+        N, C, H, W = x.shape
+        y = torch.empty(N, C, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
+        _call('sg_upsample2_fwd', _p(x), _p(y), N * C, H, W, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = _f32(gy)
+        N, C, H2, W2 = gy.shape
+        gx = torch.empty(N, C, H2 // 2, W2 // 2, dtype=torch.float32, device=gy.device)
+        _call('sg_pad_upsample_bwd', _p(gy), _p(gx), N * C, H2 // 2, W2 // 2, 0, 2, _stream())
+        return gx
+
+
+def upsample2(x):
+    return Upsample2Fn.apply(x)
+
+
+class ReflectPadFn(Function):
+    @staticmethod
+    def forward(ctx, x, pad):
+        x = _f32(x)
+        N, C, H, W = x.shape
+        y = torch.empty(N, C, H + 2 * pad, W + 2 * pad, dtype=torch.float32, device=x.device)
+        _call('sg_reflect_pad_fwd', _p(x), _p(y), N * C, H, W, pad, _stream())
+        ctx.pad = pad
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = _f32(gy)
+        p = ctx.pad
+        N, C, PH, PW = gy.shape
+        gx = torch.empty(N, C, PH - 2 * p, PW - 2 * p, dtype=torch.float32, device=gy.device)
+        _call('sg_pad_upsample_bwd', _p(gy), _p(gx), N * C, PH - 2 * p, PW - 2 * p, p, 1, _stream())
+        return gx, None
+
+
+def reflect_pad(x, pad):
+    return ReflectPadFn.apply(x, pad)
+
+
+# =============================================================================================
+# graph convolution
+# =============================================================================================
+_csr_cache = {}
+
+
+def build_csr(edges, O):
+    """Destination-major CSR of the (pass, t) entries (device-side; cached per edges tensor version)."""
+    edges = _i64(edges, 'edges')
+    key = (edges.data_ptr(), edges._version, edges.size(0), O)
+    hit = _csr_cache.get('k')
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    T = edges.size(0)
+    off = torch.empty(O + 1, dtype=torch.int32, device=edges.device)
+    ent = torch.empty(max(2 * T, 1), dtype=torch.int32, device=edges.device)
+    _call('sg_build_csr', _p(edges), T, O, _p(off), _p(ent), _stream())
+    _csr_cache['k'] = (key, off, ent, edges)      # keep edges alive so the data_ptr key stays unique
+    return off, ent
+
+
+class GatherConcatFn(Function):
+    """cur_t = [obj[s], pred, obj[o]] (graph.py:79-84); backward = deterministic segmented sums."""
+
+    @staticmethod
+    def forward(ctx, obj, pred, edges, off, ent):
+        obj, pred = _f32(obj), _f32(pred)
+        T, Do, Dp = edges.size(0), obj.size(1), pred.size(1)
+        out = torch.empty(T, 2 * Do + Dp, dtype=torch.float32, device=obj.device)
+        _call('sg_gather_concat_fwd', _p(obj), _p(pred), _p(edges), _p(out), T, Do, Dp, _stream())
+        ctx.dims = (obj.size(0), T, Do, Dp)
+        ctx.save_for_backward(off, ent)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        off, ent = ctx.saved_tensors
+        O, T, Do, Dp = ctx.dims
+        g = _f32(g)
+        s = _stream()
+        g_obj = g_pred = None
+        if ctx.needs_input_grad[0]:
+            g_obj = torch.empty(O, Do, dtype=torch.float32, device=g.device)
+            _call('sg_segment_sum', _p(g), 2 * Do + Dp, 0, Do + Dp, Do, _p(off), _p(ent), _p(g_obj), O, 0, s)
+        if ctx.needs_input_grad[1]:
+            g_pred = torch.empty(T, Dp, dtype=torch.float32, device=g.device)
+            _call('sg_copy_cols', _p(g), 2 * Do + Dp, Do, _p(g_pred), Dp, 0, T, Dp, s)
+        return g_obj, g_pred, None, None, None
+
+
+class TriplePoolFn(Function):
+    """new_t -> (pooled object vectors, new predicate vectors): the split + scatter_add + avg of graph.py:89-116,
+    accumulated in the reference's CPU order (bit-exact)."""
+
+    @staticmethod
+    def forward(ctx, new_t, edges, off, ent, O, H, Dout, avg):
+        new_t = _f32(new_t)
+        T = new_t.size(0)
+        ld = 2 * H + Dout
+        pooled = torch.empty(O, H, dtype=torch.float32, device=new_t.device)
+        new_p = torch.empty(T, Dout, dtype=torch.float32, device=new_t.device)
+        s = _stream()
+        _call('sg_segment_sum', _p(new_t), ld, 0, H + Dout, H, _p(off), _p(ent), _p(pooled), O, 1 if avg else 0, s)
+        _call('sg_copy_cols', _p(new_t), ld, H, _p(new_p), Dout, 0, T, Dout, s)
+        ctx.dims = (T, O, H, Dout, avg)
+        ctx.save_for_backward(edges, off)
+        return pooled, new_p
+
+    @staticmethod
+    def backward(ctx, g_pooled, g_new_p):
+        edges, off = ctx.saved_tensors
+        T, O, H, Dout, avg = ctx.dims
+        dev = edges.device
+        g_pooled = _f32(g_pooled) if g_pooled is not None else torch.zeros(O, H, device=dev)
+        g_new_p = None if g_new_p is None else _f32(g_new_p)
+        g = torch.empty(T, 2 * H + Dout, dtype=torch.float32, device=dev)
+        _call('sg_pool_bwd', _p(g_pooled), _p(g_new_p), _p(edges), _p(off), _p(g), T, H, Dout, 1 if avg else 0, _stream())
+        return g, None, None, None, None, None, None, None
+
+
+class EmbeddingFn(Function):
+    @staticmethod
+    def forward(ctx, table, idx):
+        table, idx = _f32(table), _i64(idx)
+        out = torch.empty(idx.numel(), table.size(1), dtype=torch.float32, device=table.device)
+        _call('sg_embedding_fwd', _p(table), _p(idx), _p(out), idx.numel(), table.size(1), _stream())
+        ctx.rows = table.size(0)
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        g = _f32(g)
+        gt = torch.empty(ctx.rows, g.size(1), dtype=torch.float32, device=g.device)
+        _call('sg_embedding_bwd', _p(g), _p(idx), _p(gt), idx.numel(), ctx.rows, g.size(1), _stream())
+        return gt, None
+
+
+def embedding(table, idx):
+    return EmbeddingFn.apply(table, idx)
+
+
+class ConcatColsFn(Function):
+    """torch.cat(tensors, dim=1) for 2-D fp32 tensors (model.py:134,152,168,171)."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        ts = [_f32(t) for t in ts]
+        rows = ts[0].size(0)
+        widths = [t.size(1) for t in ts]
+        out = torch.empty(rows, sum(widths), dtype=torch.float32, device=ts[0].device)
+        s, off = _stream(), 0
+        for t, w in zip(ts, widths):
+            _call('sg_copy_cols', _p(t), w, 0, _p(out), out.size(1), off, rows, w, s)
+            off += w
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _f32(g)
+        rows, ld = g.shape
+        outs, off, s = [], 0, _stream()
+        for i, w in enumerate(ctx.widths):
+            if ctx.needs_input_grad[i]:
+                gi = torch.empty(rows, w, dtype=torch.float32, device=g.device)
+                _call('sg_copy_cols', _p(g), ld, off, _p(gi), w, 0, rows, w, s)
+                outs.append(gi)
+            else:
+                outs.append(None)
+            off += w
+        return tuple(outs)
+
+
+def concat_cols(*ts):
+    return ConcatColsFn.apply(*ts)
+
+
+def one_hot(idx, classes, dtype=torch.float32):
+    idx = _i64(idx)
+    out = torch.empty(idx.numel(), classes, dtype=torch.float32, device=idx.device)
+    _call('sg_one_hot', _p(idx), _p(out), idx.numel(), classes, classes, 0, _stream())
+    return out
+
+
+class ConcatChannelsFn(Function):
+    """materialised torch.cat((a, b), dim=1) on NCHW (API completeness; the training path folds it into conv2d)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32(a), _f32(b)
+        N, Ca, H, W = a.shape
+        Cb = b.size(1)
+        out = torch.empty(N, Ca + Cb, H, W, dtype=torch.float32, device=a.device)
+        _call('sg_concat_channels', _p(a), _p(b), _p(out), N, Ca, Cb, H * W, _stream())
+        ctx.ca = Ca
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.ca].contiguous(), g[:, ctx.ca:].contiguous()
+
+
+# =============================================================================================
+# layout + crops + vector pool
+# =============================================================================================
+
+def segment_offsets(obj_to_img, N):
+    obj_to_img = _i64(obj_to_img, 'obj_to_img')
+    off = torch.empty(N + 1, dtype=torch.int32, device=obj_to_img.device)
+    _call('sg_segment_offsets', _p(obj_to_img), obj_to_img.numel(), N, _p(off), _stream())
+    return off
+
+
+class MasksToLayoutFn(Function):
+    """masks_to_layout (layout.py:64-93) train branch; gradient w.r.t. vecs (columns >= grad_from)."""
+
+    @staticmethod
+    def forward(ctx, vecs, boxes, masks, seg_off, N, H, W, avg, grad_from, max_per_image):
+        vecs, boxes = _f32(vecs, 'vecs'), _f32(boxes, 'boxes')
+        _dev(masks, 'masks')
+        if masks.dtype == torch.int64:
+            i64 = 1
+        elif masks.dtype == torch.float32:
+            i64 = 0
+        else:
+            raise TypeError('masks must be int64 or float32')
+        masks = masks if masks.is_contiguous() else masks.contiguous()
+        O, D = vecs.shape
+        M = masks.size(1)
+        out = torch.empty(N, D, H, W, dtype=torch.float32, device=vecs.device)
+        _call('sg_masks_to_layout_fwd', _p(vecs), _p(boxes), _p(masks), i64, _p(seg_off), _p(out), N, O, D, M, H, W,
+              1 if avg else 0, max_per_image, _stream())
+        ctx.cfg = (N, O, D, M, H, W, avg, grad_from, i64)
+        ctx.save_for_backward(boxes, masks, seg_off)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        boxes, masks, seg_off = ctx.saved_tensors
+        N, O, D, M, H, W, avg, grad_from, i64 = ctx.cfg
+        gv = None
+        if ctx.needs_input_grad[0]:
+            gout = _f32(gout)
+            gv = torch.empty(O, D, dtype=torch.float32, device=gout.device)
+            _call('sg_masks_to_layout_bwd_vecs', _p(gout), _p(boxes), _p(masks), i64, None, _p(seg_off), _p(gv), N, O, D, M,
+                  H, W, 1 if avg else 0, grad_from, _stream())
+        if ctx.needs_input_grad[2]:
+            raise NotImplementedError(
+                'masks_to_layout: gradient w.r.t. masks is not implemented (no loss of the training step consumes '
+                'pred_layout: model.py:120, train.py:203,219); detach the masks or do not backprop through this layout')
+        return gv, None, None, None, None, None, None, None, None, None
+
+
+class CropBBoxFn(Function):
+    """crop_bbox_batch (bilinear.py:26-41,67-130): gather forward, scatter-add backward w.r.t. feats."""
+
+    @staticmethod
+    def forward(ctx, feats, boxes, idx, HH, WW):
+        feats, boxes, idx = _f32(feats, 'feats'), _f32(boxes, 'bbox'), _i64(idx, 'bbox_to_feats')
+        N, C, H, W = feats.shape
+        B = boxes.size(0)
+        out = torch.empty(B, C, HH, WW, dtype=torch.float32, device=feats.device)
+        _call('sg_crop_bbox_fwd', _p(feats), _p(boxes), _p(idx), _p(out), N, C, H, W, B, HH, WW, _stream())
+        ctx.cfg = (N, C, H, W, B, HH, WW)
+        ctx.save_for_backward(boxes, idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        boxes, idx = ctx.saved_tensors
+        N, C, H, W, B, HH, WW = ctx.cfg
+        gf = None
+        if ctx.needs_input_grad[0]:
+            g = _f32(g)
+            gf = torch.zeros(N, C, H, W, dtype=torch.float32, device=g.device)
+            _call('sg_crop_bbox_bwd', _p(g), _p(boxes), _p(idx), _p(gf), N, C, H, W, B, HH, WW, _stream())
+        return gf, None, None, None, None
+
+
+def vector_pool_exchange(pool, vectors, plan):
+    vectors = _f32(vectors)
+    O, R = vectors.shape
+    out = torch.empty_like(vectors)
+    _call('sg_vector_pool_exchange', _p(pool), _p(vectors), _p(plan), _p(out), O, R, pool.size(1), _stream())
+    return out
+
+
+# =============================================================================================
+# losses
+# =============================================================================================
+
+class ScalarLossFn(Function):
+    """scale * sum_i l(a_i, b_i | target) as a 0-dim device tensor (no host sync)."""
+
+    @staticmethod
+    def forward(ctx, a, b, kind, target, scale):
+        a = _f32(a, 'loss input')
+        b = None if b is None else _f32(b, 'loss target')
+        out = torch.empty(1, dtype=torch.float32, device=a.device)
+        wsb = _L().sg_loss_ws_bytes(a.numel())
+        ws = torch.empty(wsb, dtype=torch.uint8, device=a.device)
+        _call('sg_loss_fwd', kind, _p(a), _p(b), target, a.numel(), scale, _p(out), 0, _p(ws), wsb, _stream())
+        ctx.cfg = (kind, target, scale)
+        ctx.save_for_backward(a, b)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        kind, target, scale = ctx.cfg
+        gout = _f32(gout.reshape(1))
+        ga = torch.empty_like(a)
+        _call('sg_loss_bwd', kind, _p(a), _p(b), target, a.numel(), scale, _p(gout), _p(ga), _stream())
+        return ga, None, None, None, None
+
+
+def mse_const(x, target):
+    """nn.MSELoss()(x, full_like(x, target)) (losses.py:147-175)."""
+    return ScalarLossFn.apply(x, None, LOSS_MSE_CONST, float(target), 1.0 / x.numel())
+
+
+def mse(a, b):
+    return ScalarLossFn.apply(a, b.detach(), LOSS_MSE, 0.0, 1.0 / a.numel())
+
+
+def l1(a, b):
+    return ScalarLossFn.apply(a, b.detach(), LOSS_L1, 0.0, 1.0 / a.numel())
+
+
+def bce_logits_const(x, target):
+    """bce_loss(x, full_like(x, target)) (losses.py:26-44)."""
+    return ScalarLossFn.apply(x, None, LOSS_BCE_CONST, float(target), 1.0 / x.numel())
+
+
+class CrossEntropyFn(Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits, target = _f32(logits), _i64(target)
+        rows, classes = logits.shape
+        row_loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        out = torch.empty(1, dtype=torch.float32, device=logits.device)
+        _call('sg_cross_entropy_fwd', _p(logits), _p(target), rows, classes, _p(row_loss), _p(out), _stream())
+        ctx.save_for_backward(logits, target)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, target = ctx.saved_tensors
+        rows, classes = logits.shape
+        gout = _f32(gout.reshape(1))
+        gl = torch.empty_like(logits)
+        _call('sg_cross_entropy_bwd', _p(logits), _p(target), rows, classes, _p(gout), _p(gl), _stream())
+        return gl, None
+
+
+def cross_entropy(logits, target):
+    return CrossEntropyFn.apply(logits, target)
+
+
+# =============================================================================================
+# optimiser / misc
+# =============================================================================================
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
+    bc1 = 1.0 - beta1 ** step
+    bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
+    _call('sg_adam_step', _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, bc1, bc2_sqrt, _stream())
+
+
+def fill_(t, value):
+    _call('sg_fill', _p(t), float(value), t.numel(), _stream())
+    return t
+
+
+def scale_(t, alpha):
+    _call('sg_scale', _p(t), float(alpha), t.numel(), _stream())
+    return t
+
+
+# ---- profiler ----
+def prof_enable(on=True):
+    _L().sg_prof_enable(1 if on else 0)
+
+
+def prof_reset():
+    _L().sg_prof_reset()
+
+
+def prof_read():
+    """-> {kind: dict(ms, launches, flops, bytes)} since the last reset (synchronises the recorded events)."""
+    L = _L()
+    out = {}
+    for k in range(L.sg_prof_num_kinds()):
+        ms, fl, by = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        n = ctypes.c_int64()
+        L.sg_prof_read(k, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(by))
+        out[L.sg_prof_kind_name(k).decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+    return out

@@ -1,0 +1,107 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, torch.distributed 'nccl' (= RCCL over
+xGMI on ROCm), gradients averaged with bucketed all-reduces over slices of each optimiser's FLAT gradient buffer
+(optim.FlatParams), launched from autograd hooks while the rest of the backward is still running.
+
+The batched scene graph is block-diagonal (node ids are offset per image, coco.py:527-529), so the minibatch shards
+by image with no data-path exchange (synthetic.shard_batch); the only collective is the gradient mean.  What is
+NOT exchanged -- BatchNorm batch statistics, VectorPool contents, the noise row / use_gt coin -- is per rank, i.e.
+the semantics are "the reference run independently on each shard, gradients averaged" (SURVEY 8e).
+
+xGMI note: collectives are per-link bound (7 links x ~153 GB/s), so buckets are LARGE (default 64 MB): a few big
+reduce-scatter/all-gather rings amortise the per-collective latency; the 764.7 MB generator gradient is ~12 buckets.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns (rank, world)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world == 1:
+        return 0, 1
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+class GradReducer:
+    """Mean all-reduce of one FlatParams gradient buffer, bucketed + overlapped with backward.
+
+    Buckets are contiguous slices of the flat gradient in REVERSE parameter order (gradients become ready roughly
+    last-layer-first).  A post-accumulate-grad hook per parameter counts readiness; when a bucket is complete its
+    async all-reduce is issued immediately.  ``wait()`` (called before optimizer.step) flushes stragglers --
+    parameters that received no gradient this step still hold zeros, which is what the all-reduce must see.
+    """
+
+    def __init__(self, flat_params, bucket_bytes=64 << 20, group=None, overlap=True):
+        self.fp = flat_params
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.overlap = overlap
+        self.buckets = []            # (start, end, [param indices])
+        esz = self.fp.grad.element_size()
+        cur, cur_end = [], None
+        for i in reversed(range(len(self.fp.params))):
+            o, n = self.fp.offsets[i], self.fp.params[i].numel()
+            if cur_end is None:
+                cur_end = o + n
+            cur.append(i)
+            if (cur_end - o) * esz >= bucket_bytes:
+                self.buckets.append((o, cur_end, cur))
+                cur, cur_end = [], None
+        if cur:
+            self.buckets.append((self.fp.offsets[cur[-1]], cur_end, cur))
+        self.bucket_of = {}
+        for b, (_, _, idxs) in enumerate(self.buckets):
+            for i in idxs:
+                self.bucket_of[i] = b
+        self._pending = [len(idxs) for _, _, idxs in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+        self.active = True
+        if self.world > 1 and overlap:
+            for i, p in enumerate(self.fp.params):
+                if p.requires_grad:
+                    p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(param):
+            if not self.active or not param.requires_grad:
+                return
+            b = self.bucket_of[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0 and not self._launched[b]:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        s, e, _ = self.buckets[b]
+        self._launched[b] = True
+        self._works.append(dist.all_reduce(self.fp.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        """Complete the mean all-reduce of every bucket; resets the per-step bookkeeping."""
+        if self.world > 1 and self.active:
+            for b in range(len(self.buckets)):
+                if not self._launched[b]:
+                    self._launch(b)
+            for w in self._works:
+                w.wait()
+            self.fp.grad.mul_(1.0 / self.world)
+        self._works = []
+        self._pending = [len(idxs) for _, _, idxs in self.buckets]
+        self._launched = [False] * len(self.buckets)
+
+
+def broadcast_params(flat_params, src=0, group=None):
+    """Make every rank start from rank ``src``'s parameters (one collective over the flat buffer)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_params.flat, src=src, group=group)

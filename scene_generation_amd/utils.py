@@ -64,8 +64,8 @@ def plan_pool_query(classes, pool_len, pool_size, rng=random):
     Returns (src_kind, src_idx, slot) lists, one entry per object:
       out[i]   = vectors[src_idx[i]]            if src_kind[i] == 0   (a row of THIS batch, j <= i)
                = pool[class_i][src_idx[i]]      if src_kind[i] == 1   (content from BEFORE this query)
-      slot[i]  = pool slot of class_i that vectors[i] is stored to afterwards (always >= 0 here).
-    Later writes to the same (class, slot) win, exactly as the sequential reference loop.
+      slot[i]  = pool slot of class_i that vectors[i] is stored to afterwards, or -1 if a later object of the same
+                 batch overwrites that slot (later writes win, exactly as the sequential reference loop).
     """
     src_kind, src_idx, slot = [], [], []
     shadow = {}                                   # (class, slot) -> batch row currently stored there
@@ -92,6 +92,8 @@ def plan_pool_query(classes, pool_len, pool_size, rng=random):
             src_idx.append(r if j is None else j)
             shadow[(c, r)] = i
             slot.append(r)
+    # several objects of one batch may target the same (class, slot): only the LAST write survives
+    slot = [sl if shadow[(c, sl)] == i else -1 for i, (c, sl) in enumerate(zip(classes, slot))]
     return src_kind, src_idx, slot
 
 

@@ -1,0 +1,598 @@
+"""Parity of the hand-written HIP path (through the C ABI / ctypes) against the oracle on a real MI355X.
+
+Integer / index work is compared bit-exactly (graph pool, crop permutation, one-hot, CSR); floating point within
+the tolerance written at each assert (fp32; the MFMA f32 path is an exact k-ordered fma chain, differences come
+from summation order only).  Sizes are chosen so the CPU oracle finishes in seconds; full-size (BASELINE config 2/5)
+checks use size-independent properties.
+"""
+import random
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from oracle import sg_oracle as O
+from scene_generation_amd.synthetic import fill_deterministic, make_batch, make_vocab, batch_to, _hash_uniform
+from scene_generation_amd.args import parser
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def det(shape, salt, scale=1.0, shift=0.0):
+    n = int(np.prod(shape))
+    return _hash_uniform(n, salt).view(*shape) * 2 * scale + shift
+
+
+def close(a, b, tol=1e-5, name=''):
+    a = a.detach().double().cpu()
+    b = (torch.from_numpy(np.asarray(b)) if not isinstance(b, torch.Tensor) else b.detach()).double().cpu()
+    assert a.shape == b.shape, (name, tuple(a.shape), tuple(b.shape))
+    if a.numel() == 0:
+        return
+    assert torch.isfinite(a).all(), '%s: non-finite values' % name
+    err = (a - b).abs().max().item()
+    scale = max(1.0, b.abs().max().item())
+    assert err <= tol * scale, '%s: max err %.3e (scale %.3e, tol %.1e)' % (name, err, scale, tol)
+
+
+@pytest.fixture(scope='module')
+def hip():
+    assert torch.cuda.is_available(), 'gpu tests need a device'
+    from scene_generation_amd import ops, _hip
+    _hip.lib()      # fails loudly if the extension is missing
+    return ops
+
+
+# ------------------------------------------------------------------------------------------
+# GEMM / conv kernels vs torch fp32 CPU
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('rows,inf,outf,act', [(1, 7, 5, 0), (9, 163, 64, 1), (33, 454, 512, 1), (128, 512, 1152, 1),
+                                               (70, 129, 33, 2), (16, 1024, 172, 0)])
+def test_linear(hip, rows, inf, outf, act):
+    x, w, b = det((rows, inf), 1), det((outf, inf), 2, 0.1), det((outf,), 3, 0.1)
+    gy = det((rows, outf), 4)
+    xr, wr, br = [t.clone().requires_grad_() for t in (x, w, b)]
+    yr = F.linear(xr, wr, br)
+    yr = F.relu(yr) if act == 1 else (F.leaky_relu(yr, 0.2) if act == 2 else yr)
+    yr.backward(gy)
+    xg, wg, bg = [t.to(DEV).requires_grad_() for t in (x, w, b)]
+    yg = hip.linear(xg, wg, bg, act=act, slope=0.2)
+    yg.backward(gy.to(DEV))
+    close(yg, yr, 2e-5, 'y')
+    close(xg.grad, xr.grad, 2e-5, 'gx')
+    close(wg.grad, wr.grad, 2e-5, 'gw')
+    close(bg.grad, br.grad, 2e-5, 'gb')
+
+
+CONV_CASES = [
+    # N, C1, C2, H, W, Cout, KS, stride, pad, reflect, ups, act
+    (2, 5, 0, 12, 12, 8, 3, 1, 1, False, 1, 0),
+    (2, 12, 0, 16, 16, 8, 7, 1, 3, True, 1, 1),        # ReflectionPad(3)+Conv7 (generators.py:68)
+    (2, 8, 0, 16, 16, 16, 3, 2, 1, False, 1, 0),       # down-sampling conv
+    (2, 16, 0, 8, 8, 16, 3, 1, 1, True, 1, 0),         # ResnetBlock conv
+    (3, 7, 3, 17, 19, 8, 4, 2, 2, False, 1, 2),        # image-D first conv, concat folded, odd sizes
+    (3, 8, 0, 9, 10, 16, 4, 1, 2, False, 1, 0),        # image-D k4 s1 p2
+    (5, 3, 0, 32, 32, 8, 4, 2, 0, False, 1, 0),        # encoder C4-x-2 valid
+    (5, 24, 0, 4, 4, 24, 3, 1, 1, False, 2, 0),        # mask_net: upsample folded
+    (5, 24, 0, 8, 8, 1, 1, 1, 0, False, 1, 0),         # 1x1 head, Cout=1
+    (5, 1, 0, 16, 16, 8, 3, 2, 1, False, 1, 2),        # mask-D first conv (K=9)
+    (2, 64, 0, 16, 16, 3, 7, 1, 3, True, 1, 3),        # last G conv + tanh, Cout=3
+    (4, 130, 0, 8, 8, 140, 3, 1, 1, True, 1, 0),       # multi-tile M/N, ragged
+    (2, 128, 0, 32, 32, 128, 3, 1, 1, False, 1, 0),    # big enough for the 128x128 tile
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d(hip, case):
+    N, C1, C2, H, W, Cout, KS, stride, pad, reflect, ups, act = case
+    x1, w = det((N, C1, H, W), 11), det((Cout, C1 + C2, KS, KS), 12, 0.2)
+    x2 = det((N, C2, H, W), 13) if C2 else None
+    b = det((Cout,), 14, 0.2)
+    r1, rw, rb = [t.clone().requires_grad_() for t in (x1, w, b)]
+    r2 = x2.clone().requires_grad_() if C2 else None
+    xin = torch.cat([r1, r2], 1) if C2 else r1
+    if ups == 2:
+        xin = F.interpolate(xin, scale_factor=2, mode='nearest')
+    if reflect:
+        yr = F.conv2d(F.pad(xin, (pad,) * 4, mode='reflect'), rw, rb, stride=stride)
+    else:
+        yr = F.conv2d(xin, rw, rb, stride=stride, padding=pad)
+    yr = {0: lambda t: t, 1: F.relu, 2: lambda t: F.leaky_relu(t, 0.2), 3: torch.tanh}[act](yr)
+    gy = det(tuple(yr.shape), 15)
+    yr.backward(gy)
+    g1, gw, gb = [t.to(DEV).requires_grad_() for t in (x1, w, b)]
+    g2 = x2.to(DEV).requires_grad_() if C2 else None
+    yg = hip.conv2d(g1, gw, gb, stride=stride, pad=pad, reflect=reflect, upsample=ups, act=act, slope=0.2, x2=g2)
+    yg.backward(gy.to(DEV))
+    close(yg, yr, 3e-5, 'y')
+    close(g1.grad, r1.grad, 5e-5, 'gx1')
+    if C2:
+        close(g2.grad, r2.grad, 5e-5, 'gx2')
+    close(gw.grad, rw.grad, 5e-5, 'gw')
+    close(gb.grad, rb.grad, 5e-5, 'gb')
+
+
+def test_conv2d_broadcast_second_source(hip):
+    """mask-D: one-hot class map broadcast over the grid == expand()+cat() of discriminators.py:107-110."""
+    N, C1, C2, H = 6, 16, 12, 8
+    x, cond, w, b = det((N, C1, H, H), 21), torch.zeros(N, C2), det((8, C1 + C2, 3, 3), 22, 0.2), det((8,), 23)
+    cond[torch.arange(N), torch.tensor([0, 3, 11, 5, 5, 1])] = 1
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    yr = F.conv2d(torch.cat([xr, cond.view(N, C2, 1, 1).expand(-1, -1, H, H)], 1), wr, b, padding=1)
+    gy = det(tuple(yr.shape), 24)
+    yr.backward(gy)
+    xg, wg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    yg = hip.conv2d(xg, wg, b.to(DEV), pad=1, x2=cond.to(DEV))
+    yg.backward(gy.to(DEV))
+    close(yg, yr, 3e-5)
+    close(xg.grad, xr.grad, 5e-5)
+    close(wg.grad, wr.grad, 5e-5)
+
+
+@pytest.mark.parametrize('N,Cin,Cout,H', [(2, 16, 8, 8), (3, 32, 16, 5), (2, 128, 64, 16)])
+def test_conv_transpose2d(hip, N, Cin, Cout, H):
+    x, w, b = det((N, Cin, H, H), 31), det((Cin, Cout, 3, 3), 32, 0.2), det((Cout,), 33, 0.2)
+    xr, wr, br = [t.clone().requires_grad_() for t in (x, w, b)]
+    yr = F.conv_transpose2d(xr, wr, br, stride=2, padding=1, output_padding=1)
+    gy = det(tuple(yr.shape), 34)
+    yr.backward(gy)
+    xg, wg, bg = [t.to(DEV).requires_grad_() for t in (x, w, b)]
+    yg = hip.conv_transpose2d(xg, wg, bg, stride=2, pad=1, out_pad=1)
+    yg.backward(gy.to(DEV))
+    close(yg, yr, 3e-5, 'y')
+    close(xg.grad, xr.grad, 5e-5, 'gx')
+    close(wg.grad, wr.grad, 5e-5, 'gw')
+    close(bg.grad, br.grad, 5e-5, 'gb')
+
+
+# ------------------------------------------------------------------------------------------
+# normalisation / pooling
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('shape,act,skip', [((3, 5, 8, 8), 1, False), ((2, 4, 40, 40), 0, True), ((2, 3, 7, 9), 2, False)])
+def test_instance_norm(hip, shape, act, skip):
+    x, gy = det(shape, 41, 2.0, 0.3), det(shape, 42)
+    sk = det(shape, 43) if skip else None
+    xr = x.clone().requires_grad_()
+    sr = sk.clone().requires_grad_() if skip else None
+    yr = F.instance_norm(xr, eps=1e-5)
+    yr = F.relu(yr) if act == 1 else (F.leaky_relu(yr, 0.2) if act == 2 else yr)
+    yr = yr + sr if skip else yr
+    yr.backward(gy)
+    xg = x.to(DEV).requires_grad_()
+    sg = sk.to(DEV).requires_grad_() if skip else None
+    yg = hip.instance_norm(xg, skip=sg, act=act, slope=0.2)
+    yg.backward(gy.to(DEV))
+    close(yg, yr, 2e-5, 'y')
+    close(xg.grad, xr.grad, 1e-4, 'gx')
+    if skip:
+        close(sg.grad, sr.grad, 1e-6, 'gskip')
+
+
+@pytest.mark.parametrize('shape,act,training', [((6, 5, 4, 4), 1, True), ((37, 8, 1, 1), 2, True), ((4, 3, 9, 9), 0, False)])
+def test_batch_norm(hip, shape, act, training):
+    C = shape[1]
+    x, gy = det(shape, 51, 2.0, 0.3), det(shape, 52)
+    ref = nn.BatchNorm2d(C)
+    fill_deterministic(ref)
+    ref.train(training)
+    xr = x.clone().requires_grad_()
+    yr = ref(xr)
+    yr = F.relu(yr) if act == 1 else (F.leaky_relu(yr, 0.2) if act == 2 else yr)
+    yr.backward(gy)
+    from scene_generation_amd.layers import BatchNorm2d
+    m = BatchNorm2d(C)
+    fill_deterministic(m)
+    m = m.to(DEV).train(training)
+    xg = x.to(DEV).requires_grad_()
+    yg = m(xg, act=act, slope=0.2)
+    yg.backward(gy.to(DEV))
+    close(yg, yr, 2e-5, 'y')
+    close(xg.grad, xr.grad, 1e-4, 'gx')
+    close(m.weight.grad, ref.weight.grad, 1e-4, 'ggamma')
+    close(m.bias.grad, ref.bias.grad, 1e-4, 'gbeta')
+    close(m.running_mean, ref.running_mean, 1e-5, 'running_mean')
+    close(m.running_var, ref.running_var, 1e-5, 'running_var')
+    assert int(m.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+def test_pooling_and_pads(hip):
+    x, = det((2, 3, 9, 12), 61),
+    for name, fr, fg in [
+        ('avgpool', lambda t: F.avg_pool2d(t, 3, 2, 1, count_include_pad=False), hip.avgpool3s2),
+        ('gap', lambda t: t.flatten(2).mean(2), hip.global_avg_pool),
+        ('up2', lambda t: F.interpolate(t, scale_factor=2, mode='nearest'), hip.upsample2),
+        ('rpad', lambda t: F.pad(t, (3,) * 4, mode='reflect'), lambda t: hip.reflect_pad(t, 3)),
+        ('sigmoid', torch.sigmoid, lambda t: hip.activation(t, hip.ACT_SIGMOID)),
+        ('tanh', torch.tanh, lambda t: hip.activation(t, hip.ACT_TANH)),
+    ]:
+        xr = x.clone().requires_grad_()
+        yr = fr(xr)
+        gy = det(tuple(yr.shape), 62)
+        yr.backward(gy)
+        xg = x.to(DEV).requires_grad_()
+        yg = fg(xg)
+        yg.backward(gy.to(DEV))
+        close(yg, yr, 1e-6, name)
+        close(xg.grad, xr.grad, 1e-5, name + ' grad')
+
+
+# ------------------------------------------------------------------------------------------
+# graph convolution: bit-exact pool, float parity of the layer
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('O_,T_,H_', [(9, 16, 16), (33, 96, 64), (288, 512, 512), (1056, 3072, 512)])
+def test_triple_pool_bit_exact(hip, O_, T_, H_):
+    g = torch.Generator().manual_seed(O_)
+    Dout = 8
+    edges = torch.randint(0, O_ - 1, (T_, 2), generator=g)        # last node isolated
+    edges[1] = edges[0]
+    edges[2, 1] = edges[2, 0]
+    new_t = torch.randn(T_, 2 * H_ + Dout, generator=g)
+    for avg in (True, False):
+        want = O.pool_triples(new_t[:, :H_], new_t[:, H_ + Dout:], edges[:, 0].contiguous(), edges[:, 1].contiguous(),
+                              O_, 'avg' if avg else 'sum')
+        e = edges.to(DEV)
+        off, ent = hip.build_csr(e, O_)
+        pooled, new_p = hip.TriplePoolFn.apply(new_t.to(DEV), e, off, ent, O_, H_, Dout, avg)
+        assert torch.equal(pooled.cpu(), want), 'pool must be BIT-exact (graph.py:94-116)'
+        assert torch.equal(new_p.cpu(), new_t[:, H_:H_ + Dout])
+    # CSR structure itself (integer-exact)
+    off_c = off.cpu().long()
+    deg = torch.bincount(edges.reshape(-1), minlength=O_)
+    assert torch.equal(off_c[1:] - off_c[:-1], deg)
+
+
+@pytest.mark.parametrize('case', ['small', 'small_sum', 'full', 'dense', 'one'])
+def test_gconv_layer(hip, golden, case):
+    from scene_generation_amd.graph import GraphTripleConv
+    g = golden('gconv_' + case)
+    Din, A, H, Dout, On, Tn, avg = [int(v) for v in g['cfg']]
+    m = GraphTripleConv(Din, attributes_dim=A, output_dim=Dout, hidden_dim=H, pooling='avg' if avg else 'sum')
+    fill_deterministic(m)
+    m = m.to(DEV)
+    obj = torch.from_numpy(g['obj']).to(DEV).requires_grad_()
+    pred = torch.from_numpy(g['pred']).to(DEV).requires_grad_()
+    edges = torch.from_numpy(g['edges']).to(DEV)
+    new_obj, new_pred = m(obj, pred, edges)
+    close(new_obj, g['new_obj'], 2e-5, 'new_obj')
+    close(new_pred, g['new_pred'], 2e-5, 'new_pred')
+    loss = (new_obj * torch.from_numpy(g['wo']).to(DEV)).sum() + (new_pred * torch.from_numpy(g['wp']).to(DEV)).sum()
+    loss.backward()
+    close(obj.grad, g['g_obj'], 1e-4, 'g_obj')
+    close(pred.grad, g['g_pred'], 1e-4, 'g_pred')
+    for n, p in m.named_parameters():
+        if 'gp_' + n in g.files:
+            close(p.grad, g['gp_' + n], 1e-4, n)
+
+
+def test_embedding_onehot_concat(hip):
+    table, idx = det((12, 16), 71), torch.tensor([3, 0, 11, 3, 3, 7])
+    tr = table.clone().requires_grad_()
+    yr = F.embedding(idx, tr)
+    gy = det(tuple(yr.shape), 72)
+    yr.backward(gy)
+    tg = table.to(DEV).requires_grad_()
+    yg = hip.embedding(tg, idx.to(DEV))
+    yg.backward(gy.to(DEV))
+    assert torch.equal(yg.cpu(), yr.detach())
+    close(tg.grad, tr.grad, 1e-6)
+    oh = hip.one_hot(idx.to(DEV), 12).cpu()
+    assert torch.equal(oh, F.one_hot(idx, 12).float())
+    a, b = det((6, 5), 73), det((6, 3), 74)
+    ag, bg = a.to(DEV).requires_grad_(), b.to(DEV).requires_grad_()
+    c = hip.concat_cols(ag, bg)
+    assert torch.equal(c.cpu(), torch.cat([a, b], 1))
+    gc = det((6, 8), 75)
+    c.backward(gc.to(DEV))
+    assert torch.equal(ag.grad.cpu(), gc[:, :5]) and torch.equal(bg.grad.cpu(), gc[:, 5:])
+
+
+# ------------------------------------------------------------------------------------------
+# layout + crops (oracle and reference goldens)
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('case', ['demo_16', 'demo_64', 'i64_m32', 'f32_m16', 'f32_m5_avg', 'edge'])
+def test_masks_to_layout_golden(hip, golden, case):
+    from scene_generation_amd.layout import masks_to_layout
+    g = golden('layout_' + case)
+    vecs = torch.from_numpy(g['vecs']).to(DEV).requires_grad_()
+    H = int(g['H'])
+    W = int(g['W']) if 'W' in g.files else H
+    pooling = 'avg' if ('avg' in g.files and int(g['avg'])) else 'sum'
+    out = masks_to_layout(vecs, torch.from_numpy(g['boxes']).to(DEV), torch.from_numpy(g['masks']).to(DEV),
+                          torch.from_numpy(g['obj_to_img']).to(DEV), H, W, pooling=pooling)
+    close(out, g['out'], 1e-5, 'layout')
+    if 'g_vecs' in g.files:
+        (out * torch.from_numpy(g['w']).to(DEV)).sum().backward()
+        close(vecs.grad, g['g_vecs'], 1e-4, 'g_vecs')
+
+
+def test_masks_to_layout_validation(hip):
+    from scene_generation_amd.layout import masks_to_layout
+    with pytest.raises(ValueError):
+        masks_to_layout(torch.ones(2, 3, device=DEV), torch.tensor([[0., 0, 1, 1]] * 2, device=DEV),
+                        torch.ones(2, 4, 4, device=DEV), torch.tensor([0, 2], device=DEV), 8)
+    with pytest.raises(RuntimeError):        # CPU tensors: no fallback
+        masks_to_layout(torch.ones(2, 3), torch.tensor([[0., 0, 1, 1]] * 2), torch.ones(2, 4, 4), torch.tensor([0, 1]), 8,
+                        num_images=2, validate=False)
+
+
+@pytest.mark.parametrize('cfg', [dict(N=3, min_objs=2, max_objs=5, size=32, mask_size=8, seed=1),
+                                 dict(N=2, min_objs=14, max_objs=20, size=36, mask_size=16, seed=2),     # > LDS hint: chunked
+                                 dict(N=4, min_objs=3, max_objs=8, size=128, mask_size=32, seed=3)])
+def test_masks_to_layout_vs_oracle(hip, cfg):
+    from scene_generation_amd.layout import masks_to_layout
+    b = make_batch(num_objs=20, **cfg)
+    D = 20 + 6
+    vecs = det((b.objs.numel(), D), 81)
+    for masks in (b.masks, torch.rand(b.masks.shape, generator=torch.Generator().manual_seed(5))):
+        vr = vecs.clone().requires_grad_()
+        want = O.masks_to_layout(vr, b.boxes, masks, b.obj_to_img, cfg['size'])
+        w = det(tuple(want.shape), 82)
+        (want * w).sum().backward()
+        vg = vecs.to(DEV).requires_grad_()
+        got = masks_to_layout(vg, b.boxes.to(DEV), masks.to(DEV), b.obj_to_img.to(DEV), cfg['size'],
+                              num_images=cfg['N'], validate=False, grad_from_channel=20, max_per_image=4)
+        close(got, want, 1e-5, 'layout')
+        (got * w.to(DEV)).sum().backward()
+        close(vg.grad[:, 20:], vr.grad[:, 20:], 2e-4, 'g_vecs')
+        assert float(vg.grad[:, :20].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('case', ['sorted_8', 'perm_8', 'perm_32'])
+def test_crop_golden(hip, golden, case):
+    from scene_generation_amd.bilinear import crop_bbox_batch
+    g = golden('crop_' + case)
+    feats = torch.from_numpy(g['feats']).to(DEV).requires_grad_()
+    out = crop_bbox_batch(feats, torch.from_numpy(g['boxes']).to(DEV), torch.from_numpy(g['idx']).to(DEV), int(g['HH']))
+    close(out, g['out'], 1e-5, 'crop')
+    (out * torch.from_numpy(g['w']).to(DEV)).sum().backward()
+    close(feats.grad, g['g_feats'], 1e-4, 'g_feats')
+
+
+def test_vector_pool_matches_reference_semantics(hip):
+    from scene_generation_amd.utils import VectorPool
+    random.seed(7)
+    ref, mine = O.VectorPool(3), VectorPool(3)
+    st = random.getstate()
+    g = torch.Generator().manual_seed(0)
+    outs_ref, batches = [], []
+    for it in range(6):
+        objs = torch.randint(0, 5, (11,), generator=g)
+        vec = torch.randn(11, 4, generator=g)
+        batches.append((objs, vec))
+        outs_ref.append(ref.query(objs, vec))
+    random.setstate(st)
+    for (objs, vec), want in zip(batches, outs_ref):
+        got = mine.query(objs.to(DEV), vec.to(DEV))
+        assert torch.equal(got.cpu(), want), 'VectorPool must replay utils.py:67-90 exactly'
+    for c in range(5):
+        a, b = ref.vectors.get(c, []), mine.vectors_of(c)
+        assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+# ------------------------------------------------------------------------------------------
+# losses / optimiser
+# ------------------------------------------------------------------------------------------
+def test_losses(hip, golden):
+    from scene_generation_amd.losses import GANLoss, gan_g_loss, gan_d_loss
+    g = golden('losses')
+    T = lambda k: torch.from_numpy(g[k]).to(DEV)
+    preds = [[T('p00'), T('p01')], [T('p10'), T('p11')]]
+    crit = GANLoss()
+    close(crit(preds, True), g['gan_true'], 1e-6)
+    close(crit(preds, False), g['gan_false'], 1e-6)
+    close(crit(preds[0], True), g['gan_single'], 1e-6)
+    close(gan_g_loss(T('sf')), g['g_loss'], 1e-6)
+    close(gan_d_loss(T('sr'), T('sf')), g['d_loss'], 1e-6)
+    close(hip.cross_entropy(T('logits'), T('tgt')), g['ce'], 1e-6)
+    close(hip.mse(T('p00'), T('r00')), g['mse'], 1e-6)
+    close(hip.l1(T('p00'), T('r00')), g['l1'], 1e-6)
+    # gradients vs torch
+    for name, fr, fg in [
+        ('mse_const', lambda a: F.mse_loss(a, torch.full_like(a, 1.0)), lambda a: hip.mse_const(a, 1.0)),
+        ('bce', lambda a: O.bce_loss(a.reshape(-1), torch.zeros(a.numel())), lambda a: hip.bce_logits_const(a.reshape(-1), 0.0)),
+        ('l1', lambda a: F.l1_loss(a, det(tuple(a.shape), 92)), lambda a: hip.l1(a, det(tuple(a.shape), 92).to(DEV))),
+        ('ce', lambda a: F.cross_entropy(a.view(10, 24), torch.arange(10) % 7),
+         lambda a: hip.cross_entropy(a.view(10, 24), (torch.arange(10) % 7).to(DEV))),
+    ]:
+        a = det((2, 3, 5, 8), 91, 3.0)
+        ar = a.clone().requires_grad_()
+        lr = fr(ar) * 0.37
+        lr.backward()
+        ag = a.to(DEV).requires_grad_()
+        lg = fg(ag) * 0.37
+        lg.backward()
+        close(lg, lr, 1e-6, name)
+        close(ag.grad, ar.grad, 1e-6, name + ' grad')
+
+
+def test_fused_adam_matches_torch(hip):
+    from scene_generation_amd.optim import FusedAdam
+    ref = nn.Sequential(nn.Linear(7, 5), nn.Linear(5, 3))
+    fill_deterministic(ref)
+    mine = nn.Sequential(nn.Linear(7, 5), nn.Linear(5, 3))
+    fill_deterministic(mine)
+    mine = mine.to(DEV)
+    o_ref = torch.optim.Adam(ref.parameters(), lr=1e-2, betas=(0.5, 0.999))
+    o_mine = FusedAdam(mine.parameters(), lr=1e-2, betas=(0.5, 0.999))
+    for it in range(5):
+        o_ref.zero_grad()
+        o_mine.zero_grad()
+        for (n, p), q in zip(ref.named_parameters(), mine.parameters()):
+            gr = det(tuple(p.shape), 100 + it, 0.5)
+            p.grad = gr.clone()
+            q.grad.add_(gr.to(DEV))
+        o_ref.step()
+        o_mine.step()
+    for p, q in zip(ref.parameters(), mine.parameters()):
+        close(q, p, 1e-6, 'param after adam')
+    sd = o_mine.state_dict()
+    sd_ref = o_ref.state_dict()
+    for i in sd_ref['state']:
+        close(sd['state'][i]['exp_avg'], sd_ref['state'][i]['exp_avg'], 1e-6)
+        close(sd['state'][i]['exp_avg_sq'], sd_ref['state'][i]['exp_avg_sq'], 1e-6)
+        assert float(sd['state'][i]['step']) == float(sd_ref['state'][i]['step'])
+
+
+# ------------------------------------------------------------------------------------------
+# modules vs reference goldens (same fixtures the oracle is pinned with)
+# ------------------------------------------------------------------------------------------
+def _run_module(g, mod, n_in):
+    fill_deterministic(mod)
+    mod = mod.to(DEV)
+    mod.train()
+    ins = []
+    for i in range(n_in):
+        t = torch.from_numpy(g['in%d' % i]).to(DEV)
+        ins.append(t.clone().requires_grad_() if t.is_floating_point() else t)
+    out = mod(*ins)
+    flat = []
+
+    def walk(o):
+        if isinstance(o, torch.Tensor):
+            flat.append(o)
+        elif isinstance(o, (list, tuple)):
+            for x in o:
+                walk(x)
+    walk(out)
+    loss = 0
+    for i, o in enumerate(flat):
+        close(o, g['out%d' % i], 3e-5, 'out%d' % i)
+        loss = loss + (o * torch.from_numpy(g['w%d' % i]).to(DEV)).sum()
+    loss.backward()
+    k = 0
+    for t in ins:
+        if t.is_floating_point():
+            if t.grad is not None:
+                close(t.grad, g['gin%d' % k], 3e-4, 'gin%d' % k)
+            k += 1
+    for n, p in mod.named_parameters():
+        close(p.grad if p.grad is not None else torch.zeros_like(p), g['gp_' + n], 3e-4, n)
+    for n, b in mod.named_buffers():
+        close(b, g['buf_' + n], 1e-5, n)
+
+
+def test_modules_vs_reference(hip, golden):
+    from scene_generation_amd import layers as Lh, generators as Gh, discriminators as Dh
+    vocab = make_vocab(12, 4, 0)
+    IN = Lh.get_norm_layer('instance')
+    _run_module(golden('mod_mlp'), Lh.build_mlp([10, 16, 6]), 1)
+    _run_module(golden('mod_mask_net'), Gh.mask_net(24, 8), 1)
+    _run_module(golden('mod_encoder'), Gh.AppearanceEncoder(vocab, arch='C4-8-2,C4-16-2,C4-32-2', normalization='batch',
+                                                            activation='leakyrelu-0.2', padding='valid', vecs_size=24), 1)
+    _run_module(golden('mod_globalgen'), Gh.GlobalGenerator(12, 3, ngf=8, n_downsampling=2, n_blocks=2, norm_layer=IN), 1)
+    _run_module(golden('mod_imgD'), Dh.MultiscaleDiscriminator(7, ndf=8, n_layers=3, norm_layer=IN, num_D=2), 1)
+    _run_module(golden('mod_maskD'), Dh.MultiscaleMaskDiscriminator(1, ndf=8, n_layers=2, norm_layer=IN, num_D=1,
+                                                                    num_objects=12), 2)
+    _run_module(golden('mod_objD'), Dh.AcCropDiscriminator(vocab, arch='C4-8-2,C4-16-2,C4-32-2', normalization='batch',
+                                                           activation='leakyrelu-0.2', object_size=32, padding='valid'), 4)
+
+
+def test_imgD_folded_concat_equals_materialised(hip):
+    from scene_generation_amd import layers as Lh, discriminators as Dh
+    d = Dh.MultiscaleDiscriminator(7, ndf=8, n_layers=3, norm_layer=Lh.get_norm_layer('instance'), num_D=2)
+    fill_deterministic(d)
+    d = d.to(DEV)
+    a, b = det((2, 4, 32, 32), 111).to(DEV), det((2, 3, 32, 32), 112).to(DEV)
+    r1 = d(torch.cat([a, b], 1))
+    r2 = d(a, b)
+    for s1, s2 in zip(r1, r2):
+        for f1, f2 in zip(s1, s2):
+            close(f2, f1, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------
+# full G+D step vs the reference golden (reduced widths) and vs the oracle (config 1, full widths)
+# ------------------------------------------------------------------------------------------
+def test_full_step_vs_reference_golden(hip, golden):
+    from scene_generation_amd.trainer import Trainer
+    g = golden('step_reduced')
+    args = parser.parse_args(g['argv'].tolist())
+    C, P, A = 12, 4, 35
+    tr = Trainer(args, make_vocab(C, P, A))
+    for m in (tr.model, tr.netD, tr.obj_discriminator, tr.mask_discriminator):
+        fill_deterministic(m)
+    random.seed(1234)
+    for it in range(2):
+        batch = batch_to(make_batch(N=3, min_objs=2, max_objs=4, size=32, mask_size=8, num_objs=C, num_preds=P,
+                                    num_attributes=A, seed=100 + it), DEV)
+        pre = 'it%d_' % it
+        tr.model.noise_override = torch.from_numpy(g[pre + 'noise'])
+        out = tr.step(batch, use_gt=(it == 0))
+        tol = 2e-3 if it else 1e-4
+        for n, t in zip(['imgs_pred', 'boxes_pred', 'masks_pred'], out[:3]):
+            close(t, g[pre + n], tol, n)
+        close(out[5][:, C:], g[pre + 'layout_wrong_rep'], tol, 'wrong layout')
+        for lname, L in [('g', tr.generator_losses), ('dmask', tr.d_mask_losses), ('dobj', tr.d_obj_losses),
+                         ('dimg', tr.d_img_losses)]:
+            for k, v in L.items():
+                ref = float(g[pre + 'loss_' + lname + '_' + k])
+                assert abs(v - ref) <= (5e-3 if it else 2e-4) * max(1.0, abs(ref)), (it, lname, k, v, ref)
+        for mname, m in [('model', tr.model), ('netD', tr.netD), ('objD', tr.obj_discriminator),
+                         ('maskD', tr.mask_discriminator)]:
+            sd = m.state_dict()
+            for k, (s, a) in zip(g[pre + 'keys_' + mname].tolist(), g[pre + 'stats_' + mname]):
+                got = sd[k].double().abs().sum().item()
+                assert abs(got - a) <= 3e-3 * max(1.0, a), (it, mname, k, got, a)
+
+
+def test_full_step_config1_vs_oracle(hip):
+    """BASELINE config 1: synthetic 4-object graphs, 64x64, batch 4, full widths (183 M-param generator)."""
+    from scene_generation_amd.trainer import Trainer
+    argv = ['--image_size', '64,64', '--batch_size', '4', '--vgg_features_weight', '0', '--output_dir', '/tmp/o']
+    args = parser.parse_args(argv)
+    vocab = make_vocab()
+    torch.manual_seed(0)
+    ref = O.Trainer(args, vocab)
+    for m in (ref.model, ref.netD, ref.obj_discriminator, ref.mask_discriminator):
+        fill_deterministic(m)
+    tr = Trainer(args, vocab)
+    tr.model.load_state_dict(ref.model.state_dict())
+    tr.netD.load_state_dict(ref.netD.state_dict())
+    tr.obj_discriminator.load_state_dict(ref.obj_discriminator.state_dict())
+    tr.mask_discriminator.load_state_dict(ref.mask_discriminator.state_dict())
+    batch = make_batch(N=4, min_objs=4, max_objs=4, size=64, seed=0)
+    noise = det((1, 64), 121)
+    ref.model.noise_override = noise
+    tr.model.noise_override = noise
+    random.seed(5)
+    out_ref = ref.step(batch, use_gt=True)
+    random.seed(5)
+    out = tr.step(batch_to(batch, DEV), use_gt=True)
+    for n, a, b in zip(['imgs_pred', 'boxes_pred', 'masks_pred', 'layout', 'layout_pred', 'layout_wrong'], out, out_ref):
+        close(a, b, 2e-4, n)
+    for La, Lb in [(tr.generator_losses, ref.generator_losses), (tr.d_mask_losses, ref.d_mask_losses),
+                   (tr.d_obj_losses, ref.d_obj_losses), (tr.d_img_losses, ref.d_img_losses)]:
+        a, b = dict(La.items()), dict(Lb.items())
+        assert set(a) == set(b)
+        for k in b:
+            assert abs(a[k] - b[k]) <= 5e-4 * max(1.0, abs(b[k])), (k, a[k], b[k])
+
+
+# ------------------------------------------------------------------------------------------
+# full-size (BASELINE config 2) size-independent properties
+# ------------------------------------------------------------------------------------------
+def test_layout_full_size_properties(hip):
+    from scene_generation_amd.layout import masks_to_layout
+    b = batch_to(make_batch(N=32, min_objs=3, max_objs=8, size=128, seed=0), DEV)
+    Oc = b.objs.numel()
+    g = torch.Generator().manual_seed(0)
+    v1, v2 = torch.randn(Oc, 204, generator=g).to(DEV), torch.randn(Oc, 204, generator=g).to(DEV)
+    kw = dict(num_images=32, validate=False)
+    l1 = masks_to_layout(v1, b.boxes, b.masks, b.obj_to_img, 128, **kw)
+    l2 = masks_to_layout(v2, b.boxes, b.masks, b.obj_to_img, 128, **kw)
+    l12 = masks_to_layout(v1 + 2 * v2, b.boxes, b.masks, b.obj_to_img, 128, **kw)
+    close(l12, l1 + 2 * l2, 1e-5, 'linearity in vecs')
+    # per-image independence: image 7 computed alone equals its slice of the batch
+    sel = b.obj_to_img == 7
+    alone = masks_to_layout(v1[sel], b.boxes[sel], b.masks[sel], torch.zeros(int(sel.sum()), dtype=torch.long, device=DEV),
+                            128, num_images=1, validate=False)
+    assert torch.equal(alone[0], l1[7])
+    # the __image__ node (box [0,0,1,1], all-ones mask) contributes its vector everywhere inside the image
+    ones = torch.zeros(Oc, 204, device=DEV)
+    last = torch.cat([b.obj_to_img[1:] != b.obj_to_img[:-1], torch.tensor([True], device=DEV)])
+    ones[last] = 1.0
+    lim = masks_to_layout(ones, b.boxes, b.masks, b.obj_to_img, 128, **kw)
+    close(lim[:, :, 4:-4, 4:-4], torch.ones_like(lim[:, :, 4:-4, 4:-4]), 1e-6, 'image node')

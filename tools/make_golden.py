@@ -361,9 +361,17 @@ def golden_step():
     npz('state_dict_keys_full', **inv)
 
 
+def golden_args():
+    """flag names + defaults of the reference parser (args.py:10-109)"""
+    import json
+    from scene_generation.args import parser
+    d = vars(parser.parse_args([]))
+    npz('args_defaults', json=np.array(json.dumps({k: (list(v) if isinstance(v, tuple) else v) for k, v in d.items()})))
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     install_shims()
-    which = sys.argv[1:] or ['gconv', 'layout', 'crop', 'modules', 'losses', 'step']
+    which = sys.argv[1:] or ['gconv', 'layout', 'crop', 'modules', 'losses', 'step', 'args']
     for w in which:
         globals()['golden_' + w]()
