@@ -132,8 +132,8 @@ int sg_batchnorm_fwd(const float* x, const float* gamma, const float* beta, floa
                      int HW, float eps, float momentum, int training, int act, float slope, sgStream stream);
 /* beta is needed to rebuild the pre-activation gamma*z+beta for the fused activation mask */
 int sg_batchnorm_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
-                     const float* save_rstd, float* gx, float* ggamma, float* gbeta, int N, int C, int HW, int act,
-                     float slope, sgStream stream);
+                     const float* save_rstd, float* gx, float* ggamma, float* gbeta, int N, int C, int HW, int training,
+                     int act, float slope, sgStream stream);
 int sg_avgpool3s2_fwd(const float* x, float* y, int NC, int H, int W, int OH, int OW, sgStream stream);
 int sg_avgpool3s2_bwd(const float* gy, float* gx, int NC, int H, int W, int OH, int OW, sgStream stream);
 int sg_gap_fwd(const float* x, float* y, int NC, int HW, sgStream stream);

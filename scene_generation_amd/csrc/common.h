@@ -27,10 +27,20 @@ void sg_set_error(const char* fmt, ...);
   } while (0)
 
 // ---- profiler kinds (bench.py roofline leg) -------------------------------------------------
+// ids 0..35: one per igemm instantiation family: (gather family f, kernel size index k, tile t) -> f*12 + k*3 + t
+//   f: 0 = K=(c,taps) conv-style gather   (conv fwd, convT dgrad)      -> "igemm_kn0_*"
+//      1 = K=(c,taps) transposed gather   (conv dgrad, convT fwd)      -> "igemm_kn1_*"
+//      2 = K=(img,pix) weight-gradient    (conv / convT wgrad)         -> "igemm_nk_*"
+//   k: KS in {1,3,4,7};  t: tile {128x128, 64x64, 32x128}
 enum {
-  SG_K_CONV_FWD = 0, SG_K_CONV_DGRAD, SG_K_CONV_WGRAD, SG_K_LINEAR, SG_K_LAYOUT_FWD, SG_K_LAYOUT_BWD,
-  SG_K_INSTNORM, SG_K_BATCHNORM, SG_K_ADAM, SG_K_SEGSUM, SG_K_CROP, SG_K_OTHER, SG_K_COUNT
+  SG_K_IGEMM_BASE = 0, SG_K_IGEMM_COUNT = 36,
+  SG_K_LINEAR = 36, SG_K_LAYOUT_FWD, SG_K_LAYOUT_BWD, SG_K_INSTNORM, SG_K_BATCHNORM, SG_K_ADAM, SG_K_SEGSUM,
+  SG_K_CROP, SG_K_OTHER, SG_K_COUNT
 };
+static inline int sg_igemm_kind(int family, int KS, int tile) {
+  const int k = KS == 1 ? 0 : (KS == 3 ? 1 : (KS == 4 ? 2 : 3));
+  return SG_K_IGEMM_BASE + family * 12 + k * 3 + tile;
+}
 extern int g_sg_prof_on;
 void sg_prof_begin(int kind, hipStream_t s);
 void sg_prof_end(int kind, hipStream_t s, double flops, double bytes);

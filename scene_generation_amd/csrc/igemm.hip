@@ -416,11 +416,13 @@ Gather make_gather(const float* s1, const float* s2, int C1, int C2, int SH, int
 // ---- conv-shaped GEMM: K = (c, taps), N = pixels -------------------------------------------------
 template <int KS, int MODE>
 int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* bias, float* out, int Mtot, int act,
-           float slope, hipStream_t s) {
+           float slope, double flops, hipStream_t s) {
   const int Npix = NB * g.PH * g.PW;
   EpNCHW ep{out, bias, g.PH * g.PW, Mtot, M, Npix, act, slope};
   const int vec = (K % 4 == 0) && aligned16(A);
-  switch (pick_tile(M, Npix)) {
+  const int tile = pick_tile(M, Npix);
+  SgProfScope prof(sg_igemm_kind(MODE, KS, tile), s, flops, 0);
+  switch (tile) {
     case 0: {
       LoadKContig<128> al{A, K, M, vec};
       LoadGatherKN<128, KS, MODE> bl{g, Npix};
@@ -441,12 +443,12 @@ int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* b
 
 template <int MODE>
 int run_kn_ks(int KS, const float* A, int M, int K, const Gather& g, int NB, const float* bias, float* out, int Mtot,
-              int act, float slope, hipStream_t s) {
+              int act, float slope, double flops, hipStream_t s) {
   switch (KS) {
-    case 1: return run_kn<1, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, s);
-    case 3: return run_kn<3, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, s);
-    case 4: return run_kn<4, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, s);
-    case 7: return run_kn<7, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, s);
+    case 1: return run_kn<1, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, s);
+    case 3: return run_kn<3, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, s);
+    case 4: return run_kn<4, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, s);
+    case 7: return run_kn<7, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, s);
   }
   return -1;
 }
@@ -463,7 +465,7 @@ inline int wgrad_splits(int M, int Ncols, int Kpix) {
 
 template <int KS>
 int run_nk(const float* A, int M, int Mtot, const Gather& g, int NB, float* out, void* ws, size_t ws_bytes,
-           hipStream_t s) {
+           double flops, hipStream_t s) {
   const int PQ = g.PH * g.PW;
   const int Kpix = NB * PQ;
   const int Ncols = (g.C1 + g.C2) * KS * KS;
@@ -475,18 +477,22 @@ int run_nk(const float* A, int M, int Mtot, const Gather& g, int NB, float* out,
   splits = sg_cdiv(Kpix, kchunk);
   float* dst = splits > 1 ? reinterpret_cast<float*>(ws) : out;
   EpRowMajor ep{dst, nullptr, M, Ncols, Ncols, SG_ACT_NONE, 0.f, mn};
-  if (M <= 32) {
-    LoadPixK<32> al{A, M, Mtot, PQ};
-    LoadGatherNK<128, KS> bl{g, Ncols};
-    launch_cfg<Cfg32>(al, bl, ep, M, Ncols, Kpix, splits, s);
-  } else if ((long)sg_cdiv(M, 128) * sg_cdiv(Ncols, 128) >= 384) {
-    LoadPixK<128> al{A, M, Mtot, PQ};
-    LoadGatherNK<128, KS> bl{g, Ncols};
-    launch_cfg<Cfg128>(al, bl, ep, M, Ncols, Kpix, splits, s);
-  } else {
-    LoadPixK<64> al{A, M, Mtot, PQ};
-    LoadGatherNK<64, KS> bl{g, Ncols};
-    launch_cfg<Cfg64>(al, bl, ep, M, Ncols, Kpix, splits, s);
+  const int tile = M <= 32 ? 2 : ((long)sg_cdiv(M, 128) * sg_cdiv(Ncols, 128) >= 384 ? 0 : 1);
+  {
+    SgProfScope prof(sg_igemm_kind(2, KS, tile), s, flops, 0);
+    if (tile == 2) {
+      LoadPixK<32> al{A, M, Mtot, PQ};
+      LoadGatherNK<128, KS> bl{g, Ncols};
+      launch_cfg<Cfg32>(al, bl, ep, M, Ncols, Kpix, splits, s);
+    } else if (tile == 0) {
+      LoadPixK<128> al{A, M, Mtot, PQ};
+      LoadGatherNK<128, KS> bl{g, Ncols};
+      launch_cfg<Cfg128>(al, bl, ep, M, Ncols, Kpix, splits, s);
+    } else {
+      LoadPixK<64> al{A, M, Mtot, PQ};
+      LoadGatherNK<64, KS> bl{g, Ncols};
+      launch_cfg<Cfg64>(al, bl, ep, M, Ncols, Kpix, splits, s);
+    }
   }
   if (splits > 1) {
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(sg_cdiv(mn, 256)), dim3(256), 0, s, (const float*)ws, out, mn,
@@ -496,12 +502,12 @@ int run_nk(const float* A, int M, int Mtot, const Gather& g, int NB, float* out,
 }
 
 int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, float* out, void* ws, size_t ws_bytes,
-              hipStream_t s) {
+              double flops, hipStream_t s) {
   switch (KS) {
-    case 1: return run_nk<1>(A, M, Mtot, g, NB, out, ws, ws_bytes, s);
-    case 3: return run_nk<3>(A, M, Mtot, g, NB, out, ws, ws_bytes, s);
-    case 4: return run_nk<4>(A, M, Mtot, g, NB, out, ws, ws_bytes, s);
-    case 7: return run_nk<7>(A, M, Mtot, g, NB, out, ws, ws_bytes, s);
+    case 1: return run_nk<1>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s);
+    case 3: return run_nk<3>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s);
+    case 4: return run_nk<4>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s);
+    case 7: return run_nk<7>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s);
   }
   return -1;
 }
@@ -548,8 +554,8 @@ extern "C" int sg_conv2d_fwd(const sgConvDesc* d, const float* x1, const float* 
   const int Cin = d->C1 + d->C2, K = Cin * d->KS * d->KS;
   Gather g = make_gather(x1, x2, d->C1, d->C2, d->H, d->W, d->upsample, d->OH, d->OW, d->stride, d->pad, d->pad_reflect);
   g.bcast2 = d->x2_broadcast;
-  SgProfScope prof(SG_K_CONV_FWD, s, 2.0 * d->Cout * K * (double)d->N * d->OH * d->OW, 0);
-  int rc = run_kn_ks<0>(d->KS, w, d->Cout, K, g, d->N, bias, y, d->Cout, act, slope, s);
+  const double flops = 2.0 * d->Cout * K * (double)d->N * d->OH * d->OW;
+  int rc = run_kn_ks<0>(d->KS, w, d->Cout, K, g, d->N, bias, y, d->Cout, act, slope, flops, s);
   SG_LAUNCH_CHECK("sg_conv2d_fwd");
   return rc;
 }
@@ -571,8 +577,9 @@ extern "C" int sg_conv2d_dgrad(const sgConvDesc* d, const float* gy, const float
   const int pad = d->pad_reflect ? 0 : d->pad;
   Gather g = make_gather(gy, nullptr, d->Cout, 0, d->OH, d->OW, 1, GH, GW, d->stride, pad, 0);
   const int M = c_end - c_begin, K = d->Cout * R;
-  SgProfScope prof(SG_K_CONV_DGRAD, s, 2.0 * M * K * (double)d->N * GH * GW / (d->stride * d->stride), 0);
-  int rc = run_kn_ks<1>(d->KS, wt + (size_t)c_begin * K, M, K, g, d->N, nullptr, gx, M, SG_ACT_NONE, 0.f, s);
+  // algorithmic flops of a dgrad = those of the forward conv restricted to the requested input channels
+  const double flops = 2.0 * M * (double)d->Cout * R * d->N * d->OH * d->OW;
+  int rc = run_kn_ks<1>(d->KS, wt + (size_t)c_begin * K, M, K, g, d->N, nullptr, gx, M, SG_ACT_NONE, 0.f, flops, s);
   SG_LAUNCH_CHECK("sg_conv2d_dgrad");
   return rc;
 }
@@ -586,10 +593,7 @@ extern "C" int sg_conv2d_wgrad(const sgConvDesc* d, const float* gy, const float
   Gather g = make_gather(x1, x2, d->C1, d->C2, d->H, d->W, d->upsample, d->OH, d->OW, d->stride, d->pad, d->pad_reflect);
   g.bcast2 = d->x2_broadcast;
   const double flops = 2.0 * d->Cout * (double)(d->C1 + d->C2) * d->KS * d->KS * d->N * d->OH * d->OW;
-  {
-    SgProfScope prof(SG_K_CONV_WGRAD, s, flops, 0);
-    run_nk_ks(d->KS, gy, d->Cout, d->Cout, g, d->N, gw, ws, ws ? ws_bytes : 0, s);
-  }
+  run_nk_ks(d->KS, gy, d->Cout, d->Cout, g, d->N, gw, ws, ws ? ws_bytes : 0, flops, s);
   SG_LAUNCH_CHECK("sg_conv2d_wgrad");
   if (gb) return sg_channel_sum(gy, gb, d->N, d->Cout, d->OH * d->OW, stream);
   return 0;
@@ -608,8 +612,8 @@ extern "C" int sg_convT2d_fwd(const sgConvDesc* d, const float* x, const float* 
   const size_t nw = (size_t)d->Cout * Cin * R;
   hipLaunchKernelGGL(permute_w_kernel, dim3(sg_cdiv(nw, 256)), dim3(256), 0, s, w, wt, Cin, d->Cout, R);
   Gather g = make_gather(x, nullptr, Cin, 0, d->H, d->W, 1, d->OH, d->OW, d->stride, d->pad, 0);
-  SgProfScope prof(SG_K_CONV_FWD, s, 2.0 * d->Cout * Cin * R * (double)d->N * d->H * d->W, 0);
-  int rc = run_kn_ks<1>(d->KS, wt, d->Cout, Cin * R, g, d->N, bias, y, d->Cout, SG_ACT_NONE, 0.f, s);
+  const double flops = 2.0 * d->Cout * Cin * R * (double)d->N * d->H * d->W;
+  int rc = run_kn_ks<1>(d->KS, wt, d->Cout, Cin * R, g, d->N, bias, y, d->Cout, SG_ACT_NONE, 0.f, flops, s);
   SG_LAUNCH_CHECK("sg_convT2d_fwd");
   return rc;
 }
@@ -621,8 +625,8 @@ extern "C" int sg_convT2d_dgrad(const sgConvDesc* d, const float* gy, const floa
   hipStream_t s = (hipStream_t)stream;
   const int R = d->KS * d->KS;
   Gather g = make_gather(gy, nullptr, d->Cout, 0, d->OH, d->OW, 1, d->H, d->W, d->stride, d->pad, 0);
-  SgProfScope prof(SG_K_CONV_DGRAD, s, 2.0 * d->Cout * d->C1 * R * (double)d->N * d->H * d->W, 0);
-  int rc = run_kn_ks<0>(d->KS, w, d->C1, d->Cout * R, g, d->N, nullptr, gx, d->C1, SG_ACT_NONE, 0.f, s);
+  const double flops = 2.0 * d->Cout * d->C1 * R * (double)d->N * d->H * d->W;
+  int rc = run_kn_ks<0>(d->KS, w, d->C1, d->Cout * R, g, d->N, nullptr, gx, d->C1, SG_ACT_NONE, 0.f, flops, s);
   SG_LAUNCH_CHECK("sg_convT2d_dgrad");
   return rc;
 }
@@ -634,10 +638,8 @@ extern "C" int sg_convT2d_wgrad(const sgConvDesc* d, const float* gy, const floa
   SG_ARG_CHECK(gy && x && gw, "sg_convT2d_wgrad: null pointer");
   hipStream_t s = (hipStream_t)stream;
   Gather g = make_gather(gy, nullptr, d->Cout, 0, d->OH, d->OW, 1, d->H, d->W, d->stride, d->pad, 0);
-  {
-    SgProfScope prof(SG_K_CONV_WGRAD, s, 2.0 * d->Cout * (double)d->C1 * d->KS * d->KS * d->N * d->H * d->W, 0);
-    run_nk_ks(d->KS, x, d->C1, d->C1, g, d->N, gw, ws, ws ? ws_bytes : 0, s);
-  }
+  run_nk_ks(d->KS, x, d->C1, d->C1, g, d->N, gw, ws, ws ? ws_bytes : 0,
+            2.0 * d->Cout * (double)d->C1 * d->KS * d->KS * d->N * d->H * d->W, s);
   SG_LAUNCH_CHECK("sg_convT2d_wgrad");
   if (gb) return sg_channel_sum(gy, gb, d->N, d->Cout, d->OH * d->OW, stream);
   return 0;

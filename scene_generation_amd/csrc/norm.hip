@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(512) batchnorm_bwd_kernel(const float* __restr
                                                            const float* __restrict__ save_mean,
                                                            const float* __restrict__ save_rstd, float* __restrict__ gx,
                                                            float* __restrict__ ggamma, float* __restrict__ gbeta, int N,
-                                                           int C, int HW, int act, float slope) {
+                                                           int C, int HW, int training, int act, float slope) {
   __shared__ float red[16];
   const int c = blockIdx.x;
   const int cnt = N * HW;
@@ -147,7 +147,8 @@ __global__ void __launch_bounds__(512) batchnorm_bwd_kernel(const float* __restr
   s2 = sg_block_sum(s2, red);
   if (threadIdx.x == 0) { if (gbeta) gbeta[c] = s1; if (ggamma) ggamma[c] = s2; }
   const float inv = 1.f / (float)cnt;
-  const float m1 = s1 * inv, m2 = s2 * inv;
+  // eval mode: the statistics are constants, so only the affine map is differentiated
+  const float m1 = training ? s1 * inv : 0.f, m2 = training ? s2 * inv : 0.f;
   for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
     const int n = i / HW, p = i - n * HW;
     const size_t off = ((size_t)n * C + c) * HW + p;
@@ -364,12 +365,12 @@ extern "C" int sg_batchnorm_fwd(const float* x, const float* gamma, const float*
 
 extern "C" int sg_batchnorm_bwd(const float* x, const float* gy, const float* gamma, const float* beta,
                                 const float* save_mean, const float* save_rstd, float* gx, float* ggamma, float* gbeta,
-                                int N, int C, int HW, int act, float slope, sgStream stream) {
+                                int N, int C, int HW, int training, int act, float slope, sgStream stream) {
   SG_ARG_CHECK(x && gy && save_mean && save_rstd && gx && N > 0 && C > 0 && HW > 0, "sg_batchnorm_bwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   SgProfScope prof(SG_K_BATCHNORM, s, 0, (double)N * C * HW * 20.0);
   hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(C), dim3(512), 0, s, x, gy, gamma, beta, save_mean, save_rstd, gx,
-                     ggamma, gbeta, N, C, HW, act, slope);
+                     ggamma, gbeta, N, C, HW, training, act, slope);
   SG_LAUNCH_CHECK("sg_batchnorm_bwd");
   return 0;
 }

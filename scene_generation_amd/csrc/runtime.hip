@@ -26,8 +26,22 @@ std::vector<hipEvent_t> g_free;
 hipEvent_t g_open[SG_K_COUNT];
 double g_ms[SG_K_COUNT], g_flops[SG_K_COUNT], g_bytes[SG_K_COUNT];
 int64_t g_cnt[SG_K_COUNT];
-const char* kNames[SG_K_COUNT] = {"conv_fwd", "conv_dgrad", "conv_wgrad", "linear", "layout_fwd", "layout_bwd",
-                                  "instnorm", "batchnorm", "adam", "segsum", "crop", "other"};
+const char* kTail[SG_K_COUNT - SG_K_IGEMM_COUNT] = {"linear", "layout_fwd", "layout_bwd", "instnorm", "batchnorm", "adam",
+                                                    "segsum", "crop", "other"};
+char g_names[SG_K_COUNT][32];
+bool g_names_init = false;
+void init_names() {
+  if (g_names_init) return;
+  const char* fam[3] = {"kn0", "kn1", "nk"};
+  const int ks[4] = {1, 3, 4, 7};
+  const int tl[3] = {128, 64, 32};
+  for (int f = 0; f < 3; ++f)
+    for (int k = 0; k < 4; ++k)
+      for (int t = 0; t < 3; ++t)
+        snprintf(g_names[f * 12 + k * 3 + t], 32, "igemm_%s_k%d_t%d", fam[f], ks[k], tl[t]);
+  for (int i = SG_K_IGEMM_COUNT; i < SG_K_COUNT; ++i) snprintf(g_names[i], 32, "%s", kTail[i - SG_K_IGEMM_COUNT]);
+  g_names_init = true;
+}
 
 hipEvent_t get_event() {
   if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
@@ -71,7 +85,10 @@ extern "C" int sg_prof_reset(void) {
   return 0;
 }
 extern "C" int sg_prof_num_kinds(void) { return SG_K_COUNT; }
-extern "C" const char* sg_prof_kind_name(int kind) { return (kind >= 0 && kind < SG_K_COUNT) ? kNames[kind] : "?"; }
+extern "C" const char* sg_prof_kind_name(int kind) {
+  init_names();
+  return (kind >= 0 && kind < SG_K_COUNT) ? g_names[kind] : "?";
+}
 extern "C" int sg_prof_read(int kind, double* total_ms, int64_t* launches, double* flops, double* bytes) {
   if (kind < 0 || kind >= SG_K_COUNT) { sg_set_error("sg_prof_read: bad kind %d", kind); return -1; }
   std::lock_guard<std::mutex> lk(g_mu);

@@ -116,8 +116,6 @@ class Conv2dFn(Function):
             _call('sg_act_bwd', _p(y), _p(gy), _p(g2), gy.numel(), act, slope, s)
             gy = g2
         need_x1, need_x2, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and x2 is not None, ctx.needs_input_grad[2]
-        if need_x2 and d.x2_broadcast:
-            raise NotImplementedError('gradient w.r.t. a broadcast second conv source (the constant one-hot map)')
         need_b = has_bias and ctx.needs_input_grad[3]
         gx1 = gx2 = gw = gb = None
         dev = gy.device
@@ -141,6 +139,10 @@ class Conv2dFn(Function):
                 gx1 = dgrad(0, d.C1)
             if need_x2:
                 gx2 = dgrad(d.C1, d.C1 + d.C2)
+                if d.x2_broadcast:          # [N, C2] source broadcast over H x W: reduce the map gradient
+                    red = torch.empty(d.N, d.C2, dtype=torch.float32, device=dev)
+                    _call('sg_gap_fwd', _p(gx2), _p(red), d.N * d.C2, d.H * d.W, s)
+                    gx2 = scale_(red, float(d.H * d.W))
         if need_w or need_b:
             if need_w:
                 wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 2)
@@ -336,20 +338,20 @@ class BatchNormFn(Function):
         rstd = torch.empty_like(mean)
         _call('sg_batchnorm_fwd', _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(rmean), _p(rvar), _p(nbt),
               N, C, HW, eps, momentum, 1 if training else 0, act, slope, _stream())
-        ctx.cfg = (N, C, HW, act, slope)
+        ctx.cfg = (N, C, HW, act, slope, 1 if training else 0)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, gamma, beta, mean, rstd = ctx.saved_tensors
-        N, C, HW, act, slope = ctx.cfg
+        N, C, HW, act, slope, training = ctx.cfg
         gy = _f32(gy)
         gx = torch.empty_like(x)
         gg = torch.empty(C, dtype=torch.float32, device=x.device) if gamma is not None else None
         gb = torch.empty(C, dtype=torch.float32, device=x.device) if beta is not None else None
         _call('sg_batchnorm_bwd', _p(x), _p(gy), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(gx), _p(gg), _p(gb), N, C, HW,
-              act, slope, _stream())
+              training, act, slope, _stream())
         return gx, gg, gb, None, None, None, None, None, None, None, None
 
 
