@@ -33,32 +33,43 @@ struct TileCfg {
 // to the LDS tile laid out [BK][BX+4].
 // ------------------------------------------------------------------------------------------------
 
-// rows of length K contiguous in memory: elem(x, k) = base[x*ld + k]
-template <int BX>
+// All loaders are BRANCH-FREE and DEFERRED: load() issues every global read of the k-tile from a clamped (always
+// valid) address and only records a validity bit; the zero-select happens in store(), i.e. AFTER the MFMAs of
+// the current tile, so the loads stay in flight across the whole compute phase.  (Exec-masked conditional
+// loads, or selects placed right behind the loads, made hipcc wait vmcnt(0) before the MFMAs: 4-5x slower.)
+// Offsets are 32-bit: the host rejects tensors of >= 2^31 elements.
+
+// rows of length K contiguous in memory: elem(x, k) = base[x*ld + k].  VEC: ld%4==0 and 16-B aligned base.
+template <int BX, bool VEC>
 struct LoadKContig {
-  const float* base; int ld; int X; int vec;      // vec: ld%4==0 && base 16B aligned
+  const float* base; int ld; int X;
+  static constexpr int LDS_INTS = 0;
   static constexpr int PASSES = BX >= 64 ? BX / 64 : 1;
   float r[PASSES * 4];
+  unsigned okbits_;
   int x0_, xr_, kq_;
-  __device__ __forceinline__ void init(int x0, int tid) { x0_ = x0; xr_ = tid >> 2; kq_ = (tid & 3) * 4; }
+  __device__ __forceinline__ void init(int x0, int tid, int*) { x0_ = x0; xr_ = tid >> 2; kq_ = (tid & 3) * 4; }
   __device__ __forceinline__ void load(int k0, int kend) {
+    okbits_ = 0;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int xl = xr_ + p * 64;
       const int x = x0_ + xl, k = k0 + kq_;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (xl < BX && x < X) {
-        const float* src = base + (size_t)x * ld + k;
-        if (vec && k + 3 < kend) {
-          v = *reinterpret_cast<const float4*>(src);
-        } else {
-          if (k + 0 < kend) v.x = src[0];
-          if (k + 1 < kend) v.y = src[1];
-          if (k + 2 < kend) v.z = src[2];
-          if (k + 3 < kend) v.w = src[3];
+      const bool xok = xl < BX && x < X;
+      const unsigned row = (unsigned)(xok ? x : 0) * (unsigned)ld;
+      if (VEC) {                                  // kend % 4 == 0 here, so k < kend covers the whole float4
+        const bool ok = xok && k < kend;
+        const float4 v = *reinterpret_cast<const float4*>(base + row + (ok ? k : 0));
+        r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
+        okbits_ |= ok ? (15u << (p * 4)) : 0u;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool ok = xok && k + i < kend;
+          r[p * 4 + i] = base[row + (ok ? k + i : 0)];
+          okbits_ |= ok ? (1u << (p * 4 + i)) : 0u;
         }
       }
-      r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
     }
   }
   __device__ __forceinline__ void store(float* T) const {
@@ -68,7 +79,7 @@ struct LoadKContig {
       const int xl = xr_ + p * 64;
       if (xl < BX) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) T[(kq_ + i) * LD + xl] = r[p * 4 + i];
+        for (int i = 0; i < 4; ++i) T[(kq_ + i) * LD + xl] = ((okbits_ >> (p * 4 + i)) & 1u) ? r[p * 4 + i] : 0.f;
       }
     }
   }
@@ -78,21 +89,26 @@ struct LoadKContig {
 template <int BX>
 struct LoadXContig {
   const float* base; int ld; int X;
+  static constexpr int LDS_INTS = 0;
   static constexpr int ROWS = BX * BK / 256;
   float r[ROWS];
+  unsigned okbits_;
   int x_, xl_, kr_;
-  __device__ __forceinline__ void init(int x0, int tid) { xl_ = tid % BX; x_ = x0 + xl_; kr_ = (tid / BX) * ROWS; }
+  __device__ __forceinline__ void init(int x0, int tid, int*) { xl_ = tid % BX; x_ = x0 + xl_; kr_ = (tid / BX) * ROWS; }
   __device__ __forceinline__ void load(int k0, int kend) {
+    okbits_ = 0;
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
       const int k = k0 + kr_ + i;
-      r[i] = (x_ < X && k < kend) ? base[(size_t)k * ld + x_] : 0.f;
+      const bool ok = x_ < X && k < kend;
+      r[i] = base[ok ? (unsigned)k * (unsigned)ld + (unsigned)x_ : 0u];
+      okbits_ |= ok ? (1u << i) : 0u;
     }
   }
   __device__ __forceinline__ void store(float* T) const {
     constexpr int LD = BX + 4;
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) T[(kr_ + i) * LD + xl_] = r[i];
+    for (int i = 0; i < ROWS; ++i) T[(kr_ + i) * LD + xl_] = ((okbits_ >> i) & 1u) ? r[i] : 0.f;
   }
 };
 
@@ -108,67 +124,93 @@ struct Gather {
   int bcast2;                            // src2 is [img][C2], broadcast over the spatial grid
 };
 
+// offset of tap (kh, kw) inside one stored channel plane for anchor (ah, aw); -1 = contributes zero
 template <int MODE>
-__device__ __forceinline__ float gather_fetch(const Gather& g, int img, int ah, int aw, int c, int kh, int kw) {
+__device__ __forceinline__ int tap_offset(const Gather& g, int ah, int aw, int kh, int kw) {
   if (MODE == 0) {            // source position = out*stride - pad + tap   (conv-style)
     int ih = ah + kh, iw = aw + kw;
-    if (g.reflect) {
-      ih = ih < 0 ? -ih : ih; ih = ih >= g.LH ? 2 * g.LH - 2 - ih : ih;
-      iw = iw < 0 ? -iw : iw; iw = iw >= g.LW ? 2 * g.LW - 2 - iw : iw;
-    } else if ((unsigned)ih >= (unsigned)g.LH || (unsigned)iw >= (unsigned)g.LW) {
-      return 0.f;
-    }
-    ih >>= g.ushift; iw >>= g.ushift;
-    if (c < g.C1) return g.src1[((size_t)(img * g.C1 + c) * g.SH + ih) * g.SW + iw];
-    if (g.bcast2) return g.src2[(size_t)img * g.C2 + (c - g.C1)];
-    return g.src2[((size_t)(img * g.C2 + (c - g.C1)) * g.SH + ih) * g.SW + iw];
+    const bool inside = (unsigned)ih < (unsigned)g.LH && (unsigned)iw < (unsigned)g.LW;
+    int rh = ih < 0 ? -ih : ih; rh = rh >= g.LH ? 2 * g.LH - 2 - rh : rh;
+    int rw = iw < 0 ? -iw : iw; rw = rw >= g.LW ? 2 * g.LW - 2 - rw : rw;
+    ih = (g.reflect ? rh : ih) >> g.ushift;
+    iw = (g.reflect ? rw : iw) >> g.ushift;
+    return (g.reflect || inside) ? ih * g.SW + iw : -1;
   } else {                    // source position = (out + pad - tap)/stride if divisible (transposed conv)
     int th = ah - kh, tw = aw - kw;
-    if ((th | tw) < 0) return 0.f;
     const int smask = g.stride - 1;
-    if ((th | tw) & smask) return 0.f;
+    bool ok = (th | tw) >= 0 && ((th | tw) & smask) == 0;
     th >>= g.sshift; tw >>= g.sshift;
-    if (th >= g.SH || tw >= g.SW) return 0.f;
-    return g.src1[((size_t)(img * g.C1 + c) * g.SH + th) * g.SW + tw];
+    ok = ok && th < g.SH && tw < g.SW;
+    return ok ? th * g.SW + tw : -1;
   }
 }
 
-// B operand of conv fwd / dgrad: k = (c, kh, kw), n = (img, ph, pw).  One pixel per thread, ROWS taps.
+// B operand of conv fwd / dgrad: k = (c, kh, kw), n = (img, ph, pw).  One pixel per thread, ROWS consecutive k.
+// All geometry (stride, zero/reflect padding, x2 upsample, transposed-conv divisibility) is resolved ONCE per
+// workgroup into an LDS table tap[r][pixel] of plane offsets; the k-loop is then: scalar (c, r) split of k,
+// one ds_read of the tap, one add, one global load.
 template <int BN, int KS, int MODE>
 struct LoadGatherKN {
   Gather g; int Npix;
+  static constexpr int KS2 = KS * KS;
+  static constexpr int LDS_INTS = KS2 * BN;
   static constexpr int ROWS = BN * BK / 256;
   float r[ROWS];
-  int nl_, kr_, img_, ah_, aw_, ok_;
-  __device__ __forceinline__ void init(int n0, int tid) {
-    nl_ = tid % BN; kr_ = (tid / BN) * ROWS;
+  unsigned okbits_, img1_, img2_, img2b_;
+  int nl_, kr_, ok_;
+  const int* tab_;
+  __device__ __forceinline__ void init(int n0, int tid, int* tab) {
+    nl_ = tid % BN;
+    const int grp = tid / BN;
+    kr_ = __builtin_amdgcn_readfirstlane(grp * ROWS);          // wave-uniform => (c, r) live in SGPRs
     const int n = n0 + nl_;
     ok_ = n < Npix;
     const int nn = ok_ ? n : 0;
     const int phw = g.PH * g.PW;
-    img_ = nn / phw;
-    const int pix = nn - img_ * phw;
+    const int img = nn / phw;
+    const int pix = nn - img * phw;
     const int ph = pix / g.PW, pw = pix - ph * g.PW;
-    if (MODE == 0) { ah_ = ph * g.stride - g.pad; aw_ = pw * g.stride - g.pad; }
-    else { ah_ = ph + g.pad; aw_ = pw + g.pad; }
+    int ah, aw;
+    if (MODE == 0) { ah = ph * g.stride - g.pad; aw = pw * g.stride - g.pad; }
+    else { ah = ph + g.pad; aw = pw + g.pad; }
+    const unsigned shw = (unsigned)(g.SH * g.SW);
+    img1_ = (unsigned)img * (unsigned)g.C1 * shw;
+    img2_ = (unsigned)img * (unsigned)g.C2 * shw;
+    img2b_ = (unsigned)img * (unsigned)g.C2;
+    constexpr int G = 256 / BN;
+    for (int t = grp; t < KS2; t += G) {
+      const int kh = t / KS, kw = t - kh * KS;
+      tab[t * BN + nl_] = tap_offset<MODE>(g, ah, aw, kh, kw);
+    }
+    tab_ = tab;
   }
   __device__ __forceinline__ void load(int k0, int kend) {
-    int k = k0 + kr_;
-    int c = k / (KS * KS);
-    int rr = k - c * (KS * KS);
-    int kh = rr / KS, kw = rr - kh * KS;
+    const int k = k0 + kr_;
+    int c = k / KS2;
+    int t = k - c * KS2;
+    const unsigned shw = (unsigned)(g.SH * g.SW);
+    okbits_ = 0;
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
-      float v = 0.f;
-      if (ok_ && k + i < kend) v = gather_fetch<MODE>(g, img_, ah_, aw_, c, kh, kw);
-      r[i] = v;
-      if (++kw == KS) { kw = 0; if (++kh == KS) { kh = 0; ++c; } }
+      const int tp = tab_[t * BN + nl_];
+      const bool ok = ok_ && (k + i < kend) && tp >= 0;
+      const bool second = g.C2 > 0 && c >= g.C1;                          // scalar; src2 may be null when C2==0
+      const float* base = second ? g.src2 : g.src1;
+      const unsigned cc = (unsigned)(second ? c - g.C1 : c);
+      unsigned off = (second ? img2_ : img1_) + cc * shw + (unsigned)tp;
+      off = (second && g.bcast2) ? img2b_ + cc : off;
+      r[i] = base[ok ? off : 0u];
+      okbits_ |= ok ? (1u << i) : 0u;
+      ++t;
+      const bool wrap = t == KS2;
+      t = wrap ? 0 : t;
+      c += wrap ? 1 : 0;
     }
   }
   __device__ __forceinline__ void store(float* T) const {
     constexpr int LD = BN + 4;
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) T[(kr_ + i) * LD + nl_] = r[i];
+    for (int i = 0; i < ROWS; ++i) T[(kr_ + i) * LD + nl_] = ((okbits_ >> i) & 1u) ? r[i] : 0.f;
   }
 };
 
@@ -176,48 +218,60 @@ struct LoadGatherKN {
 template <int BM>
 struct LoadPixK {
   const float* base; int M, Mtot, PQ;
+  static constexpr int LDS_INTS = 0;
   static constexpr int ROWS = BM / 16;
   float r[ROWS];
+  unsigned okbits_;
   int m0_, mr_, kl_;
-  __device__ __forceinline__ void init(int m0, int tid) { m0_ = m0; kl_ = tid & 15; mr_ = tid >> 4; }
+  __device__ __forceinline__ void init(int m0, int tid, int*) { m0_ = m0; kl_ = tid & 15; mr_ = tid >> 4; }
   __device__ __forceinline__ void load(int k0, int kend) {
     const int k = k0 + kl_;
     const bool kok = k < kend;
     const int kk = kok ? k : 0;
     const int img = kk / PQ, pix = kk - img * PQ;
-    const float* p = base + (size_t)img * Mtot * PQ + pix;
+    const unsigned p0 = (unsigned)img * (unsigned)Mtot * (unsigned)PQ + (unsigned)pix;
+    okbits_ = 0;
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
       const int m = m0_ + mr_ + 16 * i;
-      r[i] = (kok && m < M) ? p[(size_t)m * PQ] : 0.f;
+      const bool ok = kok && m < M;
+      r[i] = base[ok ? p0 + (unsigned)m * (unsigned)PQ : 0u];
+      okbits_ |= ok ? (1u << i) : 0u;
     }
   }
   __device__ __forceinline__ void store(float* T) const {
     constexpr int LD = BM + 4;
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) T[kl_ * LD + mr_ + 16 * i] = r[i];
+    for (int i = 0; i < ROWS; ++i) T[kl_ * LD + mr_ + 16 * i] = ((okbits_ >> i) & 1u) ? r[i] : 0.f;
   }
 };
 
-// B operand of wgrad: k = (img, ph, pw) over the gy grid, n = (c, kh, kw).  Lanes run along k (pixels).
+// B operand of wgrad: k = (img, ph, pw) over the gy grid, n = (c, kh, kw).  Lanes run along k (pixels); the COLS
+// columns a thread owns are fixed for the whole k-loop.
 template <int BN, int KS>
 struct LoadGatherNK {
   Gather g; int Ncols;
+  static constexpr int LDS_INTS = 0;
   static constexpr int COLS = BN / 16;
   float r[COLS];
+  unsigned okbits_;
   int kl_, nr_;
-  int c_[COLS]; int khw_[COLS];
-  __device__ __forceinline__ void init(int n0, int tid) {
+  int cofs_[COLS]; int khw_[COLS];       // channel-plane offset (or -1) / packed tap; second-source flag in bit 16
+  __device__ __forceinline__ void init(int n0, int tid, int*) {
     kl_ = tid & 15; nr_ = tid >> 4;
+    const int shw = g.SH * g.SW;
 #pragma unroll
     for (int j = 0; j < COLS; ++j) {
       const int n = n0 + nr_ + 16 * j;
-      if (n < Ncols) {
-        const int c = n / (KS * KS);
-        const int rr = n - c * (KS * KS);
-        const int kh = rr / KS;
-        c_[j] = c; khw_[j] = (kh << 8) | (rr - kh * KS);
-      } else { c_[j] = -1; khw_[j] = 0; }
+      const bool ok = n < Ncols;
+      const int nn = ok ? n : 0;
+      const int c = nn / (KS * KS);
+      const int rr = nn - c * (KS * KS);
+      const int kh = rr / KS;
+      const bool second = c >= g.C1;
+      const int cc = second ? c - g.C1 : c;
+      cofs_[j] = ok ? (second && g.bcast2 ? cc : cc * shw) : -1;
+      khw_[j] = (kh << 8) | (rr - kh * KS) | (second ? (1 << 16) : 0);
     }
   }
   __device__ __forceinline__ void load(int k0, int kend) {
@@ -228,17 +282,26 @@ struct LoadGatherNK {
     const int img = kk / phw, pix = kk - img * phw;
     const int ph = pix / g.PW, pw = pix - ph * g.PW;
     const int ah = ph * g.stride - g.pad, aw = pw * g.stride - g.pad;
+    const unsigned shw = (unsigned)(g.SH * g.SW);
+    const unsigned img1 = (unsigned)img * (unsigned)g.C1 * shw, img2 = (unsigned)img * (unsigned)g.C2 * shw;
+    const unsigned img2b = (unsigned)img * (unsigned)g.C2;
+    okbits_ = 0;
 #pragma unroll
     for (int j = 0; j < COLS; ++j) {
-      float v = 0.f;
-      if (kok && c_[j] >= 0) v = gather_fetch<0>(g, img, ah, aw, c_[j], khw_[j] >> 8, khw_[j] & 255);
-      r[j] = v;
+      const int tp = tap_offset<0>(g, ah, aw, (khw_[j] >> 8) & 255, khw_[j] & 255);
+      const bool second = (khw_[j] >> 16) & 1;
+      const bool ok = kok && cofs_[j] >= 0 && tp >= 0;
+      const float* base = second ? g.src2 : g.src1;
+      unsigned off = (second ? img2 : img1) + (unsigned)cofs_[j] + (unsigned)tp;
+      off = (second && g.bcast2) ? img2b + (unsigned)cofs_[j] : off;
+      r[j] = base[ok ? off : 0u];
+      okbits_ |= ok ? (1u << j) : 0u;
     }
   }
   __device__ __forceinline__ void store(float* T) const {
     constexpr int LD = BN + 4;
 #pragma unroll
-    for (int j = 0; j < COLS; ++j) T[kl_ * LD + nr_ + 16 * j] = r[j];
+    for (int j = 0; j < COLS; ++j) T[kl_ * LD + nr_ + 16 * j] = ((okbits_ >> j) & 1u) ? r[j] : 0.f;
   }
 };
 
@@ -301,6 +364,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, LDA = CFG::LDA, LDB = CFG::LDB;
   __shared__ float As[2][BK * LDA];
   __shared__ float Bs[2][BK * LDB];
+  __shared__ int tapA[AL::LDS_INTS > 0 ? AL::LDS_INTS : 1];
+  __shared__ int tapB[BL::LDS_INTS > 0 ? BL::LDS_INTS : 1];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm0 = (wid / CFG::WGN) * CFG::WM, wn0 = (wid % CFG::WGN) * CFG::WN;
 
@@ -316,8 +381,9 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   const int kbeg = blockIdx.z * kchunk;
   const int kend = min(K, kbeg + kchunk);
 
-  al.init(m0, tid);
-  bl.init(n0, tid);
+  al.init(m0, tid, tapA);
+  bl.init(n0, tid, tapB);
+  if (AL::LDS_INTS > 0 || BL::LDS_INTS > 0) __syncthreads();
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -419,24 +485,24 @@ int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* b
            float slope, double flops, hipStream_t s) {
   const int Npix = NB * g.PH * g.PW;
   EpNCHW ep{out, bias, g.PH * g.PW, Mtot, M, Npix, act, slope};
-  const int vec = (K % 4 == 0) && aligned16(A);
+  const bool vec = (K % 4 == 0) && aligned16(A);
   const int tile = pick_tile(M, Npix);
   SgProfScope prof(sg_igemm_kind(MODE, KS, tile), s, flops, 0);
   switch (tile) {
     case 0: {
-      LoadKContig<128> al{A, K, M, vec};
       LoadGatherKN<128, KS, MODE> bl{g, Npix};
-      return launch_cfg<Cfg128>(al, bl, ep, M, Npix, K, 1, s);
+      if (vec) return launch_cfg<Cfg128>(LoadKContig<128, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+      return launch_cfg<Cfg128>(LoadKContig<128, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
     }
     case 1: {
-      LoadKContig<64> al{A, K, M, vec};
       LoadGatherKN<64, KS, MODE> bl{g, Npix};
-      return launch_cfg<Cfg64>(al, bl, ep, M, Npix, K, 1, s);
+      if (vec) return launch_cfg<Cfg64>(LoadKContig<64, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+      return launch_cfg<Cfg64>(LoadKContig<64, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
     }
     default: {
-      LoadKContig<32> al{A, K, M, vec};
       LoadGatherKN<128, KS, MODE> bl{g, Npix};
-      return launch_cfg<Cfg32>(al, bl, ep, M, Npix, K, 1, s);
+      if (vec) return launch_cfg<Cfg32>(LoadKContig<32, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+      return launch_cfg<Cfg32>(LoadKContig<32, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
     }
   }
 }
@@ -520,6 +586,11 @@ int check_desc(const sgConvDesc* d, const char* who) {
   SG_ARG_CHECK(d->N > 0 && d->C1 > 0 && d->C2 >= 0 && d->Cout > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0,
                "%s: non-positive dimension", who);
   SG_ARG_CHECK(!d->pad_reflect || d->pad < d->H * d->upsample, "%s: reflect pad too large", who);
+  const double lim = 2147483647.0;     // kernels use 32-bit element offsets
+  SG_ARG_CHECK((double)d->N * (d->C1 + d->C2) * d->H * d->W < lim && (double)d->N * d->Cout * d->OH * d->OW < lim &&
+                   (double)d->N * (d->C1 + d->C2) * (d->H * d->upsample + 2.0 * d->pad) *
+                           (d->W * d->upsample + 2.0 * d->pad) < lim,
+               "%s: tensor has >= 2^31 elements", who);
   return 0;
 }
 
@@ -647,8 +718,8 @@ extern "C" int sg_convT2d_wgrad(const sgConvDesc* d, const float* gy, const floa
 
 // ---- dense layers --------------------------------------------------------------------------------
 namespace {
-template <class AL64, class BL64, class AL32, class BL128>
-int run_dense(const AL64& a64, const BL64& b64, const AL32& a32, const BL128& b128, const EpRowMajor& ep, int M, int N,
+template <class A64, class B64, class A32, class B128>
+int run_dense(const A64& a64, const B64& b64, const A32& a32, const B128& b128, const EpRowMajor& ep, int M, int N,
               int K, hipStream_t s) {
   if (M <= 32) return launch_cfg<Cfg32>(a32, b128, ep, M, N, K, 1, s);
   return launch_cfg<Cfg64>(a64, b64, ep, M, N, K, 1, s);
@@ -660,10 +731,14 @@ extern "C" int sg_linear_fwd(const float* x, const float* w, const float* b, flo
   SG_ARG_CHECK(x && w && y && rows > 0 && in_f > 0 && out_f > 0, "sg_linear_fwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   EpRowMajor ep{y, b, rows, out_f, out_f, act, slope, 0};
-  const int va = (in_f % 4 == 0) && aligned16(x), vb = (in_f % 4 == 0) && aligned16(w);
+  const bool vec = (in_f % 4 == 0) && aligned16(x) && aligned16(w);
   SgProfScope prof(SG_K_LINEAR, s, 2.0 * rows * (double)in_f * out_f, 0);
-  run_dense(LoadKContig<64>{x, in_f, rows, va}, LoadKContig<64>{w, in_f, out_f, vb}, LoadKContig<32>{x, in_f, rows, va},
-            LoadKContig<128>{w, in_f, out_f, vb}, ep, rows, out_f, in_f, s);
+  if (vec)
+    run_dense(LoadKContig<64, true>{x, in_f, rows}, LoadKContig<64, true>{w, in_f, out_f},
+              LoadKContig<32, true>{x, in_f, rows}, LoadKContig<128, true>{w, in_f, out_f}, ep, rows, out_f, in_f, s);
+  else
+    run_dense(LoadKContig<64, false>{x, in_f, rows}, LoadKContig<64, false>{w, in_f, out_f},
+              LoadKContig<32, false>{x, in_f, rows}, LoadKContig<128, false>{w, in_f, out_f}, ep, rows, out_f, in_f, s);
   SG_LAUNCH_CHECK("sg_linear_fwd");
   return 0;
 }
@@ -673,10 +748,14 @@ extern "C" int sg_linear_bwd_data(const float* gy, const float* w, float* gx, in
   SG_ARG_CHECK(gy && w && gx && rows > 0 && in_f > 0 && out_f > 0, "sg_linear_bwd_data: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   EpRowMajor ep{gx, nullptr, rows, in_f, in_f, SG_ACT_NONE, 0.f, 0};
-  const int va = (out_f % 4 == 0) && aligned16(gy);
+  const bool vec = (out_f % 4 == 0) && aligned16(gy);
   SgProfScope prof(SG_K_LINEAR, s, 2.0 * rows * (double)in_f * out_f, 0);
-  run_dense(LoadKContig<64>{gy, out_f, rows, va}, LoadXContig<64>{w, in_f, in_f}, LoadKContig<32>{gy, out_f, rows, va},
-            LoadXContig<128>{w, in_f, in_f}, ep, rows, in_f, out_f, s);
+  if (vec)
+    run_dense(LoadKContig<64, true>{gy, out_f, rows}, LoadXContig<64>{w, in_f, in_f}, LoadKContig<32, true>{gy, out_f, rows},
+              LoadXContig<128>{w, in_f, in_f}, ep, rows, in_f, out_f, s);
+  else
+    run_dense(LoadKContig<64, false>{gy, out_f, rows}, LoadXContig<64>{w, in_f, in_f},
+              LoadKContig<32, false>{gy, out_f, rows}, LoadXContig<128>{w, in_f, in_f}, ep, rows, in_f, out_f, s);
   SG_LAUNCH_CHECK("sg_linear_bwd_data");
   return 0;
 }
