@@ -12,16 +12,20 @@
 // and the (layout, image) channel concat are folded into the gather index, so none is materialised.
 // Replaces the cuDNN/ATen conv + addmm kernels the reference dispatches (see include/sg2im_hip.h).
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 16;
+constexpr int BK = 16;     // sub-tile depth: the unit one loader call stages (16 k-rows)
 
-template <int BM_, int BN_, int WGM_>
+// A workgroup k-tile is NSUB sub-tiles deep (BKT = 16*NSUB): all 2*NSUB loader calls of the next tile are issued
+// before the MFMAs of the current one, so NSUB*~8 global loads per thread stay in flight across 8*NSUB*TM*TN
+// MFMAs (the f32 MFMA is 64 cycles: one sub-tile of work per load round trip left the kernel latency-bound).
+template <int BM_, int BN_, int WGM_, int NSUB_>
 struct TileCfg {
-  static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = 4 / WGM_;
+  static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = 4 / WGM_, NSUB = NSUB_, BKT = BK * NSUB_;
   static constexpr int WM = BM / WGM, WN = BN / WGN;
   static constexpr int TM = WM / 32, TN = WN / 32;
   static constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -45,12 +49,11 @@ struct LoadKContig {
   const float* base; int ld; int X;
   static constexpr int LDS_INTS = 0;
   static constexpr int PASSES = BX >= 64 ? BX / 64 : 1;
-  float r[PASSES * 4];
-  unsigned okbits_;
+  struct Stage { float r[PASSES * 4]; unsigned ok; };
   int x0_, xr_, kq_;
   __device__ __forceinline__ void init(int x0, int tid, int*) { x0_ = x0; xr_ = tid >> 2; kq_ = (tid & 3) * 4; }
-  __device__ __forceinline__ void load(int k0, int kend) {
-    okbits_ = 0;
+  __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
+    st.ok = 0;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int xl = xr_ + p * 64;
@@ -60,26 +63,26 @@ struct LoadKContig {
       if (VEC) {                                  // kend % 4 == 0 here, so k < kend covers the whole float4
         const bool ok = xok && k < kend;
         const float4 v = *reinterpret_cast<const float4*>(base + row + (ok ? k : 0));
-        r[p * 4 + 0] = v.x; r[p * 4 + 1] = v.y; r[p * 4 + 2] = v.z; r[p * 4 + 3] = v.w;
-        okbits_ |= ok ? (15u << (p * 4)) : 0u;
+        st.r[p * 4 + 0] = v.x; st.r[p * 4 + 1] = v.y; st.r[p * 4 + 2] = v.z; st.r[p * 4 + 3] = v.w;
+        st.ok |= ok ? (15u << (p * 4)) : 0u;
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const bool ok = xok && k + i < kend;
-          r[p * 4 + i] = base[row + (ok ? k + i : 0)];
-          okbits_ |= ok ? (1u << (p * 4 + i)) : 0u;
+          st.r[p * 4 + i] = base[row + (ok ? k + i : 0)];
+          st.ok |= ok ? (1u << (p * 4 + i)) : 0u;
         }
       }
     }
   }
-  __device__ __forceinline__ void store(float* T) const {
+  __device__ __forceinline__ void store(const Stage& st, float* T) const {
     constexpr int LD = BX + 4;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int xl = xr_ + p * 64;
       if (xl < BX) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) T[(kq_ + i) * LD + xl] = ((okbits_ >> (p * 4 + i)) & 1u) ? r[p * 4 + i] : 0.f;
+        for (int i = 0; i < 4; ++i) T[(kq_ + i) * LD + xl] = ((st.ok >> (p * 4 + i)) & 1u) ? st.r[p * 4 + i] : 0.f;
       }
     }
   }
@@ -91,24 +94,23 @@ struct LoadXContig {
   const float* base; int ld; int X;
   static constexpr int LDS_INTS = 0;
   static constexpr int ROWS = BX * BK / 256;
-  float r[ROWS];
-  unsigned okbits_;
+  struct Stage { float r[ROWS]; unsigned ok; };
   int x_, xl_, kr_;
   __device__ __forceinline__ void init(int x0, int tid, int*) { xl_ = tid % BX; x_ = x0 + xl_; kr_ = (tid / BX) * ROWS; }
-  __device__ __forceinline__ void load(int k0, int kend) {
-    okbits_ = 0;
+  __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
+    st.ok = 0;
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
       const int k = k0 + kr_ + i;
       const bool ok = x_ < X && k < kend;
-      r[i] = base[ok ? (unsigned)k * (unsigned)ld + (unsigned)x_ : 0u];
-      okbits_ |= ok ? (1u << i) : 0u;
+      st.r[i] = base[ok ? (unsigned)k * (unsigned)ld + (unsigned)x_ : 0u];
+      st.ok |= ok ? (1u << i) : 0u;
     }
   }
-  __device__ __forceinline__ void store(float* T) const {
+  __device__ __forceinline__ void store(const Stage& st, float* T) const {
     constexpr int LD = BX + 4;
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) T[(kr_ + i) * LD + xl_] = ((okbits_ >> i) & 1u) ? r[i] : 0.f;
+    for (int i = 0; i < ROWS; ++i) T[(kr_ + i) * LD + xl_] = ((st.ok >> i) & 1u) ? st.r[i] : 0.f;
   }
 };
 
@@ -155,8 +157,8 @@ struct LoadGatherKN {
   static constexpr int KS2 = KS * KS;
   static constexpr int LDS_INTS = KS2 * BN;
   static constexpr int ROWS = BN * BK / 256;
-  float r[ROWS];
-  unsigned okbits_, img1_, img2_, img2b_;
+  struct Stage { float r[ROWS]; unsigned ok; };
+  unsigned img1_, img2_, img2b_;
   int nl_, kr_, ok_;
   const int* tab_;
   __device__ __forceinline__ void init(int n0, int tid, int* tab) {
@@ -184,33 +186,45 @@ struct LoadGatherKN {
     }
     tab_ = tab;
   }
-  __device__ __forceinline__ void load(int k0, int kend) {
+  __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
     const int k = k0 + kr_;
-    int c = k / KS2;
-    int t = k - c * KS2;
+    const int c0 = k / KS2;
+    const int t0 = k - c0 * KS2;
     const unsigned shw = (unsigned)(g.SH * g.SW);
-    okbits_ = 0;
+    // 1) all tap lookups first (independent LDS reads, one round trip) ...
+    int tp[ROWS];
+    {
+      int t = t0;
+#pragma unroll
+      for (int i = 0; i < ROWS; ++i) {
+        tp[i] = tab_[t * BN + nl_];
+        ++t;
+        t = (t == KS2) ? 0 : t;
+      }
+    }
+    // 2) ... then the global loads, back to back
+    st.ok = 0;
+    int c = c0, t = t0;
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
-      const int tp = tab_[t * BN + nl_];
-      const bool ok = ok_ && (k + i < kend) && tp >= 0;
+      const bool ok = ok_ && (k + i < kend) && tp[i] >= 0;
       const bool second = g.C2 > 0 && c >= g.C1;                          // scalar; src2 may be null when C2==0
       const float* base = second ? g.src2 : g.src1;
       const unsigned cc = (unsigned)(second ? c - g.C1 : c);
-      unsigned off = (second ? img2_ : img1_) + cc * shw + (unsigned)tp;
+      unsigned off = (second ? img2_ : img1_) + cc * shw + (unsigned)tp[i];
       off = (second && g.bcast2) ? img2b_ + cc : off;
-      r[i] = base[ok ? off : 0u];
-      okbits_ |= ok ? (1u << i) : 0u;
+      st.r[i] = base[ok ? off : 0u];
+      st.ok |= ok ? (1u << i) : 0u;
       ++t;
       const bool wrap = t == KS2;
       t = wrap ? 0 : t;
       c += wrap ? 1 : 0;
     }
   }
-  __device__ __forceinline__ void store(float* T) const {
+  __device__ __forceinline__ void store(const Stage& st, float* T) const {
     constexpr int LD = BN + 4;
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) T[(kr_ + i) * LD + nl_] = ((okbits_ >> i) & 1u) ? r[i] : 0.f;
+    for (int i = 0; i < ROWS; ++i) T[(kr_ + i) * LD + nl_] = ((st.ok >> i) & 1u) ? st.r[i] : 0.f;
   }
 };
 
@@ -220,29 +234,28 @@ struct LoadPixK {
   const float* base; int M, Mtot, PQ;
   static constexpr int LDS_INTS = 0;
   static constexpr int ROWS = BM / 16;
-  float r[ROWS];
-  unsigned okbits_;
+  struct Stage { float r[ROWS]; unsigned ok; };
   int m0_, mr_, kl_;
   __device__ __forceinline__ void init(int m0, int tid, int*) { m0_ = m0; kl_ = tid & 15; mr_ = tid >> 4; }
-  __device__ __forceinline__ void load(int k0, int kend) {
+  __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
     const int k = k0 + kl_;
     const bool kok = k < kend;
     const int kk = kok ? k : 0;
     const int img = kk / PQ, pix = kk - img * PQ;
     const unsigned p0 = (unsigned)img * (unsigned)Mtot * (unsigned)PQ + (unsigned)pix;
-    okbits_ = 0;
+    st.ok = 0;
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
       const int m = m0_ + mr_ + 16 * i;
       const bool ok = kok && m < M;
-      r[i] = base[ok ? p0 + (unsigned)m * (unsigned)PQ : 0u];
-      okbits_ |= ok ? (1u << i) : 0u;
+      st.r[i] = base[ok ? p0 + (unsigned)m * (unsigned)PQ : 0u];
+      st.ok |= ok ? (1u << i) : 0u;
     }
   }
-  __device__ __forceinline__ void store(float* T) const {
+  __device__ __forceinline__ void store(const Stage& st, float* T) const {
     constexpr int LD = BM + 4;
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) T[kl_ * LD + mr_ + 16 * i] = ((okbits_ >> i) & 1u) ? r[i] : 0.f;
+    for (int i = 0; i < ROWS; ++i) T[kl_ * LD + mr_ + 16 * i] = ((st.ok >> i) & 1u) ? st.r[i] : 0.f;
   }
 };
 
@@ -253,8 +266,7 @@ struct LoadGatherNK {
   Gather g; int Ncols;
   static constexpr int LDS_INTS = 0;
   static constexpr int COLS = BN / 16;
-  float r[COLS];
-  unsigned okbits_;
+  struct Stage { float r[COLS]; unsigned ok; };
   int kl_, nr_;
   int cofs_[COLS]; int khw_[COLS];       // channel-plane offset (or -1) / packed tap; second-source flag in bit 16
   __device__ __forceinline__ void init(int n0, int tid, int*) {
@@ -274,7 +286,7 @@ struct LoadGatherNK {
       khw_[j] = (kh << 8) | (rr - kh * KS) | (second ? (1 << 16) : 0);
     }
   }
-  __device__ __forceinline__ void load(int k0, int kend) {
+  __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
     const int k = k0 + kl_;
     const bool kok = k < kend;
     const int kk = kok ? k : 0;
@@ -285,7 +297,7 @@ struct LoadGatherNK {
     const unsigned shw = (unsigned)(g.SH * g.SW);
     const unsigned img1 = (unsigned)img * (unsigned)g.C1 * shw, img2 = (unsigned)img * (unsigned)g.C2 * shw;
     const unsigned img2b = (unsigned)img * (unsigned)g.C2;
-    okbits_ = 0;
+    st.ok = 0;
 #pragma unroll
     for (int j = 0; j < COLS; ++j) {
       const int tp = tap_offset<0>(g, ah, aw, (khw_[j] >> 8) & 255, khw_[j] & 255);
@@ -294,14 +306,14 @@ struct LoadGatherNK {
       const float* base = second ? g.src2 : g.src1;
       unsigned off = (second ? img2 : img1) + (unsigned)cofs_[j] + (unsigned)tp;
       off = (second && g.bcast2) ? img2b + (unsigned)cofs_[j] : off;
-      r[j] = base[ok ? off : 0u];
-      okbits_ |= ok ? (1u << j) : 0u;
+      st.r[j] = base[ok ? off : 0u];
+      st.ok |= ok ? (1u << j) : 0u;
     }
   }
-  __device__ __forceinline__ void store(float* T) const {
+  __device__ __forceinline__ void store(const Stage& st, float* T) const {
     constexpr int LD = BN + 4;
 #pragma unroll
-    for (int j = 0; j < COLS; ++j) T[kl_ * LD + nr_ + 16 * j] = ((okbits_ >> j) & 1u) ? r[j] : 0.f;
+    for (int j = 0; j < COLS; ++j) T[kl_ * LD + nr_ + 16 * j] = ((st.ok >> j) & 1u) ? st.r[j] : 0.f;
   }
 };
 
@@ -362,8 +374,9 @@ struct EpRowMajor {  // out[z][m*ldc + n] ; bias per column n
 template <class CFG, class AL, class BL, class EP>
 __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int kchunk) {
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, LDA = CFG::LDA, LDB = CFG::LDB;
-  __shared__ float As[2][BK * LDA];
-  __shared__ float Bs[2][BK * LDB];
+  constexpr int NSUB = CFG::NSUB, BKT = CFG::BKT;
+  __shared__ float As[2][BKT * LDA];
+  __shared__ float Bs[2][BKT * LDB];
   __shared__ int tapA[AL::LDS_INTS > 0 ? AL::LDS_INTS : 1];
   __shared__ int tapB[BL::LDS_INTS > 0 ? BL::LDS_INTS : 1];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -393,43 +406,86 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  al.load(kbeg, kend);
-  bl.load(kbeg, kend);
-  al.store(As[0]);
-  bl.store(Bs[0]);
+  typename AL::Stage sa[NSUB];
+  typename BL::Stage sb[NSUB];
+#pragma unroll
+  for (int u = 0; u < NSUB; ++u) { al.load(sa[u], kbeg + u * BK, kend); bl.load(sb[u], kbeg + u * BK, kend); }
+#pragma unroll
+  for (int u = 0; u < NSUB; ++u) { al.store(sa[u], As[0] + u * BK * LDA); bl.store(sb[u], Bs[0] + u * BK * LDB); }
   __syncthreads();
 
   const int lr = lane & 31, lk = lane >> 5;
   int buf = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
-    if (more) { al.load(k0 + BK, kend); bl.load(k0 + BK, kend); }
-    const float* A_ = As[buf];
-    const float* B_ = Bs[buf];
+  for (int k0 = kbeg; k0 < kend; k0 += BKT) {
+    const bool more = k0 + BKT < kend;
+    if (more) {
 #pragma unroll
-    for (int ks = 0; ks < BK; ks += 2) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = A_[(ks + lk) * LDA + wm0 + i * 32 + lr];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = B_[(ks + lk) * LDB + wn0 + j * 32 + lr];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int u = 0; u < NSUB; ++u) { al.load(sa[u], k0 + BKT + u * BK, kend); bl.load(sb[u], k0 + BKT + u * BK, kend); }
     }
-    if (more) { al.store(As[buf ^ 1]); bl.store(Bs[buf ^ 1]); }
+    const float* A_ = As[buf] + lk * LDA + wm0 + lr;
+    const float* B_ = Bs[buf] + lk * LDB + wn0 + lr;
+    // MFMA phase in groups of >= 4 MFMAs; the LDS fragment reads of group g+1 are pinned IN FRONT of the MFMAs of
+    // group g (sched_group_barrier), so an LDS round trip (~150-250 cycles) is covered by >= 256 cycles of matrix
+    // pipe work instead of stalling every MFMA pair.
+    constexpr int G = (TM * TN >= 4) ? 1 : (TM * TN == 2 ? 2 : 4);      // k-steps (of 2) per group
+    constexpr int NG = BKT / (2 * G);
+    float a[2][G][TM], b[2][G][TN];
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[0][q][i] = A_[(2 * q) * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[0][q][j] = B_[(2 * q) * LDB + j * 32];
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int cur = g & 1, nxt = cur ^ 1;
+      if (g + 1 < NG) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[nxt][q][i] = A_[(2 * ((g + 1) * G + q)) * LDA + i * 32];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[nxt][q][j] = B_[(2 * ((g + 1) * G + q)) * LDB + j * 32];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][q][i], b[cur][q][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, G * (TM + TN), 0);     // DS reads of the next group first
+      __builtin_amdgcn_sched_group_barrier(0x008, G * TM * TN, 0);       // then this group's MFMAs
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < NSUB; ++u) {
+        al.store(sa[u], As[buf ^ 1] + u * BK * LDA);
+        bl.store(sb[u], Bs[buf ^ 1] + u * BK * LDB);
+      }
+    }
     __syncthreads();
     buf ^= 1;
   }
   ep.store(acc, m0 + wm0, n0 + wn0, lane, blockIdx.z);
 }
 
-using Cfg128 = TileCfg<128, 128, 2>;
-using Cfg64 = TileCfg<64, 64, 2>;
-using Cfg32 = TileCfg<32, 128, 1>;
+// tile configurations: NSUB chosen so that a workgroup (tiles + tap table) stays <= ~76 KB of LDS => 2 per CU
+template <int KS> struct CfgFor {
+  using C128 = TileCfg<128, 128, 2, (KS == 7 ? 1 : 2)>;
+  using C64 = TileCfg<64, 64, 2, (KS == 7 ? 2 : 4)>;
+  using C32 = TileCfg<32, 128, 1, 2>;
+};
+using Cfg128 = CfgFor<3>::C128;      // dense layers / wgrad use the KS-independent depths
+using Cfg64 = CfgFor<3>::C64;
+using Cfg32 = CfgFor<3>::C32;
 
 inline int pick_tile(int M, int N) {
+  static int force = -2;
+  if (force == -2) { const char* e = getenv("SG_TILE"); force = e ? atoi(e) : -1; }
+  if (force >= 0) return force;
   if (M <= 32) return 2;
   const long t128 = (long)sg_cdiv(M, 128) * sg_cdiv(N, 128);
   if (M >= 96 && t128 >= 384) return 0;
@@ -440,7 +496,7 @@ template <class CFG, class AL, class BL, class EP>
 int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int splits, hipStream_t s) {
   const int tiles = sg_cdiv(M, CFG::BM) * sg_cdiv(N, CFG::BN);
   int kchunk = K;
-  if (splits > 1) kchunk = sg_cdiv(sg_cdiv(K, splits), BK) * BK;
+  if (splits > 1) kchunk = sg_cdiv(sg_cdiv(K, splits), CFG::BKT) * CFG::BKT;
   dim3 grid(tiles, 1, splits > 1 ? sg_cdiv(K, kchunk) : 1);
   hipLaunchKernelGGL((igemm_kernel<CFG, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, N, K, kchunk);
   return 0;
@@ -491,18 +547,18 @@ int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* b
   switch (tile) {
     case 0: {
       LoadGatherKN<128, KS, MODE> bl{g, Npix};
-      if (vec) return launch_cfg<Cfg128>(LoadKContig<128, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
-      return launch_cfg<Cfg128>(LoadKContig<128, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+      if (vec) return launch_cfg<typename CfgFor<KS>::C128>(LoadKContig<128, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+      return launch_cfg<typename CfgFor<KS>::C128>(LoadKContig<128, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
     }
     case 1: {
       LoadGatherKN<64, KS, MODE> bl{g, Npix};
-      if (vec) return launch_cfg<Cfg64>(LoadKContig<64, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
-      return launch_cfg<Cfg64>(LoadKContig<64, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+      if (vec) return launch_cfg<typename CfgFor<KS>::C64>(LoadKContig<64, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+      return launch_cfg<typename CfgFor<KS>::C64>(LoadKContig<64, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
     }
     default: {
       LoadGatherKN<128, KS, MODE> bl{g, Npix};
-      if (vec) return launch_cfg<Cfg32>(LoadKContig<32, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
-      return launch_cfg<Cfg32>(LoadKContig<32, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+      if (vec) return launch_cfg<typename CfgFor<KS>::C32>(LoadKContig<32, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+      return launch_cfg<typename CfgFor<KS>::C32>(LoadKContig<32, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
     }
   }
 }
@@ -539,7 +595,7 @@ int run_nk(const float* A, int M, int Mtot, const Gather& g, int NB, float* out,
   const size_t mn = (size_t)M * Ncols;
   if (splits > 1 && ws_bytes < mn * sizeof(float) * (size_t)splits) splits = (int)(ws_bytes / (mn * sizeof(float)));
   if (splits < 2) splits = 1;
-  int kchunk = sg_cdiv(sg_cdiv(Kpix, splits), BK) * BK;
+  int kchunk = sg_cdiv(sg_cdiv(Kpix, splits), 64) * 64;      // multiple of every BKT
   splits = sg_cdiv(Kpix, kchunk);
   float* dst = splits > 1 ? reinterpret_cast<float*>(ws) : out;
   EpRowMajor ep{dst, nullptr, M, Ncols, Ncols, SG_ACT_NONE, 0.f, mn};
