@@ -472,11 +472,16 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   ep.store(acc, m0 + wm0, n0 + wn0, lane, blockIdx.z);
 }
 
-// tile configurations: NSUB chosen so that a workgroup (tiles + tap table) stays <= ~76 KB of LDS => 2 per CU
+// tile configurations.  Measured on MI355X (tools/bench_conv.py): these kernels are limited by the vector-memory
+// instruction rate of the gather (one 4-byte load per lane per im2col element), not by load latency, so deeper
+// k-tiles (NSUB 2/4 => 70 KB LDS => 2 workgroups/CU) LOSE 5-15 % against NSUB=1 with 6-8 resident workgroups.
+#ifndef SG_NSUB
+#define SG_NSUB 1
+#endif
 template <int KS> struct CfgFor {
-  using C128 = TileCfg<128, 128, 2, (KS == 7 ? 1 : 2)>;
-  using C64 = TileCfg<64, 64, 2, (KS == 7 ? 2 : 4)>;
-  using C32 = TileCfg<32, 128, 1, 2>;
+  using C128 = TileCfg<128, 128, 2, SG_NSUB>;
+  using C64 = TileCfg<64, 64, 2, SG_NSUB>;
+  using C32 = TileCfg<32, 128, 1, SG_NSUB>;
 };
 using Cfg128 = CfgFor<3>::C128;      // dense layers / wgrad use the KS-independent depths
 using Cfg64 = CfgFor<3>::C64;

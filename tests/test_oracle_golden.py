@@ -202,3 +202,34 @@ def test_full_step_vs_reference(golden):
             for k, (s, a) in zip(keys, st):
                 got = sd[k].double().abs().sum().item()
                 assert abs(got - a) <= 2e-3 * max(1.0, a), (it, mname, k, got, a)
+
+
+# ------------------------------------------------------------------------------------------
+# the plain-C index oracle (oracle/sg_index_oracle.c) against the same reference goldens
+# ------------------------------------------------------------------------------------------
+from oracle import c_oracle as CO  # noqa: E402
+
+
+@pytest.mark.parametrize('case', ['small', 'small_sum', 'full', 'dense', 'one'])
+def test_c_oracle_pool_is_bit_exact(golden, case):
+    g = golden('gconv_' + case)
+    Din, A, H, Dout, On, Tn, avg = [int(v) for v in g['cfg']]
+    pooled = CO.pool_triples(T(g['new_t']), T(g['edges']), On, H, Dout, avg)
+    assert torch.equal(pooled, T(g['pooled']))
+
+
+@pytest.mark.parametrize('case', ['demo_16', 'demo_64', 'i64_m32', 'f32_m16', 'f32_m5_avg', 'edge'])
+def test_c_oracle_layout(golden, case):
+    g = golden('layout_' + case)
+    H = int(g['H'])
+    W = int(g['W']) if 'W' in g.files else H
+    pooling = 'avg' if ('avg' in g.files and int(g['avg'])) else 'sum'
+    out = CO.masks_to_layout(T(g['vecs']), T(g['boxes']), T(g['masks']), T(g['obj_to_img']), H, W, pooling)
+    close(out, g['out'], 1e-5, 'layout (C)')
+
+
+@pytest.mark.parametrize('case', ['sorted_8', 'perm_8', 'perm_32'])
+def test_c_oracle_crop(golden, case):
+    g = golden('crop_' + case)
+    out = CO.crop_bbox_batch(T(g['feats']), T(g['boxes']), T(g['idx']), int(g['HH']))
+    close(out, g['out'], 1e-5, 'crop (C)')
