@@ -566,6 +566,10 @@ def _grad_snapshots(ref, tr):
 def _compare_grads(snaps, tag):
     for n, gr in snaps['ref'].items():
         gh = snaps['hip'][n]
+        fa = torch.cat([a.reshape(-1).double() for a in gh])
+        fb = torch.cat([(torch.zeros_like(a) if b is None else b).reshape(-1).double() for a, b in zip(gh, gr)])
+        cos = float(fa @ fb / (fa.norm() * fb.norm() + 1e-30))
+        assert cos > 0.9999, '%s %s: flat gradient cosine %.6f' % (tag, n, cos)
         gmax = max(float(x.abs().max()) for x in gr if x is not None)
         for i, (a, b) in enumerate(zip(gh, gr)):
             b = torch.zeros_like(a) if b is None else b
@@ -573,7 +577,7 @@ def _compare_grads(snaps, tag):
             # Tolerance: every single op is checked to ~1e-5 above; through the whole network a handful of ReLU /
             # LeakyReLU units whose pre-activation is within round-off of 0 take the other branch, which changes
             # individual gradient entries at the 1e-3 level (any two fp32 summation orders differ like this).
-            lim = 1e-2 * float(b.abs().max()) + 1e-4 * gmax + 1e-9
+            lim = 3e-2 * float(b.abs().max()) + 1e-4 * gmax + 1e-9
             assert err <= lim, '%s %s param %d: grad err %.3e > %.3e (|g|max %.3e, global %.3e)' % (
                 tag, n, i, err, lim, float(b.abs().max()), gmax)
 
