@@ -57,10 +57,11 @@ typedef struct sgConvDesc {
   int32_t x2_broadcast; /* 1: x2 is [N, C2] and is broadcast over H x W (the one-hot class map of discriminators.py:107-110) */
 } sgConvDesc;
 
-size_t sg_conv2d_ws_bytes(const sgConvDesc* d, int kind /*0 fwd, 1 dgrad, 2 wgrad*/);
+/* scratch the caller must provide (kind 0: conv / convT forward, 1: conv / convT dgrad, 2: conv / convT wgrad) */
+size_t sg_conv2d_ws_bytes(const sgConvDesc* d, int kind);
 /* y[N,Cout,OH,OW] = act(conv(x) + bias) ; w [Cout, C1+C2, KS, KS] */
 int sg_conv2d_fwd(const sgConvDesc* d, const float* x1, const float* x2, const float* w, const float* bias,
-                  float* y, int act, float slope, sgStream stream);
+                  float* y, int act, float slope, void* ws, size_t ws_bytes, sgStream stream);
 /* gx[N, c_end-c_begin, Hg, Wg]: gradient w.r.t. input channels [c_begin, c_end) of the *padded/upsampled*
  * logical input: Hg = H*upsample + (pad_reflect ? 2*pad : 0).  Fold with sg_pad_upsample_bwd. */
 int sg_conv2d_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, int c_begin, int c_end,
@@ -71,7 +72,8 @@ int sg_conv2d_wgrad(const sgConvDesc* d, const float* gy, const float* x1, const
 /* nn.ConvTranspose2d(k3,s2,p1,op1) : w [Cin, Cout, KS, KS]; desc.H,W = input size, OH,OW = output size */
 int sg_convT2d_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y,
                    void* ws, size_t ws_bytes, sgStream stream);
-int sg_convT2d_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, sgStream stream);
+int sg_convT2d_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, void* ws, size_t ws_bytes,
+                     sgStream stream);
 int sg_convT2d_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, float* gb,
                      void* ws, size_t ws_bytes, sgStream stream);
 /* fold a dgrad taken w.r.t. the reflect-padded and/or x2-upsampled logical input back onto the stored

@@ -31,6 +31,12 @@ struct TileCfg {
   static constexpr int LDA = BM + 4, LDB = BN + 4;
 };
 
+// LDS tile layout: [x][k] with k contiguous, row pitch LDK = 16 + 4 floats (80 B).  One ds_read_b128 then feeds FOUR
+// MFMA k-steps of a 32x32 fragment row and the pitch makes both the b128 fragment reads (16-lane groups hit 16
+// distinct 4-bank slots) and the b128/b32 stores conflict-free.  MFMA k-step s pairs tile column s (lanes 0-31) with
+// column s+8 (lanes 32-63): any pairing is legal as long as A and B use the same one.
+constexpr int LDK = BK + 4;
+
 // ------------------------------------------------------------------------------------------------
 // Operand loaders.  Each keeps its per-thread staging registers; load() issues the global reads for
 // the k-tile [k0, k0+BK) (zero-filled outside [.., kend) and outside the matrix), store() writes them
@@ -52,6 +58,7 @@ struct LoadKContig {
   struct Stage { float r[PASSES * 4]; unsigned ok; };
   int x0_, xr_, kq_;
   __device__ __forceinline__ void init(int x0, int tid, int*) { x0_ = x0; xr_ = tid >> 2; kq_ = (tid & 3) * 4; }
+  __device__ __forceinline__ void prefetch(Stage&, int) const {}
   __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
     st.ok = 0;
 #pragma unroll
@@ -76,17 +83,39 @@ struct LoadKContig {
     }
   }
   __device__ __forceinline__ void store(const Stage& st, float* T) const {
-    constexpr int LD = BX + 4;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int xl = xr_ + p * 64;
       if (xl < BX) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) T[(kq_ + i) * LD + xl] = ((st.ok >> (p * 4 + i)) & 1u) ? st.r[p * 4 + i] : 0.f;
+        float4 v;
+        v.x = ((st.ok >> (p * 4 + 0)) & 1u) ? st.r[p * 4 + 0] : 0.f;
+        v.y = ((st.ok >> (p * 4 + 1)) & 1u) ? st.r[p * 4 + 1] : 0.f;
+        v.z = ((st.ok >> (p * 4 + 2)) & 1u) ? st.r[p * 4 + 2] : 0.f;
+        v.w = ((st.ok >> (p * 4 + 3)) & 1u) ? st.r[p * 4 + 3] : 0.f;
+        *reinterpret_cast<float4*>(T + xl * LDK + kq_) = v;
       }
     }
   }
 };
+
+// store ROWS consecutive k values of tile row xl starting at column kr (kr % ROWS == 0) as 16/8-byte LDS writes
+template <int ROWS>
+__device__ __forceinline__ void store_krun(float* T, int xl, int kr, const float (&r)[ROWS], unsigned ok) {
+  float v[ROWS];
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) v[i] = ((ok >> i) & 1u) ? r[i] : 0.f;
+  float* dst = T + xl * LDK + kr;
+  if (ROWS % 4 == 0) {
+#pragma unroll
+    for (int i = 0; i < ROWS; i += 4) *reinterpret_cast<float4*>(dst + i) = make_float4(v[i], v[i + 1], v[i + 2], v[i + 3]);
+  } else if (ROWS % 2 == 0) {
+#pragma unroll
+    for (int i = 0; i < ROWS; i += 2) *reinterpret_cast<float2*>(dst + i) = make_float2(v[i], v[i + 1]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) dst[i] = v[i];
+  }
+}
 
 // the M/N index contiguous in memory: elem(x, k) = base[k*ld + x]
 template <int BX>
@@ -97,6 +126,7 @@ struct LoadXContig {
   struct Stage { float r[ROWS]; unsigned ok; };
   int x_, xl_, kr_;
   __device__ __forceinline__ void init(int x0, int tid, int*) { xl_ = tid % BX; x_ = x0 + xl_; kr_ = (tid / BX) * ROWS; }
+  __device__ __forceinline__ void prefetch(Stage&, int) const {}
   __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
     st.ok = 0;
 #pragma unroll
@@ -107,11 +137,7 @@ struct LoadXContig {
       st.ok |= ok ? (1u << i) : 0u;
     }
   }
-  __device__ __forceinline__ void store(const Stage& st, float* T) const {
-    constexpr int LD = BX + 4;
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) T[(kr_ + i) * LD + xl_] = ((st.ok >> i) & 1u) ? st.r[i] : 0.f;
-  }
+  __device__ __forceinline__ void store(const Stage& st, float* T) const { store_krun<ROWS>(T, xl_, kr_, st.r, st.ok); }
 };
 
 // geometry of a gathered (im2col-style) operand
@@ -148,26 +174,48 @@ __device__ __forceinline__ int tap_offset(const Gather& g, int ah, int aw, int k
 }
 
 // B operand of conv fwd / dgrad: k = (c, kh, kw), n = (img, ph, pw).  One pixel per thread, ROWS consecutive k.
-// All geometry (stride, zero/reflect padding, x2 upsample, transposed-conv divisibility) is resolved ONCE per
-// workgroup into an LDS table tap[r][pixel] of plane offsets; the k-loop is then: scalar (c, r) split of k,
-// one ds_read of the tap, one add, one global load.
-template <int BN, int KS, int MODE>
+// Everything that does not depend on the loop is precomputed so that one gathered element costs ~6 instructions:
+//   * geometry (stride, zero/reflect padding, x2 upsample, transposed-conv divisibility, pixel tail) is resolved
+//     ONCE per workgroup into an LDS table tap[t][pixel] of plane offsets (-1 = contributes zero; row KS2 = all -1)
+//   * the k -> (channel offset, tap row, source) split is a device table ktab[k] built once per launch
+//     (build_ktab_kernel) and fetched with scalar loads, one k-tile ahead
+// (the first version recomputed the split with ~30 dependent SALU/VALU ops per element: the load phase of a
+//  64x64 tile took ~1000 cycles per k-tile against 512 cycles of MFMA work).
+struct KEntry { unsigned choff; unsigned tapsel; };     // channel-plane offset ; tap row | second-source << 8
+
+__global__ void build_ktab_kernel(KEntry* tab, int K, int Kpad, int KS2, int C1, int C2, unsigned shw, int bcast2) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Kpad) return;
+  KEntry e;
+  if (k < K) {
+    const int c = k / KS2, t = k - c * KS2;
+    const bool second = C2 > 0 && c >= C1;
+    const unsigned cc = (unsigned)(second ? c - C1 : c);
+    e.choff = (second && bcast2) ? cc : cc * shw;
+    e.tapsel = (unsigned)t | (second ? 256u : 0u);
+  } else {
+    e.choff = 0u; e.tapsel = (unsigned)KS2;
+  }
+  tab[k] = e;
+}
+
+template <int BN, int KS, int MODE, bool TWO>
 struct LoadGatherKN {
-  Gather g; int Npix;
+  Gather g; int Npix; const KEntry* ktab;
   static constexpr int KS2 = KS * KS;
-  static constexpr int LDS_INTS = KS2 * BN;
+  static constexpr int LDS_INTS = (KS2 + 1) * BN;
   static constexpr int ROWS = BN * BK / 256;
-  struct Stage { float r[ROWS]; unsigned ok; };
+  struct Stage { float r[ROWS]; unsigned ok; KEntry e[ROWS]; };
   unsigned img1_, img2_, img2b_;
-  int nl_, kr_, ok_;
+  int nl_, kr_;
   const int* tab_;
   __device__ __forceinline__ void init(int n0, int tid, int* tab) {
     nl_ = tid % BN;
     const int grp = tid / BN;
-    kr_ = __builtin_amdgcn_readfirstlane(grp * ROWS);          // wave-uniform => (c, r) live in SGPRs
+    kr_ = __builtin_amdgcn_readfirstlane(grp * ROWS);          // wave-uniform => ktab entries live in SGPRs
     const int n = n0 + nl_;
-    ok_ = n < Npix;
-    const int nn = ok_ ? n : 0;
+    const bool okn = n < Npix;
+    const int nn = okn ? n : 0;
     const int phw = g.PH * g.PW;
     const int img = nn / phw;
     const int pix = nn - img * phw;
@@ -177,55 +225,39 @@ struct LoadGatherKN {
     else { ah = ph + g.pad; aw = pw + g.pad; }
     const unsigned shw = (unsigned)(g.SH * g.SW);
     img1_ = (unsigned)img * (unsigned)g.C1 * shw;
-    img2_ = (unsigned)img * (unsigned)g.C2 * shw;
-    img2b_ = (unsigned)img * (unsigned)g.C2;
+    img2_ = g.bcast2 ? (unsigned)img * (unsigned)g.C2 : (unsigned)img * (unsigned)g.C2 * shw;
     constexpr int G = 256 / BN;
-    for (int t = grp; t < KS2; t += G) {
+    for (int t = grp; t <= KS2; t += G) {
       const int kh = t / KS, kw = t - kh * KS;
-      tab[t * BN + nl_] = tap_offset<MODE>(g, ah, aw, kh, kw);
+      tab[t * BN + nl_] = (okn && t < KS2) ? tap_offset<MODE>(g, ah, aw, kh, kw) : -1;
     }
-    tab_ = tab;
+    tab_ = tab + nl_;
+  }
+  // scalar fetch of the k-split entries of tile k0 (issued one tile ahead of load(), so SMEM latency is hidden)
+  __device__ __forceinline__ void prefetch(Stage& st, int k0) const {
+    const KEntry* e = ktab + (k0 + kr_);          // uniform address => s_load
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) st.e[i] = e[i];
   }
   __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
-    const int k = k0 + kr_;
-    const int c0 = k / KS2;
-    const int t0 = k - c0 * KS2;
-    const unsigned shw = (unsigned)(g.SH * g.SW);
-    // 1) all tap lookups first (independent LDS reads, one round trip) ...
-    int tp[ROWS];
-    {
-      int t = t0;
-#pragma unroll
-      for (int i = 0; i < ROWS; ++i) {
-        tp[i] = tab_[t * BN + nl_];
-        ++t;
-        t = (t == KS2) ? 0 : t;
-      }
-    }
-    // 2) ... then the global loads, back to back
     st.ok = 0;
-    int c = c0, t = t0;
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
-      const bool ok = ok_ && (k + i < kend) && tp[i] >= 0;
-      const bool second = g.C2 > 0 && c >= g.C1;                          // scalar; src2 may be null when C2==0
-      const float* base = second ? g.src2 : g.src1;
-      const unsigned cc = (unsigned)(second ? c - g.C1 : c);
-      unsigned off = (second ? img2_ : img1_) + cc * shw + (unsigned)tp[i];
-      off = (second && g.bcast2) ? img2b_ + cc : off;
-      st.r[i] = base[ok ? off : 0u];
+      const unsigned choff = st.e[i].choff, ts = st.e[i].tapsel;
+      const int tp = tab_[(ts & 255u) * BN];
+      const bool ok = tp >= 0;
+      if (TWO) {
+        const bool second = (ts & 256u) != 0u;                  // scalar
+        const float* base = second ? g.src2 : g.src1;
+        const unsigned off = (second ? img2_ : img1_) + choff + ((second && g.bcast2) ? 0u : (unsigned)tp);
+        st.r[i] = base[ok ? off : 0u];
+      } else {
+        st.r[i] = g.src1[ok ? img1_ + choff + (unsigned)tp : 0u];
+      }
       st.ok |= ok ? (1u << i) : 0u;
-      ++t;
-      const bool wrap = t == KS2;
-      t = wrap ? 0 : t;
-      c += wrap ? 1 : 0;
     }
   }
-  __device__ __forceinline__ void store(const Stage& st, float* T) const {
-    constexpr int LD = BN + 4;
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) T[(kr_ + i) * LD + nl_] = ((st.ok >> i) & 1u) ? st.r[i] : 0.f;
-  }
+  __device__ __forceinline__ void store(const Stage& st, float* T) const { store_krun<ROWS>(T, nl_, kr_, st.r, st.ok); }
 };
 
 // A operand of wgrad: elem(m, k) = base[(img*Mtot + m)*PQ + pix], k = img*PQ + pix.  Lanes run along k.
@@ -237,6 +269,7 @@ struct LoadPixK {
   struct Stage { float r[ROWS]; unsigned ok; };
   int m0_, mr_, kl_;
   __device__ __forceinline__ void init(int m0, int tid, int*) { m0_ = m0; kl_ = tid & 15; mr_ = tid >> 4; }
+  __device__ __forceinline__ void prefetch(Stage&, int) const {}
   __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
     const int k = k0 + kl_;
     const bool kok = k < kend;
@@ -253,9 +286,8 @@ struct LoadPixK {
     }
   }
   __device__ __forceinline__ void store(const Stage& st, float* T) const {
-    constexpr int LD = BM + 4;
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) T[kl_ * LD + mr_ + 16 * i] = ((st.ok >> i) & 1u) ? st.r[i] : 0.f;
+    for (int i = 0; i < ROWS; ++i) T[(mr_ + 16 * i) * LDK + kl_] = ((st.ok >> i) & 1u) ? st.r[i] : 0.f;
   }
 };
 
@@ -286,6 +318,7 @@ struct LoadGatherNK {
       khw_[j] = (kh << 8) | (rr - kh * KS) | (second ? (1 << 16) : 0);
     }
   }
+  __device__ __forceinline__ void prefetch(Stage&, int) const {}
   __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
     const int k = k0 + kl_;
     const bool kok = k < kend;
@@ -311,9 +344,8 @@ struct LoadGatherNK {
     }
   }
   __device__ __forceinline__ void store(const Stage& st, float* T) const {
-    constexpr int LD = BN + 4;
 #pragma unroll
-    for (int j = 0; j < COLS; ++j) T[kl_ * LD + nr_ + 16 * j] = ((st.ok >> j) & 1u) ? st.r[j] : 0.f;
+    for (int j = 0; j < COLS; ++j) T[(nr_ + 16 * j) * LDK + kl_] = ((st.ok >> j) & 1u) ? st.r[j] : 0.f;
   }
 };
 
@@ -375,8 +407,8 @@ template <class CFG, class AL, class BL, class EP>
 __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int kchunk) {
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, LDA = CFG::LDA, LDB = CFG::LDB;
   constexpr int NSUB = CFG::NSUB, BKT = CFG::BKT;
-  __shared__ float As[2][BKT * LDA];
-  __shared__ float Bs[2][BKT * LDB];
+  __shared__ __attribute__((aligned(16))) float As[2][NSUB * BM * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][NSUB * BN * LDK];
   __shared__ int tapA[AL::LDS_INTS > 0 ? AL::LDS_INTS : 1];
   __shared__ int tapB[BL::LDS_INTS > 0 ? BL::LDS_INTS : 1];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -409,9 +441,13 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   typename AL::Stage sa[NSUB];
   typename BL::Stage sb[NSUB];
 #pragma unroll
+  for (int u = 0; u < NSUB; ++u) { al.prefetch(sa[u], kbeg + u * BK); bl.prefetch(sb[u], kbeg + u * BK); }
+#pragma unroll
   for (int u = 0; u < NSUB; ++u) { al.load(sa[u], kbeg + u * BK, kend); bl.load(sb[u], kbeg + u * BK, kend); }
 #pragma unroll
-  for (int u = 0; u < NSUB; ++u) { al.store(sa[u], As[0] + u * BK * LDA); bl.store(sb[u], Bs[0] + u * BK * LDB); }
+  for (int u = 0; u < NSUB; ++u) { al.prefetch(sa[u], kbeg + BKT + u * BK); bl.prefetch(sb[u], kbeg + BKT + u * BK); }
+#pragma unroll
+  for (int u = 0; u < NSUB; ++u) { al.store(sa[u], As[0] + u * BM * LDK); bl.store(sb[u], Bs[0] + u * BN * LDK); }
   __syncthreads();
 
   const int lr = lane & 31, lk = lane >> 5;
@@ -421,49 +457,44 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     if (more) {
 #pragma unroll
       for (int u = 0; u < NSUB; ++u) { al.load(sa[u], k0 + BKT + u * BK, kend); bl.load(sb[u], k0 + BKT + u * BK, kend); }
+#pragma unroll
+      for (int u = 0; u < NSUB; ++u) { al.prefetch(sa[u], k0 + 2 * BKT + u * BK); bl.prefetch(sb[u], k0 + 2 * BKT + u * BK); }
     }
-    const float* A_ = As[buf] + lk * LDA + wm0 + lr;
-    const float* B_ = Bs[buf] + lk * LDB + wn0 + lr;
-    // MFMA phase in groups of >= 4 MFMAs; the LDS fragment reads of group g+1 are pinned IN FRONT of the MFMAs of
-    // group g (sched_group_barrier), so an LDS round trip (~150-250 cycles) is covered by >= 256 cycles of matrix
-    // pipe work instead of stalling every MFMA pair.
-    constexpr int G = (TM * TN >= 4) ? 1 : (TM * TN == 2 ? 2 : 4);      // k-steps (of 2) per group
-    constexpr int NG = BKT / (2 * G);
-    float a[2][G][TM], b[2][G][TN];
+    // fragment reads: one ds_read_b128 = four k-steps of a 32-row fragment; all reads of a sub-tile are issued up
+    // front, the second half (k-steps 4-7) lands while the first 4*TM*TN MFMAs issue
 #pragma unroll
-    for (int q = 0; q < G; ++q) {
+    for (int u = 0; u < NSUB; ++u) {
+      const float* A_ = As[buf] + u * BM * LDK + (wm0 + lr) * LDK + lk * 8;
+      const float* B_ = Bs[buf] + u * BN * LDK + (wn0 + lr) * LDK + lk * 8;
+      float4 a[TM][2], b[TN][2];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[0][q][i] = A_[(2 * q) * LDA + i * 32];
+      for (int h = 0; h < 2; ++h) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[0][q][j] = B_[(2 * q) * LDB + j * 32];
-    }
+        for (int i = 0; i < TM; ++i) a[i][h] = *reinterpret_cast<const float4*>(A_ + i * 32 * LDK + h * 4);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      const int cur = g & 1, nxt = cur ^ 1;
-      if (g + 1 < NG) {
-#pragma unroll
-        for (int q = 0; q < G; ++q) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i) a[nxt][q][i] = A_[(2 * ((g + 1) * G + q)) * LDA + i * 32];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) b[nxt][q][j] = B_[(2 * ((g + 1) * G + q)) * LDB + j * 32];
-        }
+        for (int j = 0; j < TN; ++j) b[j][h] = *reinterpret_cast<const float4*>(B_ + j * 32 * LDK + h * 4);
       }
 #pragma unroll
-      for (int q = 0; q < G; ++q)
+      for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int e = 0; e < 4; ++e) {
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][q][i], b[cur][q][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, G * (TM + TN), 0);     // DS reads of the next group first
-      __builtin_amdgcn_sched_group_barrier(0x008, G * TM * TN, 0);       // then this group's MFMAs
+          for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const float av = e == 0 ? a[i][h].x : (e == 1 ? a[i][h].y : (e == 2 ? a[i][h].z : a[i][h].w));
+              const float bv = e == 0 ? b[j][h].x : (e == 1 ? b[j][h].y : (e == 2 ? b[j][h].z : b[j][h].w));
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+      }
     }
     if (more) {
 #pragma unroll
       for (int u = 0; u < NSUB; ++u) {
-        al.store(sa[u], As[buf ^ 1] + u * BK * LDA);
-        bl.store(sb[u], Bs[buf ^ 1] + u * BK * LDB);
+        al.store(sa[u], As[buf ^ 1] + u * BM * LDK);
+        bl.store(sb[u], Bs[buf ^ 1] + u * BN * LDK);
       }
     }
     __syncthreads();
@@ -541,41 +572,57 @@ Gather make_gather(const float* s1, const float* s2, int C1, int C2, int SH, int
 }
 
 // ---- conv-shaped GEMM: K = (c, taps), N = pixels -------------------------------------------------
+template <class CFG, int BM, int BN, int KS, int MODE>
+int launch_ab(const float* A, int K, int M, bool vec, const Gather& g, int Npix, const KEntry* ktab, const EpNCHW& ep,
+              hipStream_t s) {
+  const bool two = g.C2 > 0;
+  if (two) {
+    LoadGatherKN<BN, KS, MODE, true> bl{g, Npix, ktab};
+    if (vec) return launch_cfg<CFG>(LoadKContig<BM, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+    return launch_cfg<CFG>(LoadKContig<BM, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+  }
+  LoadGatherKN<BN, KS, MODE, false> bl{g, Npix, ktab};
+  if (vec) return launch_cfg<CFG>(LoadKContig<BM, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+  return launch_cfg<CFG>(LoadKContig<BM, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+}
+
+inline size_t ktab_bytes(int K) { return (size_t)(sg_cdiv(K, 64) * 64 + 128) * sizeof(KEntry); }
+
 template <int KS, int MODE>
 int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* bias, float* out, int Mtot, int act,
-           float slope, double flops, hipStream_t s) {
+           float slope, double flops, void* ktab_ws, hipStream_t s) {
   const int Npix = NB * g.PH * g.PW;
+  KEntry* ktab = reinterpret_cast<KEntry*>(ktab_ws);
+  {
+    const int Kpad = sg_cdiv(K, 64) * 64 + 128;      // the k-loop prefetches entries up to two tiles past the end
+    hipLaunchKernelGGL(build_ktab_kernel, dim3(sg_cdiv(Kpad, 256)), dim3(256), 0, s, ktab, K, Kpad, KS * KS, g.C1, g.C2,
+                       (unsigned)(g.SH * g.SW), g.bcast2);
+  }
   EpNCHW ep{out, bias, g.PH * g.PW, Mtot, M, Npix, act, slope};
   const bool vec = (K % 4 == 0) && aligned16(A);
   const int tile = pick_tile(M, Npix);
   SgProfScope prof(sg_igemm_kind(MODE, KS, tile), s, flops, 0);
   switch (tile) {
     case 0: {
-      LoadGatherKN<128, KS, MODE> bl{g, Npix};
-      if (vec) return launch_cfg<typename CfgFor<KS>::C128>(LoadKContig<128, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
-      return launch_cfg<typename CfgFor<KS>::C128>(LoadKContig<128, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+      return launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, s);
     }
     case 1: {
-      LoadGatherKN<64, KS, MODE> bl{g, Npix};
-      if (vec) return launch_cfg<typename CfgFor<KS>::C64>(LoadKContig<64, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
-      return launch_cfg<typename CfgFor<KS>::C64>(LoadKContig<64, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+      return launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, s);
     }
     default: {
-      LoadGatherKN<128, KS, MODE> bl{g, Npix};
-      if (vec) return launch_cfg<typename CfgFor<KS>::C32>(LoadKContig<32, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
-      return launch_cfg<typename CfgFor<KS>::C32>(LoadKContig<32, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+      return launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, s);
     }
   }
 }
 
 template <int MODE>
 int run_kn_ks(int KS, const float* A, int M, int K, const Gather& g, int NB, const float* bias, float* out, int Mtot,
-              int act, float slope, double flops, hipStream_t s) {
+              int act, float slope, double flops, void* ktab_ws, hipStream_t s) {
   switch (KS) {
-    case 1: return run_kn<1, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, s);
-    case 3: return run_kn<3, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, s);
-    case 4: return run_kn<4, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, s);
-    case 7: return run_kn<7, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, s);
+    case 1: return run_kn<1, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, ktab_ws, s);
+    case 3: return run_kn<3, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, ktab_ws, s);
+    case 4: return run_kn<4, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, ktab_ws, s);
+    case 7: return run_kn<7, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, ktab_ws, s);
   }
   return -1;
 }
@@ -667,8 +714,10 @@ inline size_t wgrad_ws(int M, int Ncols, int Kpix) {
 extern "C" size_t sg_conv2d_ws_bytes(const sgConvDesc* d, int kind) {
   if (!d) return 0;
   const size_t wbytes = (size_t)d->Cout * (d->C1 + d->C2) * d->KS * d->KS * sizeof(float);
-  if (kind == 0) return wbytes;                    // convT fwd: transposed weights
-  if (kind == 1) return wbytes;                    // conv dgrad: transposed weights
+  const int Kmax = (d->Cout > d->C1 + d->C2 ? d->Cout : d->C1 + d->C2) * d->KS * d->KS;
+  const size_t kt = ktab_bytes(Kmax);
+  if (kind == 0) return wbytes + kt;               // fwd: k-split table (+ transposed weights for convT)
+  if (kind == 1) return wbytes + kt;               // dgrad: transposed weights + k-split table
   const int M = d->Cout > (d->C1 + d->C2) ? d->Cout : (d->C1 + d->C2);
   const int Kp = d->N * (d->OH * d->OW > d->H * d->W ? d->OH * d->OW : d->H * d->W);
   size_t a = wgrad_ws(d->Cout, (d->C1 + d->C2) * d->KS * d->KS, d->N * d->OH * d->OW);
@@ -678,16 +727,17 @@ extern "C" size_t sg_conv2d_ws_bytes(const sgConvDesc* d, int kind) {
 }
 
 extern "C" int sg_conv2d_fwd(const sgConvDesc* d, const float* x1, const float* x2, const float* w, const float* bias,
-                             float* y, int act, float slope, sgStream stream) {
+                             float* y, int act, float slope, void* ws, size_t ws_bytes, sgStream stream) {
   if (check_desc(d, "sg_conv2d_fwd")) return -1;
-  SG_ARG_CHECK(x1 && w && y, "sg_conv2d_fwd: null pointer");
+  SG_ARG_CHECK(x1 && w && y && ws, "sg_conv2d_fwd: null pointer");
+  SG_ARG_CHECK(ws_bytes >= ktab_bytes((d->C1 + d->C2) * d->KS * d->KS), "sg_conv2d_fwd: workspace too small");
   SG_ARG_CHECK(d->C2 == 0 || x2, "sg_conv2d_fwd: C2>0 but x2 null");
   hipStream_t s = (hipStream_t)stream;
   const int Cin = d->C1 + d->C2, K = Cin * d->KS * d->KS;
   Gather g = make_gather(x1, x2, d->C1, d->C2, d->H, d->W, d->upsample, d->OH, d->OW, d->stride, d->pad, d->pad_reflect);
   g.bcast2 = d->x2_broadcast;
   const double flops = 2.0 * d->Cout * K * (double)d->N * d->OH * d->OW;
-  int rc = run_kn_ks<0>(d->KS, w, d->Cout, K, g, d->N, bias, y, d->Cout, act, slope, flops, s);
+  int rc = run_kn_ks<0>(d->KS, w, d->Cout, K, g, d->N, bias, y, d->Cout, act, slope, flops, ws, s);
   SG_LAUNCH_CHECK("sg_conv2d_fwd");
   return rc;
 }
@@ -698,7 +748,8 @@ extern "C" int sg_conv2d_dgrad(const sgConvDesc* d, const float* gy, const float
   const int Cin = d->C1 + d->C2, R = d->KS * d->KS;
   SG_ARG_CHECK(gy && w && gx && ws, "sg_conv2d_dgrad: null pointer");
   SG_ARG_CHECK(0 <= c_begin && c_begin < c_end && c_end <= Cin, "sg_conv2d_dgrad: bad channel range [%d,%d)", c_begin, c_end);
-  SG_ARG_CHECK(ws_bytes >= (size_t)d->Cout * Cin * R * sizeof(float), "sg_conv2d_dgrad: workspace too small");
+  SG_ARG_CHECK(ws_bytes >= (size_t)d->Cout * Cin * R * sizeof(float) + ktab_bytes(d->Cout * R),
+               "sg_conv2d_dgrad: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   float* wt = reinterpret_cast<float*>(ws);      // [Cin][Cout][R]
   const size_t nw = (size_t)d->Cout * Cin * R;
@@ -711,7 +762,8 @@ extern "C" int sg_conv2d_dgrad(const sgConvDesc* d, const float* gy, const float
   const int M = c_end - c_begin, K = d->Cout * R;
   // algorithmic flops of a dgrad = those of the forward conv restricted to the requested input channels
   const double flops = 2.0 * M * (double)d->Cout * R * d->N * d->OH * d->OW;
-  int rc = run_kn_ks<1>(d->KS, wt + (size_t)c_begin * K, M, K, g, d->N, nullptr, gx, M, SG_ACT_NONE, 0.f, flops, s);
+  int rc = run_kn_ks<1>(d->KS, wt + (size_t)c_begin * K, M, K, g, d->N, nullptr, gx, M, SG_ACT_NONE, 0.f, flops,
+                        wt + nw, s);
   SG_LAUNCH_CHECK("sg_conv2d_dgrad");
   return rc;
 }
@@ -738,27 +790,30 @@ extern "C" int sg_convT2d_fwd(const sgConvDesc* d, const float* x, const float* 
   SG_ARG_CHECK(x && w && y && ws, "sg_convT2d_fwd: null pointer");
   const int Cin = d->C1, R = d->KS * d->KS;
   SG_ARG_CHECK(d->C2 == 0 && d->upsample == 1 && !d->pad_reflect, "sg_convT2d_fwd: unsupported desc");
-  SG_ARG_CHECK(ws_bytes >= (size_t)d->Cout * Cin * R * sizeof(float), "sg_convT2d_fwd: workspace too small");
+  SG_ARG_CHECK(ws_bytes >= (size_t)d->Cout * Cin * R * sizeof(float) + ktab_bytes(Cin * R),
+               "sg_convT2d_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   float* wt = reinterpret_cast<float*>(ws);      // [Cout][Cin][R]
   const size_t nw = (size_t)d->Cout * Cin * R;
   hipLaunchKernelGGL(permute_w_kernel, dim3(sg_cdiv(nw, 256)), dim3(256), 0, s, w, wt, Cin, d->Cout, R);
   Gather g = make_gather(x, nullptr, Cin, 0, d->H, d->W, 1, d->OH, d->OW, d->stride, d->pad, 0);
   const double flops = 2.0 * d->Cout * Cin * R * (double)d->N * d->H * d->W;
-  int rc = run_kn_ks<1>(d->KS, wt, d->Cout, Cin * R, g, d->N, bias, y, d->Cout, SG_ACT_NONE, 0.f, flops, s);
+  int rc = run_kn_ks<1>(d->KS, wt, d->Cout, Cin * R, g, d->N, bias, y, d->Cout, SG_ACT_NONE, 0.f, flops, wt + nw, s);
   SG_LAUNCH_CHECK("sg_convT2d_fwd");
   return rc;
 }
 
 // gx[n,ci,ih,iw] = sum_{co,kh,kw} w[ci,co,kh,kw] gy[n,co,ih*s-p+kh,iw*s-p+kw]   (a plain strided conv over gy)
-extern "C" int sg_convT2d_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, sgStream stream) {
+extern "C" int sg_convT2d_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, void* ws, size_t ws_bytes,
+                                sgStream stream) {
   if (check_desc(d, "sg_convT2d_dgrad")) return -1;
-  SG_ARG_CHECK(gy && w && gx, "sg_convT2d_dgrad: null pointer");
+  SG_ARG_CHECK(gy && w && gx && ws, "sg_convT2d_dgrad: null pointer");
+  SG_ARG_CHECK(ws_bytes >= ktab_bytes(d->Cout * d->KS * d->KS), "sg_convT2d_dgrad: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const int R = d->KS * d->KS;
   Gather g = make_gather(gy, nullptr, d->Cout, 0, d->OH, d->OW, 1, d->H, d->W, d->stride, d->pad, 0);
   const double flops = 2.0 * d->Cout * d->C1 * R * (double)d->N * d->H * d->W;
-  int rc = run_kn_ks<0>(d->KS, w, d->C1, d->Cout * R, g, d->N, nullptr, gx, d->C1, SG_ACT_NONE, 0.f, flops, s);
+  int rc = run_kn_ks<0>(d->KS, w, d->C1, d->Cout * R, g, d->N, nullptr, gx, d->C1, SG_ACT_NONE, 0.f, flops, ws, s);
   SG_LAUNCH_CHECK("sg_convT2d_dgrad");
   return rc;
 }

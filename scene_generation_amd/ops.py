@@ -98,7 +98,10 @@ class Conv2dFn(Function):
         bcast = 1 if (x2 is not None and x2.dim() == 2) else 0      # [N, C2] broadcast over H x W
         d = _conv_desc(N, C1, C2, H, W, Cout, KS, stride, pad, reflect, upsample, OH, OW, 0, bcast)
         y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=x1.device)
-        _call('sg_conv2d_fwd', ctypes.byref(d), _p(x1), _p(x2), _p(weight), _p(bias), _p(y), act, slope, _stream())
+        wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 0)
+        ws = workspace(wsb, x1.device)
+        _call('sg_conv2d_fwd', ctypes.byref(d), _p(x1), _p(x2), _p(weight), _p(bias), _p(y), act, slope, _p(ws), wsb,
+              _stream())
         ctx.desc = d
         ctx.cfg = (act, slope, bias is not None)
         ctx.save_for_backward(x1, x2, weight, y if act != ACT_NONE else None)
@@ -191,7 +194,9 @@ class ConvTranspose2dFn(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            _call('sg_convT2d_dgrad', ctypes.byref(d), _p(gy), _p(weight), _p(gx), s)
+            wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 1)
+            ws = workspace(wsb, gy.device)
+            _call('sg_convT2d_dgrad', ctypes.byref(d), _p(gy), _p(weight), _p(gx), _p(ws), wsb, s)
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 2)

@@ -36,7 +36,7 @@ def test_argument_errors_are_reported_not_thrown():
     rc = lib.sg_linear_fwd(None, None, None, None, 4, 4, 4, 0, 0.0, None)
     assert rc < 0 and b'sg_linear_fwd' in lib.sg_last_error_string()
     d = _hip.sgConvDesc(1, 3, 0, 8, 8, 4, 5, 1, 0, 0, 1, 4, 4, 0, 0)      # kernel size 5 unsupported
-    rc = lib.sg_conv2d_fwd(ctypes.byref(d), ctypes.c_void_p(8), None, ctypes.c_void_p(8), None, ctypes.c_void_p(8), 0, 0.0, None)
+    rc = lib.sg_conv2d_fwd(ctypes.byref(d), ctypes.c_void_p(8), None, ctypes.c_void_p(8), None, ctypes.c_void_p(8), 0, 0.0, ctypes.c_void_p(8), 1 << 20, None)
     assert rc < 0 and b'kernel size' in lib.sg_last_error_string()
 
 
