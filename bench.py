@@ -90,8 +90,8 @@ def main():
     # two pre-staged batches per rank (different data per rank: weak scaling), resident in HBM
     batches = [batch_to(make_batch(N=B, min_objs=3, max_objs=8, size=S, seed=1000 * rank + i), dev) for i in range(2)]
     hosts = [b.objs.tolist() for b in batches]
-    random.seed(rank)
-    torch.manual_seed(100 + rank)
+    random.seed(0)                                # the use_gt coin (train.py:195) must agree on all ranks: it decides
+    torch.manual_seed(100 + rank)                 # which parameters receive gradients (and hence Adam updates)
 
     def one_step(i):
         tr.model.objs_host = hosts[i % 2]

@@ -95,7 +95,7 @@ def masks_to_layout(vecs, boxes, masks, obj_to_img, H, W=None, pooling='sum', te
     if test_mode:
         raise NotImplementedError('test-mode compositing is SURVEY 8f rank 1 (next)')
     gx, gy = _box_grid(boxes, H, W)
-    S = bilinear_sample(masks.float().view(O, 1, M, M), gx, gy)[:, 0]      # (O,H,W)
+    S = bilinear_sample(masks.to(vecs.dtype).view(O, 1, M, M), gx, gy)[:, 0]      # (O,H,W); masks.float() in fp32
     N, starts, ends, counts = _segments(obj_to_img)
     out = vecs.new_zeros(N, D, H, W)
     for n in range(N):
@@ -761,7 +761,7 @@ class Trainer:
         mfake = self.mask_discriminator(masks_pred.unsqueeze(1), one_hot)
         L.add_loss(self.criterionGAN(mfake, True), 'g_gan_mask_obj_loss', a.d_mask_weight)
         if a.d_mask_features_weight > 0:
-            mreal = self.mask_discriminator(masks.float().unsqueeze(1), one_hot)
+            mreal = self.mask_discriminator(masks.to(masks_pred.dtype).unsqueeze(1), one_hot)
             L.add_loss(features_loss(mfake, mreal), 'g_mask_features_loss', a.d_mask_features_weight)
         pred_real = self.netD(torch.cat((layout, imgs), dim=1))
         pred_fake = self.netD(torch.cat((layout.detach(), imgs_pred), dim=1))
@@ -788,7 +788,7 @@ class Trainer:
         L = self.d_mask_losses = LossManager()
         one_hot = self._one_hot(objs, masks_pred)
         sf = self.mask_discriminator(masks_pred.unsqueeze(1), one_hot)
-        sr = self.mask_discriminator(masks.float().unsqueeze(1), one_hot)
+        sr = self.mask_discriminator(masks.to(masks_pred.dtype).unsqueeze(1), one_hot)
         L.add_loss(self.criterionGAN(sf, False), 'fake_loss', 0.5)
         L.add_loss(self.criterionGAN(sr, True), 'real_loss', 0.5)
         self.optimizer_d_mask.zero_grad()

@@ -48,15 +48,33 @@ class FlatParams:
 
 
 class FusedAdam:
-    """torch.optim.Adam(params, lr, betas, eps, weight_decay=0, amsgrad=False) semantics on flat buffers."""
+    """torch.optim.Adam(params, lr, betas, eps, weight_decay=0, amsgrad=False) semantics on flat buffers.
+
+    Like torch, a parameter that received NO gradient since the last zero_grad() is skipped entirely (no moment
+    decay, no update, its step count does not advance) -- e.g. ``box_net`` in iterations with ``use_gt == False``
+    (trainer.py:210-216).  "Received a gradient" is tracked with post-accumulate-grad hooks; step() launches the fused
+    kernel once per maximal run of adjacent active parameters that share a step count (normally one launch)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         self.fp = FlatParams(params)
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.exp_avg = torch.zeros_like(self.fp.flat)
         self.exp_avg_sq = torch.zeros_like(self.fp.flat)
-        self.step_count = 0
+        n = len(self.fp.params)
+        self.steps = [0] * n
+        self._touched = [False] * n
         self.pre_step_hooks = []          # e.g. GradReducer.wait
+        for i, p in enumerate(self.fp.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(param):
+            self._touched[i] = True
+        return hook
+
+    @property
+    def step_count(self):
+        return max(self.steps) if self.steps else 0
 
     @property
     def param_groups(self):
@@ -66,24 +84,42 @@ class FusedAdam:
     def zero_grad(self, set_to_none=False):
         ops.fill_(self.fp.grad, 0.0)
         self.fp.attach_grads()
+        self._touched = [False] * len(self.fp.params)
+
+    def mark_all_touched(self):
+        """for callers that write gradients directly into the flat buffer (tests, custom reducers)"""
+        self._touched = [True] * len(self.fp.params)
 
     def step(self):
         for h in self.pre_step_hooks:
             h()
         self.fp.attach_grads()
-        self.step_count += 1
-        ops.adam_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0],
-                      self.betas[1], self.eps, self.step_count)
+        fp = self.fp
+        i, n = 0, len(fp.params)
+        while i < n:
+            if not self._touched[i]:
+                i += 1
+                continue
+            j, st = i, self.steps[i]
+            while j + 1 < n and self._touched[j + 1] and self.steps[j + 1] == st:
+                j += 1
+            lo, hi = fp.offsets[i], fp.offsets[j] + fp.params[j].numel()
+            ops.adam_step(fp.flat[lo:hi], fp.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
+                          self.betas[0], self.betas[1], self.eps, st + 1)
+            for q in range(i, j + 1):
+                self.steps[q] = st + 1
+            i = j + 1
 
     # ---- torch.optim.Adam-compatible (de)serialisation ----
     def state_dict(self):
         state = {}
-        if self.step_count > 0:
-            for i, (p, o) in enumerate(zip(self.fp.params, self.fp.offsets)):
-                n = p.numel()
-                state[i] = {'step': torch.tensor(float(self.step_count)),
-                            'exp_avg': self.exp_avg[o:o + n].view(p.shape).clone(),
-                            'exp_avg_sq': self.exp_avg_sq[o:o + n].view(p.shape).clone()}
+        for i, (p, o) in enumerate(zip(self.fp.params, self.fp.offsets)):
+            if self.steps[i] == 0:
+                continue
+            n = p.numel()
+            state[i] = {'step': torch.tensor(float(self.steps[i])),
+                        'exp_avg': self.exp_avg[o:o + n].view(p.shape).clone(),
+                        'exp_avg_sq': self.exp_avg_sq[o:o + n].view(p.shape).clone()}
         group = dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=0, amsgrad=False, maximize=False,
                      foreach=None, capturable=False, differentiable=False, fused=None,
                      params=list(range(len(self.fp.params))))
@@ -92,15 +128,15 @@ class FusedAdam:
     def load_state_dict(self, sd):
         g = sd['param_groups'][0]
         self.lr, self.betas, self.eps = float(g['lr']), tuple(float(b) for b in g['betas']), float(g['eps'])
-        steps = set()
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(self.fp.params, self.fp.offsets)):
                 st = sd['state'].get(i)
-                if st is None:
-                    continue
                 n = p.numel()
+                if st is None:
+                    self.steps[i] = 0
+                    self.exp_avg[o:o + n].zero_()
+                    self.exp_avg_sq[o:o + n].zero_()
+                    continue
                 self.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
                 self.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
-                steps.add(int(float(st['step'])))
-        assert len(steps) <= 1, 'per-parameter step counts differ'
-        self.step_count = steps.pop() if steps else 0
+                self.steps[i] = int(float(st['step']))
