@@ -79,8 +79,9 @@ int sg_convT2d_wgrad(const sgConvDesc* d, const float* gy, const float* x, float
 /* fold a dgrad taken w.r.t. the reflect-padded and/or x2-upsampled logical input back onto the stored
  * input: gx[NC,H,W] = sum of gp[NC, H*up+2p, W*up+2p] over reflected / replicated positions */
 int sg_pad_upsample_bwd(const float* gp, float* gx, int NC, int H, int W, int pad, int upsample, sgStream stream);
-/* per-channel sum over (N, HW): bias gradients */
-int sg_channel_sum(const float* g, float* out, int N, int C, int HW, sgStream stream);
+/* per-channel sum over (N, HW): bias gradients.  ws (optional, sg_channel_sum_ws_bytes) enables the two-stage form */
+size_t sg_channel_sum_ws_bytes(int C);
+int sg_channel_sum(const float* g, float* out, int N, int C, int HW, void* ws, size_t ws_bytes, sgStream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense layers (nn.Linear inside build_mlp layers.py:215-231, generators.py:45, discriminators.py:23-27)

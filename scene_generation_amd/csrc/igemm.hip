@@ -352,8 +352,8 @@ struct LoadGatherNK {
 // ------------------------------------------------------------------------------------------------
 // Epilogues.  Accumulator register r of a 32x32 tile <-> row (r&3)+8*(r>>2)+4*(lane>>5), col lane&31.
 // ------------------------------------------------------------------------------------------------
-struct EpNCHW {     // out[img][m_off+m][pix], n = img*PHW + pix ; bias per row m
-  float* out; const float* bias; int PHW, Mtot, M, Npix, act; float slope;
+struct EpNCHW {     // out[z][img][m][pix], n = img*PHW + pix ; bias per row m (z = split-K slab, raw partials)
+  float* out; const float* bias; int PHW, Mtot, M, Npix, act; float slope; size_t zstride;
   template <int TM, int TN>
   __device__ __forceinline__ void store(f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int z) const {
 #pragma unroll
@@ -361,7 +361,7 @@ struct EpNCHW {     // out[img][m_off+m][pix], n = img*PHW + pix ; bias per row 
       const int n = nbase + j * 32 + (lane & 31);
       if (n >= Npix) continue;
       const int img = n / PHW, pix = n - img * PHW;
-      float* o = out + (size_t)img * Mtot * PHW + pix;
+      float* o = out + (size_t)z * zstride + (size_t)img * Mtot * PHW + pix;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -549,6 +549,17 @@ __global__ void slab_reduce_kernel(const float* ws, float* out, size_t n, int S)
   out[i] = v;
 }
 
+// split-K epilogue of the conv-shaped GEMMs: out[i] = act(sum_z ws[z][i] + bias[channel(i)])
+__global__ void slab_reduce_nchw_kernel(const float* ws, float* out, size_t n, int S, const float* bias, int PHW, int Mtot,
+                                        int act, float slope) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = 0.f;
+  for (int z = 0; z < S; ++z) v += ws[(size_t)z * n + i];
+  if (bias) v += bias[(i / PHW) % Mtot];
+  out[i] = sg_apply_act(v, act, slope);
+}
+
 // Wt[b][a][r] = W[a][b][r]
 __global__ void permute_w_kernel(const float* W, float* Wt, int A, int B, int R) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -574,55 +585,79 @@ Gather make_gather(const float* s1, const float* s2, int C1, int C2, int SH, int
 // ---- conv-shaped GEMM: K = (c, taps), N = pixels -------------------------------------------------
 template <class CFG, int BM, int BN, int KS, int MODE>
 int launch_ab(const float* A, int K, int M, bool vec, const Gather& g, int Npix, const KEntry* ktab, const EpNCHW& ep,
-              hipStream_t s) {
+              int splits, hipStream_t s) {
   const bool two = g.C2 > 0;
   if (two) {
     LoadGatherKN<BN, KS, MODE, true> bl{g, Npix, ktab};
-    if (vec) return launch_cfg<CFG>(LoadKContig<BM, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
-    return launch_cfg<CFG>(LoadKContig<BM, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+    if (vec) return launch_cfg<CFG>(LoadKContig<BM, true>{A, K, M}, bl, ep, M, Npix, K, splits, s);
+    return launch_cfg<CFG>(LoadKContig<BM, false>{A, K, M}, bl, ep, M, Npix, K, splits, s);
   }
   LoadGatherKN<BN, KS, MODE, false> bl{g, Npix, ktab};
-  if (vec) return launch_cfg<CFG>(LoadKContig<BM, true>{A, K, M}, bl, ep, M, Npix, K, 1, s);
-  return launch_cfg<CFG>(LoadKContig<BM, false>{A, K, M}, bl, ep, M, Npix, K, 1, s);
+  if (vec) return launch_cfg<CFG>(LoadKContig<BM, true>{A, K, M}, bl, ep, M, Npix, K, splits, s);
+  return launch_cfg<CFG>(LoadKContig<BM, false>{A, K, M}, bl, ep, M, Npix, K, splits, s);
+}
+
+// split-K for conv-shaped GEMMs that would otherwise leave most CUs idle (few output tiles, long K): e.g. the
+// Cout=1 heads of the PatchGANs (91 tiles of 32x128, K=8192)
+inline int kn_tiles(int M, int Npix) {
+  const int t = pick_tile(M, Npix);
+  return t == 0 ? sg_cdiv(M, 128) * sg_cdiv(Npix, 128) : (t == 1 ? sg_cdiv(M, 64) * sg_cdiv(Npix, 64) : sg_cdiv(Npix, 128));
+}
+inline int kn_splits(int M, int Npix, int K) {
+  const int tiles = kn_tiles(M, Npix);
+  if (tiles >= 256 || K < 2048) return 1;
+  int sp = 512 / tiles;
+  if (sp > K / 512) sp = K / 512;
+  if (sp > 8) sp = 8;
+  return sp < 2 ? 1 : sp;
+}
+inline size_t kn_slab_bytes(int M, int Npix, int K) {
+  const int sp = kn_splits(M, Npix, K);
+  return sp > 1 ? (size_t)sp * M * Npix * sizeof(float) : 0;
 }
 
 inline size_t ktab_bytes(int K) { return (size_t)(sg_cdiv(K, 64) * 64 + 128) * sizeof(KEntry); }
 
 template <int KS, int MODE>
 int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* bias, float* out, int Mtot, int act,
-           float slope, double flops, void* ktab_ws, hipStream_t s) {
+           float slope, double flops, void* ktab_ws, size_t ws_avail, hipStream_t s) {
   const int Npix = NB * g.PH * g.PW;
   KEntry* ktab = reinterpret_cast<KEntry*>(ktab_ws);
+  float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ktab_ws) + ktab_bytes(K));
+  int splits = (Mtot == M) ? kn_splits(M, Npix, K) : 1;
+  if (splits > 1 && ws_avail < ktab_bytes(K) + (size_t)splits * M * Npix * sizeof(float)) splits = 1;
   {
     const int Kpad = sg_cdiv(K, 64) * 64 + 128;      // the k-loop prefetches entries up to two tiles past the end
     hipLaunchKernelGGL(build_ktab_kernel, dim3(sg_cdiv(Kpad, 256)), dim3(256), 0, s, ktab, K, Kpad, KS * KS, g.C1, g.C2,
                        (unsigned)(g.SH * g.SW), g.bcast2);
   }
-  EpNCHW ep{out, bias, g.PH * g.PW, Mtot, M, Npix, act, slope};
+  const size_t nout = (size_t)M * Npix;
+  EpNCHW ep{out, bias, g.PH * g.PW, Mtot, M, Npix, act, slope, 0};
+  if (splits > 1) ep = EpNCHW{slabs, nullptr, g.PH * g.PW, Mtot, M, Npix, SG_ACT_NONE, 0.f, nout};
   const bool vec = (K % 4 == 0) && aligned16(A);
   const int tile = pick_tile(M, Npix);
-  SgProfScope prof(sg_igemm_kind(MODE, KS, tile), s, flops, 0);
-  switch (tile) {
-    case 0: {
-      return launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, s);
-    }
-    case 1: {
-      return launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, s);
-    }
-    default: {
-      return launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, s);
+  {
+    SgProfScope prof(sg_igemm_kind(MODE, KS, tile), s, flops, 0);
+    switch (tile) {
+      case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, s); break;
+      case 1: launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, s); break;
+      default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, s); break;
     }
   }
+  if (splits > 1)
+    hipLaunchKernelGGL(slab_reduce_nchw_kernel, dim3(sg_cdiv(nout, 256)), dim3(256), 0, s, (const float*)slabs, out, nout,
+                       splits, bias, g.PH * g.PW, Mtot, act, slope);
+  return 0;
 }
 
 template <int MODE>
 int run_kn_ks(int KS, const float* A, int M, int K, const Gather& g, int NB, const float* bias, float* out, int Mtot,
-              int act, float slope, double flops, void* ktab_ws, hipStream_t s) {
+              int act, float slope, double flops, void* ktab_ws, size_t ws_avail, hipStream_t s) {
   switch (KS) {
-    case 1: return run_kn<1, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, ktab_ws, s);
-    case 3: return run_kn<3, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, ktab_ws, s);
-    case 4: return run_kn<4, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, ktab_ws, s);
-    case 7: return run_kn<7, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, ktab_ws, s);
+    case 1: return run_kn<1, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, ktab_ws, ws_avail, s);
+    case 3: return run_kn<3, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, ktab_ws, ws_avail, s);
+    case 4: return run_kn<4, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, ktab_ws, ws_avail, s);
+    case 7: return run_kn<7, MODE>(A, M, K, g, NB, bias, out, Mtot, act, slope, flops, ktab_ws, ws_avail, s);
   }
   return -1;
 }
@@ -716,14 +751,22 @@ extern "C" size_t sg_conv2d_ws_bytes(const sgConvDesc* d, int kind) {
   const size_t wbytes = (size_t)d->Cout * (d->C1 + d->C2) * d->KS * d->KS * sizeof(float);
   const int Kmax = (d->Cout > d->C1 + d->C2 ? d->Cout : d->C1 + d->C2) * d->KS * d->KS;
   const size_t kt = ktab_bytes(Kmax);
-  if (kind == 0) return wbytes + kt;               // fwd: k-split table (+ transposed weights for convT)
-  if (kind == 1) return wbytes + kt;               // dgrad: transposed weights + k-split table
+  const int Cin = d->C1 + d->C2, R = d->KS * d->KS;
+  const size_t sl_f = kn_slab_bytes(d->Cout, d->N * d->OH * d->OW, Cin * R);                 // conv fwd / convT fwd
+  const int GH = d->H * d->upsample + (d->pad_reflect ? 2 * d->pad : 0), GW = d->W * d->upsample + (d->pad_reflect ? 2 * d->pad : 0);
+  const size_t sl_d = kn_slab_bytes(Cin, d->N * GH * GW, d->Cout * R);                        // conv dgrad (all channels)
+  const size_t sl_t = kn_slab_bytes(d->C1, d->N * d->H * d->W, d->Cout * R);                  // convT dgrad
+  const size_t sl = sl_f > sl_d ? (sl_f > sl_t ? sl_f : sl_t) : (sl_d > sl_t ? sl_d : sl_t);
+  if (kind == 0) return wbytes + kt + sl;          // fwd: k-split table, split-K slabs (+ transposed weights for convT)
+  if (kind == 1) return wbytes + kt + sl;          // dgrad: transposed weights + k-split table + split-K slabs
   const int M = d->Cout > (d->C1 + d->C2) ? d->Cout : (d->C1 + d->C2);
   const int Kp = d->N * (d->OH * d->OW > d->H * d->W ? d->OH * d->OW : d->H * d->W);
   size_t a = wgrad_ws(d->Cout, (d->C1 + d->C2) * d->KS * d->KS, d->N * d->OH * d->OW);
   size_t b = wgrad_ws(d->C1 + d->C2, d->Cout * d->KS * d->KS, d->N * d->H * d->W);
   (void)M; (void)Kp;
-  return a > b ? a : b;
+  const size_t cs = sg_channel_sum_ws_bytes(d->Cout);
+  a = a > b ? a : b;
+  return a > cs ? a : cs;
 }
 
 extern "C" int sg_conv2d_fwd(const sgConvDesc* d, const float* x1, const float* x2, const float* w, const float* bias,
@@ -737,7 +780,7 @@ extern "C" int sg_conv2d_fwd(const sgConvDesc* d, const float* x1, const float* 
   Gather g = make_gather(x1, x2, d->C1, d->C2, d->H, d->W, d->upsample, d->OH, d->OW, d->stride, d->pad, d->pad_reflect);
   g.bcast2 = d->x2_broadcast;
   const double flops = 2.0 * d->Cout * K * (double)d->N * d->OH * d->OW;
-  int rc = run_kn_ks<0>(d->KS, w, d->Cout, K, g, d->N, bias, y, d->Cout, act, slope, flops, ws, s);
+  int rc = run_kn_ks<0>(d->KS, w, d->Cout, K, g, d->N, bias, y, d->Cout, act, slope, flops, ws, ws_bytes, s);
   SG_LAUNCH_CHECK("sg_conv2d_fwd");
   return rc;
 }
@@ -763,7 +806,7 @@ extern "C" int sg_conv2d_dgrad(const sgConvDesc* d, const float* gy, const float
   // algorithmic flops of a dgrad = those of the forward conv restricted to the requested input channels
   const double flops = 2.0 * M * (double)d->Cout * R * d->N * d->OH * d->OW;
   int rc = run_kn_ks<1>(d->KS, wt + (size_t)c_begin * K, M, K, g, d->N, nullptr, gx, M, SG_ACT_NONE, 0.f, flops,
-                        wt + nw, s);
+                        wt + nw, ws_bytes - nw * sizeof(float), s);
   SG_LAUNCH_CHECK("sg_conv2d_dgrad");
   return rc;
 }
@@ -779,7 +822,7 @@ extern "C" int sg_conv2d_wgrad(const sgConvDesc* d, const float* gy, const float
   const double flops = 2.0 * d->Cout * (double)(d->C1 + d->C2) * d->KS * d->KS * d->N * d->OH * d->OW;
   run_nk_ks(d->KS, gy, d->Cout, d->Cout, g, d->N, gw, ws, ws ? ws_bytes : 0, flops, s);
   SG_LAUNCH_CHECK("sg_conv2d_wgrad");
-  if (gb) return sg_channel_sum(gy, gb, d->N, d->Cout, d->OH * d->OW, stream);
+  if (gb) return sg_channel_sum(gy, gb, d->N, d->Cout, d->OH * d->OW, ws, ws ? ws_bytes : 0, stream);
   return 0;
 }
 
@@ -798,7 +841,8 @@ extern "C" int sg_convT2d_fwd(const sgConvDesc* d, const float* x, const float* 
   hipLaunchKernelGGL(permute_w_kernel, dim3(sg_cdiv(nw, 256)), dim3(256), 0, s, w, wt, Cin, d->Cout, R);
   Gather g = make_gather(x, nullptr, Cin, 0, d->H, d->W, 1, d->OH, d->OW, d->stride, d->pad, 0);
   const double flops = 2.0 * d->Cout * Cin * R * (double)d->N * d->H * d->W;
-  int rc = run_kn_ks<1>(d->KS, wt, d->Cout, Cin * R, g, d->N, bias, y, d->Cout, SG_ACT_NONE, 0.f, flops, wt + nw, s);
+  int rc = run_kn_ks<1>(d->KS, wt, d->Cout, Cin * R, g, d->N, bias, y, d->Cout, SG_ACT_NONE, 0.f, flops, wt + nw,
+                        ws_bytes - nw * sizeof(float), s);
   SG_LAUNCH_CHECK("sg_convT2d_fwd");
   return rc;
 }
@@ -813,7 +857,7 @@ extern "C" int sg_convT2d_dgrad(const sgConvDesc* d, const float* gy, const floa
   const int R = d->KS * d->KS;
   Gather g = make_gather(gy, nullptr, d->Cout, 0, d->OH, d->OW, 1, d->H, d->W, d->stride, d->pad, 0);
   const double flops = 2.0 * d->Cout * d->C1 * R * (double)d->N * d->H * d->W;
-  int rc = run_kn_ks<0>(d->KS, w, d->C1, d->Cout * R, g, d->N, nullptr, gx, d->C1, SG_ACT_NONE, 0.f, flops, ws, s);
+  int rc = run_kn_ks<0>(d->KS, w, d->C1, d->Cout * R, g, d->N, nullptr, gx, d->C1, SG_ACT_NONE, 0.f, flops, ws, ws_bytes, s);
   SG_LAUNCH_CHECK("sg_convT2d_dgrad");
   return rc;
 }
@@ -828,7 +872,7 @@ extern "C" int sg_convT2d_wgrad(const sgConvDesc* d, const float* gy, const floa
   run_nk_ks(d->KS, x, d->C1, d->C1, g, d->N, gw, ws, ws ? ws_bytes : 0,
             2.0 * d->Cout * (double)d->C1 * d->KS * d->KS * d->N * d->H * d->W, s);
   SG_LAUNCH_CHECK("sg_convT2d_wgrad");
-  if (gb) return sg_channel_sum(gy, gb, d->N, d->Cout, d->OH * d->OW, stream);
+  if (gb) return sg_channel_sum(gy, gb, d->N, d->Cout, d->OH * d->OW, ws, ws ? ws_bytes : 0, stream);
   return 0;
 }
 
@@ -887,6 +931,6 @@ extern "C" int sg_linear_bwd_weight(const float* gy, const float* x, float* gw, 
               LoadXContig<128>{x, in_f, in_f}, ep, out_f, in_f, rows, s);
   }
   SG_LAUNCH_CHECK("sg_linear_bwd_weight");
-  if (gb) return sg_channel_sum(gy, gb, rows, out_f, 1, stream);   // column sums of gy[rows][out_f]
+  if (gb) return sg_channel_sum(gy, gb, rows, out_f, 1, nullptr, 0, stream);   // column sums of gy[rows][out_f]
   return 0;
 }

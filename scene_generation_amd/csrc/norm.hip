@@ -158,6 +158,32 @@ __global__ void __launch_bounds__(512) batchnorm_bwd_kernel(const float* __restr
   }
 }
 
+// per-channel sum over (N, HW): two deterministic stages -- grid (C, S) partial sums over contiguous chunks of the
+// (n, p) index space, then one block per channel adds the S partials in fixed order.
+__global__ void __launch_bounds__(256) channel_sum_partial_kernel(const float* __restrict__ g, float* __restrict__ part, int N,
+                                                                 int C, int HW, int S) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, z = blockIdx.y;
+  const long cnt = (long)N * HW;
+  const long chunk = (cnt + S - 1) / S;
+  const long beg = z * chunk, end = beg + chunk < cnt ? beg + chunk : cnt;
+  float s = 0.f;
+  for (long i = beg + threadIdx.x; i < end; i += 256) {
+    const int n = (int)(i / HW), p = (int)(i - (long)n * HW);
+    s += g[((size_t)n * C + c) * HW + p];
+  }
+  s = sg_block_sum(s, red);
+  if (threadIdx.x == 0) part[(size_t)c * S + z] = s;
+}
+
+__global__ void channel_sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int S) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int z = 0; z < S; ++z) s += part[(size_t)c * S + z];
+  out[c] = s;
+}
+
 __global__ void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int N, int C, int HW) {
   __shared__ float red[16];
   const int c = blockIdx.x;
@@ -375,9 +401,26 @@ extern "C" int sg_batchnorm_bwd(const float* x, const float* gy, const float* ga
   return 0;
 }
 
-extern "C" int sg_channel_sum(const float* g, float* out, int N, int C, int HW, sgStream stream) {
+extern "C" size_t sg_channel_sum_ws_bytes(int C) { return (size_t)C * 64 * sizeof(float); }
+
+extern "C" int sg_channel_sum(const float* g, float* out, int N, int C, int HW, void* ws, size_t ws_bytes,
+                              sgStream stream) {
   SG_ARG_CHECK(g && out && N > 0 && C > 0 && HW > 0, "sg_channel_sum: bad arguments");
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, g, out, N, C, HW);
+  hipStream_t s = (hipStream_t)stream;
+  const long cnt = (long)N * HW;
+  // small reductions: one block per channel; large ones: split so that ~1024 workgroups stream the tensor
+  int S = (int)(cnt / 4096);
+  const int want = (1024 + C - 1) / C;
+  if (S > want) S = want;
+  if (S > 64) S = 64;
+  if (S > 1 && (!ws || ws_bytes < (size_t)C * S * sizeof(float))) S = 1;      // no scratch: single-stage fallback
+  if (S <= 1) {
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, s, g, out, N, C, HW);
+  } else {
+    float* part = reinterpret_cast<float*>(ws);
+    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(C, S), dim3(256), 0, s, g, part, N, C, HW, S);
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(sg_cdiv(C, 64)), dim3(64), 0, s, (const float*)part, out, C, S);
+  }
   SG_LAUNCH_CHECK("sg_channel_sum");
   return 0;
 }

@@ -44,8 +44,12 @@ def masks_to_layout(vecs, boxes, masks, obj_to_img, H, W=None, pooling='sum', te
         W = H
     N = _num_images(obj_to_img, num_images, validate)
     seg = ops.segment_offsets(obj_to_img, N)
-    return ops.MasksToLayoutFn.apply(vecs, boxes, masks, seg, N, H, W, pooling == 'avg', int(grad_from_channel),
-                                     int(max_per_image))
+    out = ops.MasksToLayoutFn.apply(vecs, boxes, masks, seg, N, H, W, pooling == 'avg', int(grad_from_channel),
+                                    int(max_per_image))
+    if grad_from_channel > 0:
+        # backward only reads d out[:, grad_from_channel:]; consumers (the generator's first conv) may skip the rest
+        out._sg_grad_from = int(grad_from_channel)
+    return out
 
 
 def boxes_to_layout(vecs, boxes, obj_to_img, H, W=None, pooling='sum', **kw):

@@ -86,7 +86,7 @@ class Conv2dFn(Function):
     discriminators.py:137-158,215-234)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, stride, pad, reflect, upsample, act, slope):
+    def forward(ctx, x1, x2, weight, bias, stride, pad, reflect, upsample, act, slope, grad_from):
         x1 = _f32(x1, 'conv input')
         x2 = None if x2 is None else _f32(x2, 'conv input 2')
         weight = _f32(weight, 'conv weight')
@@ -103,7 +103,7 @@ class Conv2dFn(Function):
         _call('sg_conv2d_fwd', ctypes.byref(d), _p(x1), _p(x2), _p(weight), _p(bias), _p(y), act, slope, _p(ws), wsb,
               _stream())
         ctx.desc = d
-        ctx.cfg = (act, slope, bias is not None)
+        ctx.cfg = (act, slope, bias is not None, int(grad_from))
         ctx.save_for_backward(x1, x2, weight, y if act != ACT_NONE else None)
         return y
 
@@ -111,7 +111,7 @@ class Conv2dFn(Function):
     def backward(ctx, gy):
         x1, x2, weight, y = ctx.saved_tensors
         d = ctx.desc
-        act, slope, has_bias = ctx.cfg
+        act, slope, has_bias, grad_from = ctx.cfg
         gy = _f32(gy)
         s = _stream()
         if act != ACT_NONE:
@@ -139,7 +139,11 @@ class Conv2dFn(Function):
                     return out
                 return g
             if need_x1:
-                gx1 = dgrad(0, d.C1)
+                if grad_from > 0:      # channels [0, grad_from) of x1 are constants of the graph (one-hot layout block)
+                    gx1 = torch.zeros(d.N, d.C1, d.H, d.W, dtype=torch.float32, device=dev)
+                    gx1[:, grad_from:] = dgrad(grad_from, d.C1)
+                else:
+                    gx1 = dgrad(0, d.C1)
             if need_x2:
                 gx2 = dgrad(d.C1, d.C1 + d.C2)
                 if d.x2_broadcast:          # [N, C2] source broadcast over H x W: reduce the map gradient
@@ -155,12 +159,19 @@ class Conv2dFn(Function):
                 _call('sg_conv2d_wgrad', ctypes.byref(d), _p(gy), _p(x1), _p(x2), _p(gw), _p(gb), _p(ws), wsb, s)
             else:
                 gb = torch.empty(d.Cout, dtype=torch.float32, device=dev)
-                _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, s)
-        return gx1, gx2, gw, gb, None, None, None, None, None, None
+                wsb = _L().sg_channel_sum_ws_bytes(d.Cout)
+                ws = workspace(wsb, dev)
+                _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb, s)
+        return gx1, gx2, gw, gb, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, upsample=1, act=ACT_NONE, slope=0.0, x2=None):
-    return Conv2dFn.apply(x, x2, weight, bias, stride, pad, reflect, upsample, act, float(slope))
+    """``x._sg_grad_from = c`` (set by masks_to_layout) promises that nobody needs d/dx[:, :c]: the data gradient is then
+    only computed for channels >= c (the rest is returned as zeros)."""
+    grad_from = int(getattr(x, '_sg_grad_from', 0))
+    if not (0 < grad_from < x.size(1)):
+        grad_from = 0
+    return Conv2dFn.apply(x, x2, weight, bias, stride, pad, reflect, upsample, act, float(slope), grad_from)
 
 
 class ConvTranspose2dFn(Function):
@@ -206,7 +217,9 @@ class ConvTranspose2dFn(Function):
             _call('sg_convT2d_wgrad', ctypes.byref(d), _p(gy), _p(x), _p(gw), _p(gb), _p(ws), wsb, s)
         elif need_b:
             gb = torch.empty(d.Cout, dtype=torch.float32, device=gy.device)
-            _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, s)
+            wsb = _L().sg_channel_sum_ws_bytes(d.Cout)
+            ws = workspace(wsb, gy.device)
+            _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb, s)
         return gx, gw, gb, None, None, None
 
 
@@ -261,7 +274,7 @@ class LinearFn(Function):
             _call('sg_linear_bwd_weight', _p(gy), _p(x), _p(gw), _p(gb), rows, in_f, out_f, s)
         elif need_b:
             gb = torch.empty(out_f, dtype=torch.float32, device=x.device)
-            _call('sg_channel_sum', _p(gy), _p(gb), rows, out_f, 1, s)
+            _call('sg_channel_sum', _p(gy), _p(gb), rows, out_f, 1, None, 0, s)
         return gx, gw, gb, None, None
 
 
