@@ -18,6 +18,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+#ifndef SG_NSUB
+#define SG_NSUB 1    // sub-tiles per workgroup k-tile (see CfgFor below for why 1)
+#endif
 constexpr int BK = 16;     // sub-tile depth: the unit one loader call stages (16 k-rows)
 
 // A workgroup k-tile is NSUB sub-tiles deep (BKT = 16*NSUB): all 2*NSUB loader calls of the next tile are issued
@@ -50,14 +53,14 @@ constexpr int LDK = BK + 4;
 // Offsets are 32-bit: the host rejects tensors of >= 2^31 elements.
 
 // rows of length K contiguous in memory: elem(x, k) = base[x*ld + k].  VEC: ld%4==0 and 16-B aligned base.
-template <int BX, bool VEC>
+template <int BX, bool VEC, bool MASK = true>
 struct LoadKContig {
   const float* base; int ld; int X;
   static constexpr int LDS_INTS = 0;
   static constexpr int PASSES = BX >= 64 ? BX / 64 : 1;
   struct Stage { float r[PASSES * 4]; unsigned ok; };
   int x0_, xr_, kq_;
-  __device__ __forceinline__ void init(int x0, int tid, int*) { x0_ = x0; xr_ = tid >> 2; kq_ = (tid & 3) * 4; }
+  __device__ __forceinline__ void init(int x0, int tid, int*, int, int) { x0_ = x0; xr_ = tid >> 2; kq_ = (tid & 3) * 4; }
   __device__ __forceinline__ void prefetch(Stage&, int) const {}
   __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
     st.ok = 0;
@@ -67,7 +70,10 @@ struct LoadKContig {
       const int x = x0_ + xl, k = k0 + kq_;
       const bool xok = xl < BX && x < X;
       const unsigned row = (unsigned)(xok ? x : 0) * (unsigned)ld;
-      if (VEC) {                                  // kend % 4 == 0 here, so k < kend covers the whole float4
+      if (VEC && !MASK) {                         // full tiles only (X % BX == 0, K % 16 == 0): no validity at all
+        const float4 v = *reinterpret_cast<const float4*>(base + (unsigned)x * (unsigned)ld + k);
+        st.r[p * 4 + 0] = v.x; st.r[p * 4 + 1] = v.y; st.r[p * 4 + 2] = v.z; st.r[p * 4 + 3] = v.w;
+      } else if (VEC) {                           // kend % 4 == 0 here, so k < kend covers the whole float4
         const bool ok = xok && k < kend;
         const float4 v = *reinterpret_cast<const float4*>(base + row + (ok ? k : 0));
         st.r[p * 4 + 0] = v.x; st.r[p * 4 + 1] = v.y; st.r[p * 4 + 2] = v.z; st.r[p * 4 + 3] = v.w;
@@ -86,7 +92,9 @@ struct LoadKContig {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int xl = xr_ + p * 64;
-      if (xl < BX) {
+      if (xl < BX && VEC && !MASK) {
+        *reinterpret_cast<float4*>(T + xl * LDK + kq_) = make_float4(st.r[p * 4], st.r[p * 4 + 1], st.r[p * 4 + 2], st.r[p * 4 + 3]);
+      } else if (xl < BX) {
         float4 v;
         v.x = ((st.ok >> (p * 4 + 0)) & 1u) ? st.r[p * 4 + 0] : 0.f;
         v.y = ((st.ok >> (p * 4 + 1)) & 1u) ? st.r[p * 4 + 1] : 0.f;
@@ -99,11 +107,11 @@ struct LoadKContig {
 };
 
 // store ROWS consecutive k values of tile row xl starting at column kr (kr % ROWS == 0) as 16/8-byte LDS writes
-template <int ROWS>
+template <int ROWS, bool MASK = true>
 __device__ __forceinline__ void store_krun(float* T, int xl, int kr, const float (&r)[ROWS], unsigned ok) {
   float v[ROWS];
 #pragma unroll
-  for (int i = 0; i < ROWS; ++i) v[i] = ((ok >> i) & 1u) ? r[i] : 0.f;
+  for (int i = 0; i < ROWS; ++i) v[i] = (!MASK || ((ok >> i) & 1u)) ? r[i] : 0.f;
   float* dst = T + xl * LDK + kr;
   if (ROWS % 4 == 0) {
 #pragma unroll
@@ -125,7 +133,7 @@ struct LoadXContig {
   static constexpr int ROWS = BX * BK / 256;
   struct Stage { float r[ROWS]; unsigned ok; };
   int x_, xl_, kr_;
-  __device__ __forceinline__ void init(int x0, int tid, int*) { xl_ = tid % BX; x_ = x0 + xl_; kr_ = (tid / BX) * ROWS; }
+  __device__ __forceinline__ void init(int x0, int tid, int*, int, int) { xl_ = tid % BX; x_ = x0 + xl_; kr_ = (tid / BX) * ROWS; }
   __device__ __forceinline__ void prefetch(Stage&, int) const {}
   __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
     st.ok = 0;
@@ -183,7 +191,8 @@ __device__ __forceinline__ int tap_offset(const Gather& g, int ah, int aw, int k
 //  64x64 tile took ~1000 cycles per k-tile against 512 cycles of MFMA work).
 struct KEntry { unsigned choff; unsigned tapsel; };     // channel-plane offset ; tap row | second-source << 8
 
-__global__ void build_ktab_kernel(KEntry* tab, int K, int Kpad, int KS2, int C1, int C2, unsigned shw, int bcast2) {
+__global__ void build_ktab_kernel(KEntry* tab, int K, int Kpad, int KS2, int C1, int C2, unsigned shw, int bcast2,
+                                  int tail_valid) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= Kpad) return;
   KEntry e;
@@ -194,12 +203,13 @@ __global__ void build_ktab_kernel(KEntry* tab, int K, int Kpad, int KS2, int C1,
     e.choff = (second && bcast2) ? cc : cc * shw;
     e.tapsel = (unsigned)t | (second ? 256u : 0u);
   } else {
-    e.choff = 0u; e.tapsel = (unsigned)KS2;
+    // k >= K: either the all-invalid tap row, or (mask-free kernels) any valid element: the A operand is zero there
+    e.choff = 0u; e.tapsel = tail_valid ? 0u : (unsigned)KS2;
   }
   tab[k] = e;
 }
 
-template <int BN, int KS, int MODE, bool TWO>
+template <int BN, int KS, int MODE, bool TWO, bool MASK = true>
 struct LoadGatherKN {
   Gather g; int Npix; const KEntry* ktab;
   static constexpr int KS2 = KS * KS;
@@ -209,7 +219,7 @@ struct LoadGatherKN {
   unsigned img1_, img2_, img2b_;
   int nl_, kr_;
   const int* tab_;
-  __device__ __forceinline__ void init(int n0, int tid, int* tab) {
+  __device__ __forceinline__ void init(int n0, int tid, int* tab, int, int) {
     nl_ = tid % BN;
     const int grp = tid / BN;
     kr_ = __builtin_amdgcn_readfirstlane(grp * ROWS);          // wave-uniform => ktab entries live in SGPRs
@@ -245,7 +255,7 @@ struct LoadGatherKN {
     for (int i = 0; i < ROWS; ++i) {
       const unsigned choff = st.e[i].choff, ts = st.e[i].tapsel;
       const int tp = tab_[(ts & 255u) * BN];
-      const bool ok = tp >= 0;
+      const bool ok = !MASK || tp >= 0;           // !MASK: reflection padding + full pixel tiles => every tap is valid
       if (TWO) {
         const bool second = (ts & 256u) != 0u;                  // scalar
         const float* base = second ? g.src2 : g.src1;
@@ -257,18 +267,18 @@ struct LoadGatherKN {
       st.ok |= ok ? (1u << i) : 0u;
     }
   }
-  __device__ __forceinline__ void store(const Stage& st, float* T) const { store_krun<ROWS>(T, nl_, kr_, st.r, st.ok); }
+  __device__ __forceinline__ void store(const Stage& st, float* T) const { store_krun<ROWS, MASK>(T, nl_, kr_, st.r, st.ok); }
 };
 
 // A operand of wgrad: elem(m, k) = base[(img*Mtot + m)*PQ + pix], k = img*PQ + pix.  Lanes run along k.
-template <int BM>
+template <int BM, bool MASK = true>
 struct LoadPixK {
   const float* base; int M, Mtot, PQ;
   static constexpr int LDS_INTS = 0;
   static constexpr int ROWS = BM / 16;
   struct Stage { float r[ROWS]; unsigned ok; };
   int m0_, mr_, kl_;
-  __device__ __forceinline__ void init(int m0, int tid, int*) { m0_ = m0; kl_ = tid & 15; mr_ = tid >> 4; }
+  __device__ __forceinline__ void init(int m0, int tid, int*, int, int) { m0_ = m0; kl_ = tid & 15; mr_ = tid >> 4; }
   __device__ __forceinline__ void prefetch(Stage&, int) const {}
   __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
     const int k = k0 + kl_;
@@ -280,72 +290,118 @@ struct LoadPixK {
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
       const int m = m0_ + mr_ + 16 * i;
-      const bool ok = kok && m < M;
+      const bool ok = !MASK || (kok && m < M);
       st.r[i] = base[ok ? p0 + (unsigned)m * (unsigned)PQ : 0u];
       st.ok |= ok ? (1u << i) : 0u;
     }
   }
   __device__ __forceinline__ void store(const Stage& st, float* T) const {
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) T[(mr_ + 16 * i) * LDK + kl_] = ((st.ok >> i) & 1u) ? st.r[i] : 0.f;
+    for (int i = 0; i < ROWS; ++i) T[(mr_ + 16 * i) * LDK + kl_] = (!MASK || ((st.ok >> i) & 1u)) ? st.r[i] : 0.f;
   }
 };
 
-// B operand of wgrad: k = (img, ph, pw) over the gy grid, n = (c, kh, kw).  Lanes run along k (pixels); the COLS
-// columns a thread owns are fixed for the whole k-loop.
-template <int BN, int KS>
+// B operand of wgrad: k = (img, ph, pw) over the gy grid, n = (c, kh, kw).  Lanes run along k (16 pixels per tile); the
+// COLS columns a thread owns are fixed for the whole k-loop, so their (channel offset, tap row) split is done once.
+// The geometry of the 16 pixels of a k-tile (tap offsets incl. padding / reflection / upsampling, image bases) is
+// computed cooperatively ONE TILE AHEAD into a double-buffered LDS table (prefetch()), which turns a gathered
+// element into: 1 ds_read + 1 add + 1 load (it was a ~30-instruction tap_offset() per element per tile).
+// one axis of tap_offset<0>: source coordinate (already >> upsample) or -1
+__device__ __forceinline__ int axis_offset(int a, int k, int L, int reflect, int ushift) {
+  int i = a + k;
+  const bool inside = (unsigned)i < (unsigned)L;
+  int r = i < 0 ? -i : i; r = r >= L ? 2 * L - 2 - r : r;
+  i = (reflect ? r : i) >> ushift;
+  return (reflect || inside) ? i : -1;
+}
+
+template <int BN, int KS, bool TWO, bool MASK = true>
 struct LoadGatherNK {
   Gather g; int Ncols;
-  static constexpr int LDS_INTS = 0;
+  static constexpr int KS2 = KS * KS;
+  // per k-tile LDS table (separable): rowoff[KS][16] (= ih*SW or -1), coloff[KS][16] (= iw or -1), one all -1 row,
+  // img1[16], img2[16]
+  static constexpr int NEG = 2 * KS;
+  static constexpr int BUF = (2 * KS + 1) * BK + 2 * BK;
+  static constexpr int LDS_INTS = 2 * SG_NSUB * BUF;
   static constexpr int COLS = BN / 16;
   struct Stage { float r[COLS]; unsigned ok; };
-  int kl_, nr_;
-  int cofs_[COLS]; int khw_[COLS];       // channel-plane offset (or -1) / packed tap; second-source flag in bit 16
-  __device__ __forceinline__ void init(int n0, int tid, int*) {
-    kl_ = tid & 15; nr_ = tid >> 4;
-    const int shw = g.SH * g.SW;
+  int kl_, tid_, nr_, kbeg_, kend_;
+  unsigned choff_[COLS], secmask_;
+  int rrow_[COLS], crow_[COLS];
+  int* lds_;
+  __device__ __forceinline__ void init(int n0, int tid, int* lds, int kbeg, int kend) {
+    kl_ = tid & 15; nr_ = tid >> 4; tid_ = tid; lds_ = lds; kbeg_ = kbeg; kend_ = kend;
+    const unsigned shw = (unsigned)(g.SH * g.SW);
+    secmask_ = 0;
 #pragma unroll
     for (int j = 0; j < COLS; ++j) {
       const int n = n0 + nr_ + 16 * j;
       const bool ok = n < Ncols;
       const int nn = ok ? n : 0;
-      const int c = nn / (KS * KS);
-      const int rr = nn - c * (KS * KS);
-      const int kh = rr / KS;
-      const bool second = c >= g.C1;
-      const int cc = second ? c - g.C1 : c;
-      cofs_[j] = ok ? (second && g.bcast2 ? cc : cc * shw) : -1;
-      khw_[j] = (kh << 8) | (rr - kh * KS) | (second ? (1 << 16) : 0);
+      const int c = nn / KS2;
+      const int t = nn - c * KS2;
+      const int kh = t / KS, kw = t - kh * KS;
+      const bool second = TWO && c >= g.C1;
+      const unsigned cc = (unsigned)(second ? c - g.C1 : c);
+      choff_[j] = (second && g.bcast2) ? cc : cc * shw;
+      // column tail: the all -1 row, or (mask-free kernels) any valid tap -- the epilogue never stores n >= Ncols
+      rrow_[j] = (ok ? kh : (MASK ? NEG : 0)) * BK + kl_;
+      crow_[j] = (ok ? KS + kw : (MASK ? NEG : KS)) * BK + kl_;
+      secmask_ |= second ? (1u << j) : 0u;
     }
   }
-  __device__ __forceinline__ void prefetch(Stage&, int) const {}
-  __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
-    const int k = k0 + kl_;
-    const bool kok = k < kend;
-    const int kk = kok ? k : 0;
+  __device__ __forceinline__ int* buf_of(int k0) const { return lds_ + (((k0 - kbeg_) / BK) % (2 * SG_NSUB)) * BUF; }
+  __device__ __forceinline__ void prefetch(Stage&, int k0) const {
+    int* buf = buf_of(k0);
     const int phw = g.PH * g.PW;
-    const int img = kk / phw, pix = kk - img * phw;
-    const int ph = pix / g.PW, pw = pix - ph * g.PW;
-    const int ah = ph * g.stride - g.pad, aw = pw * g.stride - g.pad;
     const unsigned shw = (unsigned)(g.SH * g.SW);
-    const unsigned img1 = (unsigned)img * (unsigned)g.C1 * shw, img2 = (unsigned)img * (unsigned)g.C2 * shw;
-    const unsigned img2b = (unsigned)img * (unsigned)g.C2;
+    for (int e = tid_; e < BUF; e += 256) {
+      const int p = e & (BK - 1), row = e / BK;
+      const int k = k0 + p;
+      const bool kok = k < kend_;
+      const int kk = kok ? k : 0;
+      const int img = kk / phw, pix = kk - img * phw;
+      const int ph = pix / g.PW, pw = pix - ph * g.PW;
+      int val = -1;
+      if (row < KS) {
+        const int i = axis_offset(ph * g.stride - g.pad, row, g.LH, g.reflect, g.ushift);
+        val = (kok && i >= 0) ? i * g.SW : -1;
+      } else if (row < 2 * KS) {
+        const int i = axis_offset(pw * g.stride - g.pad, row - KS, g.LW, g.reflect, g.ushift);
+        val = kok ? i : -1;
+      } else if (row == 2 * KS + 1) {
+        val = (int)((unsigned)img * (unsigned)g.C1 * shw);
+      } else if (row == 2 * KS + 2) {
+        val = (int)(g.bcast2 ? (unsigned)img * (unsigned)g.C2 : (unsigned)img * (unsigned)g.C2 * shw);
+      }
+      buf[e] = val;
+    }
+  }
+  __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
+    const int* buf = buf_of(k0);
+    const unsigned img1 = (unsigned)buf[(2 * KS + 1) * BK + kl_];
+    const unsigned img2 = TWO ? (unsigned)buf[(2 * KS + 2) * BK + kl_] : 0u;
     st.ok = 0;
 #pragma unroll
     for (int j = 0; j < COLS; ++j) {
-      const int tp = tap_offset<0>(g, ah, aw, (khw_[j] >> 8) & 255, khw_[j] & 255);
-      const bool second = (khw_[j] >> 16) & 1;
-      const bool ok = kok && cofs_[j] >= 0 && tp >= 0;
-      const float* base = second ? g.src2 : g.src1;
-      unsigned off = (second ? img2 : img1) + (unsigned)cofs_[j] + (unsigned)tp;
-      off = (second && g.bcast2) ? img2b + (unsigned)cofs_[j] : off;
-      st.r[j] = base[ok ? off : 0u];
+      const int ro = buf[rrow_[j]], co = buf[crow_[j]];
+      const bool ok = !MASK || (ro | co) >= 0;
+      const unsigned tp = (unsigned)(ro + co);
+      if (TWO) {
+        const bool second = (secmask_ >> j) & 1u;
+        const float* base = second ? g.src2 : g.src1;
+        const unsigned off = (second ? img2 : img1) + choff_[j] + ((second && g.bcast2) ? 0u : tp);
+        st.r[j] = base[ok ? off : 0u];
+      } else {
+        st.r[j] = g.src1[ok ? img1 + choff_[j] + tp : 0u];
+      }
       st.ok |= ok ? (1u << j) : 0u;
     }
   }
   __device__ __forceinline__ void store(const Stage& st, float* T) const {
 #pragma unroll
-    for (int j = 0; j < COLS; ++j) T[(nr_ + 16 * j) * LDK + kl_] = ((st.ok >> j) & 1u) ? st.r[j] : 0.f;
+    for (int j = 0; j < COLS; ++j) T[(nr_ + 16 * j) * LDK + kl_] = (!MASK || ((st.ok >> j) & 1u)) ? st.r[j] : 0.f;
   }
 };
 
@@ -426,9 +482,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   const int kbeg = blockIdx.z * kchunk;
   const int kend = min(K, kbeg + kchunk);
 
-  al.init(m0, tid, tapA);
-  bl.init(n0, tid, tapB);
-  if (AL::LDS_INTS > 0 || BL::LDS_INTS > 0) __syncthreads();
+  al.init(m0, tid, tapA, kbeg, kend);
+  bl.init(n0, tid, tapB, kbeg, kend);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -442,6 +497,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   typename BL::Stage sb[NSUB];
 #pragma unroll
   for (int u = 0; u < NSUB; ++u) { al.prefetch(sa[u], kbeg + u * BK); bl.prefetch(sb[u], kbeg + u * BK); }
+  if (AL::LDS_INTS > 0 || BL::LDS_INTS > 0) __syncthreads();      // tap tables written by init()/prefetch()
 #pragma unroll
   for (int u = 0; u < NSUB; ++u) { al.load(sa[u], kbeg + u * BK, kend); bl.load(sb[u], kbeg + u * BK, kend); }
 #pragma unroll
@@ -506,9 +562,6 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
 // tile configurations.  Measured on MI355X (tools/bench_conv.py): these kernels are limited by the vector-memory
 // instruction rate of the gather (one 4-byte load per lane per im2col element), not by load latency, so deeper
 // k-tiles (NSUB 2/4 => 70 KB LDS => 2 workgroups/CU) LOSE 5-15 % against NSUB=1 with 6-8 resident workgroups.
-#ifndef SG_NSUB
-#define SG_NSUB 1
-#endif
 template <int KS> struct CfgFor {
   using C128 = TileCfg<128, 128, 2, SG_NSUB>;
   using C64 = TileCfg<64, 64, 2, SG_NSUB>;
@@ -585,16 +638,20 @@ Gather make_gather(const float* s1, const float* s2, int C1, int C2, int SH, int
 // ---- conv-shaped GEMM: K = (c, taps), N = pixels -------------------------------------------------
 template <class CFG, int BM, int BN, int KS, int MODE>
 int launch_ab(const float* A, int K, int M, bool vec, const Gather& g, int Npix, const KEntry* ktab, const EpNCHW& ep,
-              int splits, hipStream_t s) {
+              int splits, bool nomask, hipStream_t s) {
   const bool two = g.C2 > 0;
-  if (two) {
-    LoadGatherKN<BN, KS, MODE, true> bl{g, Npix, ktab};
-    if (vec) return launch_cfg<CFG>(LoadKContig<BM, true>{A, K, M}, bl, ep, M, Npix, K, splits, s);
-    return launch_cfg<CFG>(LoadKContig<BM, false>{A, K, M}, bl, ep, M, Npix, K, splits, s);
+  if (MODE == 0 && two) {                                 // channel-concatenated sources only exist on the forward gather
+    if (vec) {
+      if (nomask) return launch_cfg<CFG>(LoadKContig<BM, true, false>{A, K, M}, LoadGatherKN<BN, KS, MODE, true, false>{g, Npix, ktab}, ep, M, Npix, K, splits, s);
+      return launch_cfg<CFG>(LoadKContig<BM, true>{A, K, M}, LoadGatherKN<BN, KS, MODE, true>{g, Npix, ktab}, ep, M, Npix, K, splits, s);
+    }
+    return launch_cfg<CFG>(LoadKContig<BM, false>{A, K, M}, LoadGatherKN<BN, KS, MODE, true>{g, Npix, ktab}, ep, M, Npix, K, splits, s);
   }
-  LoadGatherKN<BN, KS, MODE, false> bl{g, Npix, ktab};
-  if (vec) return launch_cfg<CFG>(LoadKContig<BM, true>{A, K, M}, bl, ep, M, Npix, K, splits, s);
-  return launch_cfg<CFG>(LoadKContig<BM, false>{A, K, M}, bl, ep, M, Npix, K, splits, s);
+  if (vec) {
+    if (nomask) return launch_cfg<CFG>(LoadKContig<BM, true, false>{A, K, M}, LoadGatherKN<BN, KS, MODE, false, false>{g, Npix, ktab}, ep, M, Npix, K, splits, s);
+    return launch_cfg<CFG>(LoadKContig<BM, true>{A, K, M}, LoadGatherKN<BN, KS, MODE, false>{g, Npix, ktab}, ep, M, Npix, K, splits, s);
+  }
+  return launch_cfg<CFG>(LoadKContig<BM, false>{A, K, M}, LoadGatherKN<BN, KS, MODE, false>{g, Npix, ktab}, ep, M, Npix, K, splits, s);
 }
 
 // split-K for conv-shaped GEMMs that would otherwise leave most CUs idle (few output tiles, long K): e.g. the
@@ -623,25 +680,30 @@ int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* b
            float slope, double flops, void* ktab_ws, size_t ws_avail, hipStream_t s) {
   const int Npix = NB * g.PH * g.PW;
   KEntry* ktab = reinterpret_cast<KEntry*>(ktab_ws);
+  const bool vec = (K % 4 == 0) && aligned16(A);
+  int tile = pick_tile(M, Npix);
+  if (!vec && tile == 0) tile = 1;                  // the scalar-A variant is only instantiated for the small tiles
+  const int tBM = tile == 0 ? 128 : (tile == 1 ? 64 : 32), tBN = tile == 1 ? 64 : 128;
+  // mask-free kernels: reflection padding (every tap valid), full pixel tiles, full M tiles; a K tail is legal because
+  // the A operand... would need masking -- so also require K % 16 == 0
+  const bool nomask = MODE == 0 && vec && g.reflect && (Npix % tBN == 0) && (M % tBM == 0) && (K % BK == 0);
   float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ktab_ws) + ktab_bytes(K));
   int splits = (Mtot == M) ? kn_splits(M, Npix, K) : 1;
   if (splits > 1 && ws_avail < ktab_bytes(K) + (size_t)splits * M * Npix * sizeof(float)) splits = 1;
   {
     const int Kpad = sg_cdiv(K, 64) * 64 + 128;      // the k-loop prefetches entries up to two tiles past the end
     hipLaunchKernelGGL(build_ktab_kernel, dim3(sg_cdiv(Kpad, 256)), dim3(256), 0, s, ktab, K, Kpad, KS * KS, g.C1, g.C2,
-                       (unsigned)(g.SH * g.SW), g.bcast2);
+                       (unsigned)(g.SH * g.SW), g.bcast2, nomask ? 1 : 0);
   }
   const size_t nout = (size_t)M * Npix;
   EpNCHW ep{out, bias, g.PH * g.PW, Mtot, M, Npix, act, slope, 0};
   if (splits > 1) ep = EpNCHW{slabs, nullptr, g.PH * g.PW, Mtot, M, Npix, SG_ACT_NONE, 0.f, nout};
-  const bool vec = (K % 4 == 0) && aligned16(A);
-  const int tile = pick_tile(M, Npix);
   {
     SgProfScope prof(sg_igemm_kind(MODE, KS, tile), s, flops, 0);
     switch (tile) {
-      case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, s); break;
-      case 1: launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, s); break;
-      default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, s); break;
+      case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, MODE>(A, K, M, true, g, Npix, ktab, ep, splits, nomask, s); break;
+      case 1: launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, nomask, s); break;
+      default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, nomask, s); break;
     }
   }
   if (splits > 1)
@@ -689,19 +751,20 @@ int run_nk(const float* A, int M, int Mtot, const Gather& g, int NB, float* out,
   const int tile = M <= 32 ? 2 : ((long)sg_cdiv(M, 128) * sg_cdiv(Ncols, 128) >= 384 ? 0 : 1);
   {
     SgProfScope prof(sg_igemm_kind(2, KS, tile), s, flops, 0);
-    if (tile == 2) {
-      LoadPixK<32> al{A, M, Mtot, PQ};
-      LoadGatherNK<128, KS> bl{g, Ncols};
-      launch_cfg<Cfg32>(al, bl, ep, M, Ncols, Kpix, splits, s);
-    } else if (tile == 0) {
-      LoadPixK<128> al{A, M, Mtot, PQ};
-      LoadGatherNK<128, KS> bl{g, Ncols};
-      launch_cfg<Cfg128>(al, bl, ep, M, Ncols, Kpix, splits, s);
-    } else {
-      LoadPixK<64> al{A, M, Mtot, PQ};
-      LoadGatherNK<64, KS> bl{g, Ncols};
-      launch_cfg<Cfg64>(al, bl, ep, M, Ncols, Kpix, splits, s);
-    }
+    const bool two = g.C2 > 0;
+    const int tBM = tile == 0 ? 128 : (tile == 1 ? 64 : 32);
+    // mask-free: reflection padding, full M tiles, whole 16-pixel k-tiles (split chunks are multiples of 64)
+    const bool nomask = !two && g.reflect && (M % tBM == 0) && (Kpix % BK == 0);
+#define SG_NK_LAUNCH(CFGT, BMv, BNv)                                                               \
+  do {                                                                                             \
+    if (two) { launch_cfg<CFGT>(LoadPixK<BMv>{A, M, Mtot, PQ}, LoadGatherNK<BNv, KS, true>{g, Ncols}, ep, M, Ncols, Kpix, splits, s); } \
+    else if (nomask) { launch_cfg<CFGT>(LoadPixK<BMv, false>{A, M, Mtot, PQ}, LoadGatherNK<BNv, KS, false, false>{g, Ncols}, ep, M, Ncols, Kpix, splits, s); } \
+    else { launch_cfg<CFGT>(LoadPixK<BMv>{A, M, Mtot, PQ}, LoadGatherNK<BNv, KS, false>{g, Ncols}, ep, M, Ncols, Kpix, splits, s); }    \
+  } while (0)
+    if (tile == 2) SG_NK_LAUNCH(Cfg32, 32, 128);
+    else if (tile == 0) SG_NK_LAUNCH(Cfg128, 128, 128);
+    else SG_NK_LAUNCH(Cfg64, 64, 64);
+#undef SG_NK_LAUNCH
   }
   if (splits > 1) {
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(sg_cdiv(mn, 256)), dim3(256), 0, s, (const float*)ws, out, mn,
