@@ -89,12 +89,12 @@ def main():
     tr.model.layout_objects_hint = 9
     # two pre-staged batches per rank (different data per rank: weak scaling), resident in HBM
     batches = [batch_to(make_batch(N=B, min_objs=3, max_objs=8, size=S, seed=1000 * rank + i), dev) for i in range(2)]
-    hosts = [b.objs.tolist() for b in batches]
+    hosts = [(b.objs.tolist(), b.obj_to_img.tolist()) for b in batches]
     random.seed(0)                                # the use_gt coin (train.py:195) must agree on all ranks: it decides
     torch.manual_seed(100 + rank)                 # which parameters receive gradients (and hence Adam updates)
 
     def one_step(i):
-        tr.model.objs_host = hosts[i % 2]
+        tr.model.objs_host, tr.model.obj_to_img_host = hosts[i % 2]
         tr.step(batches[i % 2], use_gt=random.randint(0, 1) != 0)      # train.py:195
 
     for i in range(a.warmup):

@@ -69,6 +69,18 @@ int sg_conv2d_dgrad(const sgConvDesc* d, const float* gy, const float* w, float*
 /* gw[Cout, C1+C2, KS, KS] (+ gb[Cout] if non-null) */
 int sg_conv2d_wgrad(const sgConvDesc* d, const float* gy, const float* x1, const float* x2, float* gw, float* gb,
                     void* ws, size_t ws_bytes, sgStream stream);
+/* Channel-sparse variants for a layer whose input is a masks_to_layout() layout (reference model.py:165-168 and
+   layout.py:64-93: per image only the one-hot planes of the classes present and the dense representation block are
+   non-zero).  chan_list [N, L] int32: ascending concat-channel ids (over x1|x2) that may be non-zero in image n, the
+   first chan_cnt[n] (<= L) entries are used; every other channel of that image MUST be all-zero or the result
+   differs from sg_conv2d_fwd / sg_conv2d_wgrad.  Same outputs as the dense calls (different summation order). */
+size_t sg_conv2d_sparse_ws_bytes(const sgConvDesc* d, int L, int kind /* 0 fwd, 2 wgrad */);
+int sg_conv2d_fwd_sparse(const sgConvDesc* d, const float* x1, const float* x2, const float* w, const float* bias,
+                         const int32_t* chan_list, const int32_t* chan_cnt, int L, float* y, int act, float slope,
+                         void* ws, size_t ws_bytes, sgStream stream);
+int sg_conv2d_wgrad_sparse(const sgConvDesc* d, const float* gy, const float* x1, const float* x2,
+                           const int32_t* chan_list, const int32_t* chan_cnt, int L, float* gw, float* gb,
+                           void* ws, size_t ws_bytes, sgStream stream);
 /* nn.ConvTranspose2d(k3,s2,p1,op1) : w [Cin, Cout, KS, KS]; desc.H,W = input size, OH,OW = output size */
 int sg_convT2d_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y,
                    void* ws, size_t ws_bytes, sgStream stream);

@@ -61,6 +61,7 @@ struct LoadKContig {
   struct Stage { float r[PASSES * 4]; unsigned ok; };
   int x0_, xr_, kq_;
   __device__ __forceinline__ void init(int x0, int tid, int*, int, int) { x0_ = x0; xr_ = tid >> 2; kq_ = (tid & 3) * 4; }
+  __device__ __forceinline__ void set_batch(int b, int stride, int) { base += (size_t)b * (size_t)stride; }
   __device__ __forceinline__ void prefetch(Stage&, int) const {}
   __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
     st.ok = 0;
@@ -134,6 +135,7 @@ struct LoadXContig {
   struct Stage { float r[ROWS]; unsigned ok; };
   int x_, xl_, kr_;
   __device__ __forceinline__ void init(int x0, int tid, int*, int, int) { xl_ = tid % BX; x_ = x0 + xl_; kr_ = (tid / BX) * ROWS; }
+  __device__ __forceinline__ void set_batch(int, int, int) {}
   __device__ __forceinline__ void prefetch(Stage&, int) const {}
   __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
     st.ok = 0;
@@ -219,6 +221,7 @@ struct LoadGatherKN {
   unsigned img1_, img2_, img2b_;
   int nl_, kr_;
   const int* tab_;
+  __device__ __forceinline__ void set_batch(int b, int stride, int limit) { ktab += (size_t)b * (size_t)stride; Npix = limit; }
   __device__ __forceinline__ void init(int n0, int tid, int* tab, int, int) {
     nl_ = tid % BN;
     const int grp = tid / BN;
@@ -279,6 +282,7 @@ struct LoadPixK {
   struct Stage { float r[ROWS]; unsigned ok; };
   int m0_, mr_, kl_;
   __device__ __forceinline__ void init(int m0, int tid, int*, int, int) { m0_ = m0; kl_ = tid & 15; mr_ = tid >> 4; }
+  __device__ __forceinline__ void set_batch(int, int, int) {}
   __device__ __forceinline__ void prefetch(Stage&, int) const {}
   __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
     const int k = k0 + kl_;
@@ -318,6 +322,7 @@ __device__ __forceinline__ int axis_offset(int a, int k, int L, int reflect, int
 template <int BN, int KS, bool TWO, bool MASK = true>
 struct LoadGatherNK {
   Gather g; int Ncols;
+  const int* chan_list; const int* chan_cnt; int L;     // optional per-image active-channel lists (image = blockIdx.z)
   static constexpr int KS2 = KS * KS;
   // per k-tile LDS table (separable): rowoff[KS][16] (= ih*SW or -1), coloff[KS][16] (= iw or -1), one all -1 row,
   // img1[16], img2[16]
@@ -330,17 +335,21 @@ struct LoadGatherNK {
   unsigned choff_[COLS], secmask_;
   int rrow_[COLS], crow_[COLS];
   int* lds_;
+  __device__ __forceinline__ void set_batch(int, int, int) {}
   __device__ __forceinline__ void init(int n0, int tid, int* lds, int kbeg, int kend) {
     kl_ = tid & 15; nr_ = tid >> 4; tid_ = tid; lds_ = lds; kbeg_ = kbeg; kend_ = kend;
     const unsigned shw = (unsigned)(g.SH * g.SW);
+    const int* list = chan_list ? chan_list + (size_t)blockIdx.z * L : nullptr;
+    const int ncols = chan_list ? chan_cnt[blockIdx.z] * KS2 : Ncols;
     secmask_ = 0;
 #pragma unroll
     for (int j = 0; j < COLS; ++j) {
       const int n = n0 + nr_ + 16 * j;
-      const bool ok = n < Ncols;
+      const bool ok = n < ncols;
       const int nn = ok ? n : 0;
-      const int c = nn / KS2;
-      const int t = nn - c * KS2;
+      const int cj = nn / KS2;
+      const int t = nn - cj * KS2;
+      const int c = list ? list[cj] : cj;
       const int kh = t / KS, kw = t - kh * KS;
       const bool second = TWO && c >= g.C1;
       const unsigned cc = (unsigned)(second ? c - g.C1 : c);
@@ -410,6 +419,7 @@ struct LoadGatherNK {
 // ------------------------------------------------------------------------------------------------
 struct EpNCHW {     // out[z][img][m][pix], n = img*PHW + pix ; bias per row m (z = split-K slab, raw partials)
   float* out; const float* bias; int PHW, Mtot, M, Npix, act; float slope; size_t zstride;
+  __device__ __forceinline__ void set_limit(int n) { Npix = n; }
   template <int TM, int TN>
   __device__ __forceinline__ void store(f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int z) const {
 #pragma unroll
@@ -436,6 +446,7 @@ struct EpNCHW {     // out[z][img][m][pix], n = img*PHW + pix ; bias per row m (
 
 struct EpRowMajor {  // out[z][m*ldc + n] ; bias per column n
   float* out; const float* bias; int M, N, ldc, act; float slope; size_t zstride;
+  __device__ __forceinline__ void set_limit(int) {}
   template <int TM, int TN>
   __device__ __forceinline__ void store(f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int z) const {
     float* o = out + (size_t)z * zstride;
@@ -459,8 +470,11 @@ struct EpRowMajor {  // out[z][m*ldc + n] ; bias per column n
 // ------------------------------------------------------------------------------------------------
 // The kernel
 // ------------------------------------------------------------------------------------------------
+// Batched mode (channel-sparse first layers): the N axis is split into `nbatch` images of `cols_per_batch` columns,
+// tiles never straddle images, and each image has its own compact A operand, k-table and K extent.
+struct BatchInfo { int cols_per_batch; int nbatch; const int* kcnt; int a_stride; int b_stride; };
 template <class CFG, class AL, class BL, class EP>
-__global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int kchunk) {
+__global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int kchunk, BatchInfo bi) {
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, LDA = CFG::LDA, LDB = CFG::LDB;
   constexpr int NSUB = CFG::NSUB, BKT = CFG::BKT;
   __shared__ __attribute__((aligned(16))) float As[2][NSUB * BM * LDK];
@@ -471,16 +485,26 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   const int wm0 = (wid / CFG::WGN) * CFG::WM, wn0 = (wid % CFG::WGN) * CFG::WN;
 
   // XCD-aware, bijective tile remap: consecutive tiles (same weight rows, overlapping gathers) share an L2
-  const int tiles_n = (N + BN - 1) / BN;
+  const int tiles_pb = bi.cols_per_batch > 0 ? (bi.cols_per_batch + BN - 1) / BN : 0;
+  const int tiles_n = bi.cols_per_batch > 0 ? bi.nbatch * tiles_pb : (N + BN - 1) / BN;
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
   {
     const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   }
-  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  const int m0 = (bid / tiles_n) * BM;
+  int n0 = (bid % tiles_n) * BN;
   const int kbeg = blockIdx.z * kchunk;
-  const int kend = min(K, kbeg + kchunk);
+  int kend = min(K, kbeg + kchunk);
+  if (bi.cols_per_batch > 0) {
+    const int tn = bid % tiles_n, batch = tn / tiles_pb;
+    n0 = batch * bi.cols_per_batch + (tn - batch * tiles_pb) * BN;
+    kend = min(kend, bi.kcnt[batch]);
+    al.set_batch(batch, bi.a_stride, 0);
+    bl.set_batch(batch, bi.b_stride, (batch + 1) * bi.cols_per_batch);
+    ep.set_limit((batch + 1) * bi.cols_per_batch);
+  }
 
   al.init(m0, tid, tapA, kbeg, kend);
   bl.init(n0, tid, tapB, kbeg, kend);
@@ -581,13 +605,21 @@ inline int pick_tile(int M, int N) {
   return 1;
 }
 
+// thread-local launch modifiers (set by the sparse entry points around a regular dispatch)
+thread_local BatchInfo t_batch = {0, 0, nullptr, 0, 0};
+struct Sparse { const int* list; const int* cnt; int L; };   // per-image ascending active-channel lists
+thread_local Sparse t_sp = {nullptr, nullptr, 0};
+thread_local int t_fixed_kchunk = 0;        // >0: grid.z = ceil(K / chunk) with exactly this chunk (one image per z)
+
 template <class CFG, class AL, class BL, class EP>
 int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int splits, hipStream_t s) {
-  const int tiles = sg_cdiv(M, CFG::BM) * sg_cdiv(N, CFG::BN);
+  int tiles = sg_cdiv(M, CFG::BM) * sg_cdiv(N, CFG::BN);
+  if (t_batch.cols_per_batch > 0) tiles = sg_cdiv(M, CFG::BM) * t_batch.nbatch * sg_cdiv(t_batch.cols_per_batch, CFG::BN);
   int kchunk = K;
   if (splits > 1) kchunk = sg_cdiv(sg_cdiv(K, splits), CFG::BKT) * CFG::BKT;
-  dim3 grid(tiles, 1, splits > 1 ? sg_cdiv(K, kchunk) : 1);
-  hipLaunchKernelGGL((igemm_kernel<CFG, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, N, K, kchunk);
+  if (t_fixed_kchunk > 0) kchunk = t_fixed_kchunk;
+  dim3 grid(tiles, 1, (splits > 1 || t_fixed_kchunk > 0) ? sg_cdiv(K, kchunk) : 1);
+  hipLaunchKernelGGL((igemm_kernel<CFG, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, N, K, kchunk, t_batch);
   return 0;
 }
 
@@ -712,6 +744,79 @@ int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* b
   return 0;
 }
 
+// ---- channel-sparse conv forward ---------------------------------------------------------------------
+// A masks_to_layout() layout has, per image, only the one-hot channels of the classes present plus the dense
+// representation block non-zero (model.py:165-168 of the reference builds it that way): ~40 of 204 channels.
+// Per image b the builder below makes a compact weight matrix Wc[b][m][k'] (k' = j*KS2 + t over the image's
+// active channels list[b][j], zero padded to Kc), the matching k-table, and the K extent; the regular kernel then
+// runs in batched mode (tiles never straddle images).
+__global__ void build_sparse_fwd_kernel(const float* W, int M, int K, int KS2, int C1, int C2, unsigned shw, int bcast2,
+                                        const int* list, const int* cnt, int L, int Kc, int Kpad, float* Wc,
+                                        KEntry* ktab, int* kcnt, int tail_valid) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = cnt[b];
+  if (i < M * Kc) {
+    const int m = i / Kc, k = i - m * Kc;
+    const int j = k / KS2, t = k - j * KS2;
+    Wc[((size_t)b * M + m) * Kc + k] = j < n ? W[(size_t)m * K + list[b * L + j] * KS2 + t] : 0.f;
+  }
+  if (i < Kpad) {
+    const int j = i / KS2, t = i - j * KS2;
+    KEntry e;
+    if (j < n) {
+      const int c = list[b * L + j];
+      const bool second = C2 > 0 && c >= C1;
+      const unsigned cc = (unsigned)(second ? c - C1 : c);
+      e.choff = (second && bcast2) ? cc : cc * shw;
+      e.tapsel = (unsigned)t | (second ? 256u : 0u);
+    } else {
+      e.choff = 0u; e.tapsel = tail_valid ? 0u : (unsigned)KS2;     // Wc is zero there
+    }
+    ktab[(size_t)b * Kpad + i] = e;
+  }
+  if (i == 0) kcnt[b] = ((n * KS2 + BK - 1) / BK) * BK;
+}
+
+inline int sparse_kc(int L, int KS2) { return sg_cdiv(L * KS2, BK) * BK; }
+inline int sparse_kpad(int L, int KS2) { return sg_cdiv(sparse_kc(L, KS2), 64) * 64 + 128; }
+inline size_t sparse_fwd_ws(int NB, int M, int L, int KS2) {
+  return (size_t)NB * ((size_t)sparse_kpad(L, KS2) * sizeof(KEntry) + (size_t)M * sparse_kc(L, KS2) * sizeof(float) + 64);
+}
+
+template <int KS>
+int run_kn_sparse(const float* W, int M, int K, const Gather& g, int NB, const float* bias, float* out, int act,
+                  float slope, const Sparse& sp, void* ws, hipStream_t s) {
+  constexpr int KS2 = KS * KS;
+  const int PHW = g.PH * g.PW, Npix = NB * PHW;
+  const int Kc = sparse_kc(sp.L, KS2), Kpad = sparse_kpad(sp.L, KS2);
+  KEntry* ktab = reinterpret_cast<KEntry*>(ws);
+  float* Wc = reinterpret_cast<float*>(ktab + (size_t)NB * Kpad);
+  int* kcnt = reinterpret_cast<int*>(Wc + (size_t)NB * M * Kc);
+  int tile = pick_tile(M, Npix);
+  const int tBM = tile == 0 ? 128 : (tile == 1 ? 64 : 32), tBN = tile == 1 ? 64 : 128;
+  const bool nomask = g.reflect && (PHW % tBN == 0) && (M % tBM == 0);
+  {
+    const int work = M * Kc > Kpad ? M * Kc : Kpad;
+    hipLaunchKernelGGL(build_sparse_fwd_kernel, dim3(sg_cdiv(work, 256), NB), dim3(256), 0, s, W, M, K, KS2, g.C1, g.C2,
+                       (unsigned)(g.SH * g.SW), g.bcast2, sp.list, sp.cnt, sp.L, Kc, Kpad, Wc, ktab, kcnt, nomask ? 1 : 0);
+  }
+  EpNCHW ep{out, bias, PHW, M, M, Npix, act, slope, 0};
+  // flops actually issued: the padded compact K of every image (bench.py prices the dominant kernel with this)
+  const double flops = 2.0 * M * (double)Kc * Npix;
+  t_batch = BatchInfo{PHW, NB, kcnt, M * Kc, Kpad};
+  {
+    SgProfScope prof(sg_igemm_kind(0, KS, tile), s, flops, 0);
+    switch (tile) {
+      case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, 0>(Wc, Kc, M, true, g, Npix, ktab, ep, 1, nomask, s); break;
+      case 1: launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, 0>(Wc, Kc, M, true, g, Npix, ktab, ep, 1, nomask, s); break;
+      default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, 0>(Wc, Kc, M, true, g, Npix, ktab, ep, 1, nomask, s); break;
+    }
+  }
+  t_batch = BatchInfo{0, 0, nullptr, 0, 0};
+  return 0;
+}
+
 template <int MODE>
 int run_kn_ks(int KS, const float* A, int M, int K, const Gather& g, int NB, const float* bias, float* out, int Mtot,
               int act, float slope, double flops, void* ktab_ws, size_t ws_avail, hipStream_t s) {
@@ -725,6 +830,33 @@ int run_kn_ks(int KS, const float* A, int M, int K, const Gather& g, int NB, con
 }
 
 // ---- wgrad-shaped GEMM: K = (img, pix), N = (c, taps) --------------------------------------------
+// inverse of the per-image channel lists: inv[b][c] = position of c in list[b] or -1
+__global__ void sparse_inv_kernel(const int* list, const int* cnt, int L, int C, int* inv) {
+  const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  int pos = -1;
+  const int n = cnt[b];
+  for (int j = 0; j < n; ++j) pos = list[b * L + j] == c ? j : pos;
+  inv[b * C + c] = pos;
+}
+// gw[m][c][t] = sum_b slab[b][m][inv[b][c]][t]  (images in ascending order => deterministic)
+__global__ void sparse_wgrad_reduce_kernel(const float* slabs, const int* inv, float* gw, int M, int C, int KS2, int L,
+                                           int NB) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * C * KS2) return;
+  const int t = (int)(i % KS2);
+  const int c = (int)((i / KS2) % C);
+  const int m = (int)(i / ((size_t)KS2 * C));
+  float v = 0.f;
+  for (int b = 0; b < NB; ++b) {
+    const int j = inv[b * C + c];
+    if (j >= 0) v += slabs[(((size_t)b * M + m) * L + j) * KS2 + t];
+  }
+  gw[i] = v;
+}
+inline size_t sparse_wgrad_ws(int NB, int M, int C, int L, int KS2) {
+  return (size_t)NB * M * L * KS2 * sizeof(float) + (size_t)NB * C * sizeof(int);
+}
 inline int wgrad_splits(int M, int Ncols, int Kpix) {
   const long tiles = (long)sg_cdiv(M, M <= 32 ? 32 : 64) * sg_cdiv(Ncols, M <= 32 ? 128 : 64);
   int s = (int)((768 + tiles - 1) / tiles);
@@ -736,17 +868,20 @@ inline int wgrad_splits(int M, int Ncols, int Kpix) {
 
 template <int KS>
 int run_nk(const float* A, int M, int Mtot, const Gather& g, int NB, float* out, void* ws, size_t ws_bytes,
-           double flops, hipStream_t s) {
+           double flops, hipStream_t s, const Sparse* sp = nullptr) {
   const int PQ = g.PH * g.PW;
   const int Kpix = NB * PQ;
-  const int Ncols = (g.C1 + g.C2) * KS * KS;
-  int splits = wgrad_splits(M, Ncols, Kpix);
+  // channel-sparse input (see run_kn_sparse): one k-chunk per image, compact columns, per-image slabs that
+  // sparse_wgrad_reduce_kernel scatters back to the dense gradient in a fixed order
+  const int Ncols = (sp ? sp->L : g.C1 + g.C2) * KS * KS;
+  int splits = sp ? NB : wgrad_splits(M, Ncols, Kpix);
   const size_t mn = (size_t)M * Ncols;
-  if (splits > 1 && ws_bytes < mn * sizeof(float) * (size_t)splits) splits = (int)(ws_bytes / (mn * sizeof(float)));
-  if (splits < 2) splits = 1;
-  int kchunk = sg_cdiv(sg_cdiv(Kpix, splits), 64) * 64;      // multiple of every BKT
+  if (!sp && splits > 1 && ws_bytes < mn * sizeof(float) * (size_t)splits) splits = (int)(ws_bytes / (mn * sizeof(float)));
+  if (splits < 2 && !sp) splits = 1;
+  int kchunk = sp ? PQ : sg_cdiv(sg_cdiv(Kpix, splits), 64) * 64;      // multiple of every BKT
   splits = sg_cdiv(Kpix, kchunk);
-  float* dst = splits > 1 ? reinterpret_cast<float*>(ws) : out;
+  if (sp) { t_sp = *sp; t_fixed_kchunk = PQ; flops = 2.0 * M * (double)Ncols * Kpix; }
+  float* dst = (splits > 1 || sp) ? reinterpret_cast<float*>(ws) : out;
   EpRowMajor ep{dst, nullptr, M, Ncols, Ncols, SG_ACT_NONE, 0.f, mn};
   const int tile = M <= 32 ? 2 : ((long)sg_cdiv(M, 128) * sg_cdiv(Ncols, 128) >= 384 ? 0 : 1);
   {
@@ -754,17 +889,27 @@ int run_nk(const float* A, int M, int Mtot, const Gather& g, int NB, float* out,
     const bool two = g.C2 > 0;
     const int tBM = tile == 0 ? 128 : (tile == 1 ? 64 : 32);
     // mask-free: reflection padding, full M tiles, whole 16-pixel k-tiles (split chunks are multiples of 64)
-    const bool nomask = !two && g.reflect && (M % tBM == 0) && (Kpix % BK == 0);
+    const bool nomask = !two && g.reflect && (M % tBM == 0) && (Kpix % BK == 0) && (!sp || PQ % BK == 0);
 #define SG_NK_LAUNCH(CFGT, BMv, BNv)                                                               \
   do {                                                                                             \
-    if (two) { launch_cfg<CFGT>(LoadPixK<BMv>{A, M, Mtot, PQ}, LoadGatherNK<BNv, KS, true>{g, Ncols}, ep, M, Ncols, Kpix, splits, s); } \
-    else if (nomask) { launch_cfg<CFGT>(LoadPixK<BMv, false>{A, M, Mtot, PQ}, LoadGatherNK<BNv, KS, false, false>{g, Ncols}, ep, M, Ncols, Kpix, splits, s); } \
-    else { launch_cfg<CFGT>(LoadPixK<BMv>{A, M, Mtot, PQ}, LoadGatherNK<BNv, KS, false>{g, Ncols}, ep, M, Ncols, Kpix, splits, s); }    \
+    if (two) { launch_cfg<CFGT>(LoadPixK<BMv>{A, M, Mtot, PQ}, LoadGatherNK<BNv, KS, true>{g, Ncols, t_sp.list, t_sp.cnt, t_sp.L}, ep, M, Ncols, Kpix, splits, s); } \
+    else if (nomask) { launch_cfg<CFGT>(LoadPixK<BMv, false>{A, M, Mtot, PQ}, LoadGatherNK<BNv, KS, false, false>{g, Ncols, t_sp.list, t_sp.cnt, t_sp.L}, ep, M, Ncols, Kpix, splits, s); } \
+    else { launch_cfg<CFGT>(LoadPixK<BMv>{A, M, Mtot, PQ}, LoadGatherNK<BNv, KS, false>{g, Ncols, t_sp.list, t_sp.cnt, t_sp.L}, ep, M, Ncols, Kpix, splits, s); }    \
   } while (0)
     if (tile == 2) SG_NK_LAUNCH(Cfg32, 32, 128);
     else if (tile == 0) SG_NK_LAUNCH(Cfg128, 128, 128);
     else SG_NK_LAUNCH(Cfg64, 64, 64);
 #undef SG_NK_LAUNCH
+  }
+  if (sp) {
+    t_sp = Sparse{nullptr, nullptr, 0}; t_fixed_kchunk = 0;
+    const int C = g.C1 + g.C2;
+    int* inv = reinterpret_cast<int*>(reinterpret_cast<float*>(ws) + (size_t)NB * mn);
+    hipLaunchKernelGGL(sparse_inv_kernel, dim3(sg_cdiv(C, 256), NB), dim3(256), 0, s, sp->list, sp->cnt, sp->L, C, inv);
+    const size_t n = (size_t)M * C * KS * KS;
+    hipLaunchKernelGGL(sparse_wgrad_reduce_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, (const int*)inv,
+                       out, M, C, KS * KS, sp->L, NB);
+    return 0;
   }
   if (splits > 1) {
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(sg_cdiv(mn, 256)), dim3(256), 0, s, (const float*)ws, out, mn,
@@ -774,12 +919,12 @@ int run_nk(const float* A, int M, int Mtot, const Gather& g, int NB, float* out,
 }
 
 int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, float* out, void* ws, size_t ws_bytes,
-              double flops, hipStream_t s) {
+              double flops, hipStream_t s, const Sparse* sp = nullptr) {
   switch (KS) {
-    case 1: return run_nk<1>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s);
-    case 3: return run_nk<3>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s);
-    case 4: return run_nk<4>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s);
-    case 7: return run_nk<7>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s);
+    case 1: return run_nk<1>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s, sp);
+    case 3: return run_nk<3>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s, sp);
+    case 4: return run_nk<4>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s, sp);
+    case 7: return run_nk<7>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s, sp);
   }
   return -1;
 }
@@ -890,6 +1035,58 @@ extern "C" int sg_conv2d_wgrad(const sgConvDesc* d, const float* gy, const float
 }
 
 // ConvTranspose2d: y[n,co,oh,ow] = b + sum_{ci,kh,kw} w[ci,co,kh,kw] x[n,ci,(oh+p-kh)/s,(ow+p-kw)/s]
+
+// ---- channel-sparse variants (layers fed by a masks_to_layout() layout) ---------------------------
+static int check_sparse(const sgConvDesc* d, const int32_t* list, const int32_t* cnt, int L, const char* who) {
+  SG_ARG_CHECK(list && cnt, "%s: null channel list", who);
+  SG_ARG_CHECK(L > 0 && L <= d->C1 + d->C2, "%s: L=%d outside (0, %d]", who, L, d->C1 + d->C2);
+  return 0;
+}
+extern "C" size_t sg_conv2d_sparse_ws_bytes(const sgConvDesc* d, int L, int kind) {
+  if (!d || L <= 0) return 0;
+  const int KS2 = d->KS * d->KS;
+  if (kind == 0) return sparse_fwd_ws(d->N, d->Cout, L, KS2);
+  const size_t a = sparse_wgrad_ws(d->N, d->Cout, d->C1 + d->C2, L, KS2), cs = sg_channel_sum_ws_bytes(d->Cout);
+  return a > cs ? a : cs;
+}
+extern "C" int sg_conv2d_fwd_sparse(const sgConvDesc* d, const float* x1, const float* x2, const float* w,
+                                    const float* bias, const int32_t* chan_list, const int32_t* chan_cnt, int L, float* y,
+                                    int act, float slope, void* ws, size_t ws_bytes, sgStream stream) {
+  if (check_desc(d, "sg_conv2d_fwd_sparse") || check_sparse(d, chan_list, chan_cnt, L, "sg_conv2d_fwd_sparse")) return -1;
+  SG_ARG_CHECK(x1 && w && y && ws, "sg_conv2d_fwd_sparse: null pointer");
+  SG_ARG_CHECK(d->C2 == 0 || x2, "sg_conv2d_fwd_sparse: C2>0 but x2 null");
+  SG_ARG_CHECK(ws_bytes >= sg_conv2d_sparse_ws_bytes(d, L, 0), "sg_conv2d_fwd_sparse: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int K = (d->C1 + d->C2) * d->KS * d->KS;
+  Gather g = make_gather(x1, x2, d->C1, d->C2, d->H, d->W, d->upsample, d->OH, d->OW, d->stride, d->pad, d->pad_reflect);
+  g.bcast2 = d->x2_broadcast;
+  const Sparse sp{chan_list, chan_cnt, L};
+  int rc = -1;
+  switch (d->KS) {
+    case 1: rc = run_kn_sparse<1>(w, d->Cout, K, g, d->N, bias, y, act, slope, sp, ws, s); break;
+    case 3: rc = run_kn_sparse<3>(w, d->Cout, K, g, d->N, bias, y, act, slope, sp, ws, s); break;
+    case 4: rc = run_kn_sparse<4>(w, d->Cout, K, g, d->N, bias, y, act, slope, sp, ws, s); break;
+    case 7: rc = run_kn_sparse<7>(w, d->Cout, K, g, d->N, bias, y, act, slope, sp, ws, s); break;
+  }
+  SG_LAUNCH_CHECK("sg_conv2d_fwd_sparse");
+  return rc;
+}
+extern "C" int sg_conv2d_wgrad_sparse(const sgConvDesc* d, const float* gy, const float* x1, const float* x2,
+                                      const int32_t* chan_list, const int32_t* chan_cnt, int L, float* gw, float* gb,
+                                      void* ws, size_t ws_bytes, sgStream stream) {
+  if (check_desc(d, "sg_conv2d_wgrad_sparse") || check_sparse(d, chan_list, chan_cnt, L, "sg_conv2d_wgrad_sparse")) return -1;
+  SG_ARG_CHECK(gy && x1 && gw && ws, "sg_conv2d_wgrad_sparse: null pointer");
+  SG_ARG_CHECK(d->C2 == 0 || x2, "sg_conv2d_wgrad_sparse: C2>0 but x2 null");
+  SG_ARG_CHECK(ws_bytes >= sg_conv2d_sparse_ws_bytes(d, L, 2), "sg_conv2d_wgrad_sparse: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  Gather g = make_gather(x1, x2, d->C1, d->C2, d->H, d->W, d->upsample, d->OH, d->OW, d->stride, d->pad, d->pad_reflect);
+  g.bcast2 = d->x2_broadcast;
+  const Sparse sp{chan_list, chan_cnt, L};
+  run_nk_ks(d->KS, gy, d->Cout, d->Cout, g, d->N, gw, ws, ws_bytes, 0.0, s, &sp);
+  SG_LAUNCH_CHECK("sg_conv2d_wgrad_sparse");
+  if (gb) return sg_channel_sum(gy, gb, d->N, d->Cout, d->OH * d->OW, ws, ws_bytes, stream);
+  return 0;
+}
 extern "C" int sg_convT2d_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y,
                               void* ws, size_t ws_bytes, sgStream stream) {
   if (check_desc(d, "sg_convT2d_fwd")) return -1;

@@ -15,7 +15,7 @@ from .generators import mask_net, AppearanceEncoder, define_G
 from .graph import GraphTripleConv, GraphTripleConvNet
 from .layers import build_mlp, Embedding, Linear
 from .layout import masks_to_layout
-from .utils import VectorPool
+from .utils import VectorPool, active_layout_channels
 
 
 class Model(nn.Module):
@@ -69,7 +69,9 @@ class Model(nn.Module):
         # hooks that are not part of the reference surface
         self.noise_override = None          # (1, mask_noise_dim) row used instead of torch.randn (parity tests)
         self.layout_objects_hint = 0        # objects/image the layout kernel provisions LDS for (0 = default 12)
-        self.objs_host = None               # optional host copy of ``objs`` (skips VectorPool's D2H copy)
+        self.objs_host = None               # optional host copies of ``objs`` / ``obj_to_img`` (lists): skip the one
+        self.obj_to_img_host = None         # D2H copy per forward that VectorPool and the sparse first conv need
+        self.rep_size = rep_size
 
     def forward(self, gt_imgs, objs, triples, obj_to_img, boxes_gt=None, masks_gt=None, attributes=None,
                 test_mode=False, use_gt_box=False, features=None):
@@ -77,9 +79,12 @@ class Model(nn.Module):
             raise NotImplementedError('Model.forward(test_mode=True) (model.py:111-117) is SURVEY 8f rank 1 (next)')
         O = objs.size(0)
         N = gt_imgs.size(0)
+        objs_h, o2i_h = self.objs_host, self.obj_to_img_host
+        if objs_h is None or o2i_h is None:      # one sync (the reference's pool does objs.tolist(), utils.py:104)
+            objs_h, o2i_h = torch.stack((objs, obj_to_img)).tolist()
         obj_vecs, pred_vecs = self.scene_graph_to_vectors(objs, triples, attributes)
         box_vecs, mask_vecs, scene_layout_vecs, wrong_layout_vecs = \
-            self.create_components_vecs(gt_imgs, boxes_gt, obj_to_img, objs, obj_vecs, features)
+            self.create_components_vecs(gt_imgs, boxes_gt, obj_to_img, objs, obj_vecs, features, objs_host=objs_h)
 
         boxes_pred = self.box_net(box_vecs)
 
@@ -95,6 +100,11 @@ class Model(nn.Module):
                                       test_mode=False, grad_from_channel=self.num_objs, **kw)
         wrong_layout = masks_to_layout(wrong_layout_vecs, boxes_gt, masks_gt, obj_to_img, H, W, test_mode=False,
                                        grad_from_channel=self.num_objs, **kw)
+        # per image only the one-hot planes of its own classes + the representation block are non-zero: the
+        # generator's first conv (204 -> 64 channels, 7x7, full resolution) skips the rest
+        chan_list, chan_cnt = active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size)
+        gt_layout._sg_sparse = (torch.from_numpy(chan_list).to(gt_layout.device, non_blocking=True),
+                                torch.from_numpy(chan_cnt).to(gt_layout.device, non_blocking=True))
         imgs_pred = self.layout_to_image(gt_layout)
         return imgs_pred, boxes_pred, masks_pred, gt_layout, pred_layout, wrong_layout
 
@@ -113,7 +123,7 @@ class Model(nn.Module):
             obj_vecs, pred_vecs = self.gconv_net(obj_vecs, pred_vecs, edges)
         return obj_vecs, pred_vecs
 
-    def create_components_vecs(self, imgs, boxes, obj_to_img, objs, obj_vecs, features):
+    def create_components_vecs(self, imgs, boxes, obj_to_img, objs, obj_vecs, features, objs_host=None):
         if features is not None:
             raise NotImplementedError('inference-time feature injection (model.py:158-163) is SURVEY 8f (next)')
         O = objs.size(0)
@@ -130,6 +140,6 @@ class Model(nn.Module):
         one_hot_obj = ops.one_hot(objs, self.num_objs)
         layout_vecs = ops.concat_cols(one_hot_obj, obj_repr)
 
-        wrong_objs_rep = self.fake_pool.query(objs, obj_repr, objs_host=self.objs_host)
+        wrong_objs_rep = self.fake_pool.query(objs, obj_repr, objs_host=objs_host if objs_host is not None else self.objs_host)
         wrong_layout_vecs = ops.concat_cols(one_hot_obj, wrong_objs_rep)
         return box_vecs, mask_vecs, layout_vecs, wrong_layout_vecs

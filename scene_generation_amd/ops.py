@@ -86,7 +86,7 @@ class Conv2dFn(Function):
     discriminators.py:137-158,215-234)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, stride, pad, reflect, upsample, act, slope, grad_from):
+    def forward(ctx, x1, x2, weight, bias, stride, pad, reflect, upsample, act, slope, grad_from, sparse=None):
         x1 = _f32(x1, 'conv input')
         x2 = None if x2 is None else _f32(x2, 'conv input 2')
         weight = _f32(weight, 'conv weight')
@@ -98,11 +98,21 @@ class Conv2dFn(Function):
         bcast = 1 if (x2 is not None and x2.dim() == 2) else 0      # [N, C2] broadcast over H x W
         d = _conv_desc(N, C1, C2, H, W, Cout, KS, stride, pad, reflect, upsample, OH, OW, 0, bcast)
         y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=x1.device)
-        wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 0)
-        ws = workspace(wsb, x1.device)
-        _call('sg_conv2d_fwd', ctypes.byref(d), _p(x1), _p(x2), _p(weight), _p(bias), _p(y), act, slope, _p(ws), wsb,
-              _stream())
+        if sparse is not None:      # (chan_list [N, L] int32, chan_cnt [N] int32): see sg_conv2d_fwd_sparse
+            clist, ccnt = sparse
+            assert clist.dtype == torch.int32 and ccnt.dtype == torch.int32 and clist.size(0) == N == ccnt.numel()
+            L = int(clist.size(1))
+            wsb = _L().sg_conv2d_sparse_ws_bytes(ctypes.byref(d), L, 0)
+            ws = workspace(wsb, x1.device)
+            _call('sg_conv2d_fwd_sparse', ctypes.byref(d), _p(x1), _p(x2), _p(weight), _p(bias), _p(clist), _p(ccnt), L,
+                  _p(y), act, slope, _p(ws), wsb, _stream())
+        else:
+            wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 0)
+            ws = workspace(wsb, x1.device)
+            _call('sg_conv2d_fwd', ctypes.byref(d), _p(x1), _p(x2), _p(weight), _p(bias), _p(y), act, slope, _p(ws), wsb,
+                  _stream())
         ctx.desc = d
+        ctx.sparse = sparse
         ctx.cfg = (act, slope, bias is not None, int(grad_from))
         ctx.save_for_backward(x1, x2, weight, y if act != ACT_NONE else None)
         return y
@@ -152,26 +162,39 @@ class Conv2dFn(Function):
                     gx2 = scale_(red, float(d.H * d.W))
         if need_w or need_b:
             if need_w:
-                wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 2)
-                ws = workspace(wsb, dev)
                 gw = torch.empty_like(weight)
                 gb = torch.empty(d.Cout, dtype=torch.float32, device=dev) if need_b else None
-                _call('sg_conv2d_wgrad', ctypes.byref(d), _p(gy), _p(x1), _p(x2), _p(gw), _p(gb), _p(ws), wsb, s)
+                if ctx.sparse is not None:
+                    clist, ccnt = ctx.sparse
+                    L = int(clist.size(1))
+                    wsb = _L().sg_conv2d_sparse_ws_bytes(ctypes.byref(d), L, 2)
+                    ws = workspace(wsb, dev)
+                    _call('sg_conv2d_wgrad_sparse', ctypes.byref(d), _p(gy), _p(x1), _p(x2), _p(clist), _p(ccnt), L,
+                          _p(gw), _p(gb), _p(ws), wsb, s)
+                else:
+                    wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 2)
+                    ws = workspace(wsb, dev)
+                    _call('sg_conv2d_wgrad', ctypes.byref(d), _p(gy), _p(x1), _p(x2), _p(gw), _p(gb), _p(ws), wsb, s)
             else:
                 gb = torch.empty(d.Cout, dtype=torch.float32, device=dev)
                 wsb = _L().sg_channel_sum_ws_bytes(d.Cout)
                 ws = workspace(wsb, dev)
                 _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb, s)
-        return gx1, gx2, gw, gb, None, None, None, None, None, None, None
+        return gx1, gx2, gw, gb, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, upsample=1, act=ACT_NONE, slope=0.0, x2=None):
     """``x._sg_grad_from = c`` (set by masks_to_layout) promises that nobody needs d/dx[:, :c]: the data gradient is then
-    only computed for channels >= c (the rest is returned as zeros)."""
+    only computed for channels >= c (the rest is returned as zeros).  ``x._sg_sparse = (chan_list, chan_cnt)`` (set by the
+    model next to the layout) promises that, per image, every channel outside the list is all-zero: forward and weight
+    gradient then only visit the listed channels (sg_conv2d_*_sparse)."""
     grad_from = int(getattr(x, '_sg_grad_from', 0))
     if not (0 < grad_from < x.size(1)):
         grad_from = 0
-    return Conv2dFn.apply(x, x2, weight, bias, stride, pad, reflect, upsample, act, float(slope), grad_from)
+    sparse = getattr(x, '_sg_sparse', None) if x2 is None else None
+    if sparse is not None and not (2 * sparse[0].size(1) <= x.size(1)):
+        sparse = None                      # not sparse enough to pay for the per-image weight compaction
+    return Conv2dFn.apply(x, x2, weight, bias, stride, pad, reflect, upsample, act, float(slope), grad_from, sparse)
 
 
 class ConvTranspose2dFn(Function):

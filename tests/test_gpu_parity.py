@@ -115,6 +115,47 @@ def test_conv2d(hip, case):
     close(gb.grad, rb.grad, 5e-5, 'gb')
 
 
+@pytest.mark.parametrize('N,C,dense,H,Cout,KS,stride,pad,reflect', [
+    (5, 40, 6, 16, 64, 7, 1, 3, True),      # generator stem: mask-free 64x64 tiles
+    (3, 30, 4, 11, 24, 3, 1, 1, False),     # ragged everything, zero padding
+    (4, 24, 3, 9, 8, 4, 2, 2, False),       # strided, 32-row tile, images of 25 pixels
+    (2, 64, 8, 32, 128, 3, 1, 1, True),
+])
+def test_conv2d_channel_sparse(hip, N, C, dense, H, Cout, KS, stride, pad, reflect):
+    """sg_conv2d_fwd_sparse / sg_conv2d_wgrad_sparse == the dense conv when every unlisted channel is zero."""
+    from scene_generation_amd.utils import active_layout_channels
+    num_objs = C - dense
+    rng = np.random.RandomState(7)
+    objs, o2i = [], []
+    for n in range(N):
+        k = rng.randint(1, 5)
+        objs += list(rng.randint(0, num_objs, size=k)); o2i += [n] * k
+    cl, cc = active_layout_channels(objs, o2i, N, num_objs, dense)
+    x = det((N, C, H, H), 51)
+    keep = torch.zeros(N, C)
+    for n in range(N):
+        keep[n, torch.from_numpy(cl[n, :cc[n]]).long()] = 1
+    x = x * keep.view(N, C, 1, 1)
+    w, b = det((Cout, C, KS, KS), 52, 0.2), det((Cout,), 53, 0.2)
+    xr, wr, br = [t.clone().requires_grad_() for t in (x, w, b)]
+    if reflect:
+        yr = F.conv2d(F.pad(xr, (pad,) * 4, mode='reflect'), wr, br, stride=stride)
+    else:
+        yr = F.conv2d(xr, wr, br, stride=stride, padding=pad)
+    yr = F.relu(yr)
+    gy = det(tuple(yr.shape), 54)
+    yr.backward(gy)
+    xg, wg, bg = [t.to(DEV).requires_grad_() for t in (x, w, b)]
+    xg._sg_sparse = (torch.from_numpy(cl).to(DEV), torch.from_numpy(cc).to(DEV))
+    assert 2 * cl.shape[1] <= C
+    yg = hip.conv2d(xg, wg, bg, stride=stride, pad=pad, reflect=reflect, act=1)
+    yg.backward(gy.to(DEV))
+    close(yg, yr, 3e-5, 'y')
+    close(xg.grad, xr.grad, 5e-5, 'gx')
+    close(wg.grad, wr.grad, 5e-5, 'gw')
+    close(bg.grad, br.grad, 5e-5, 'gb')
+
+
 def test_conv2d_broadcast_second_source(hip):
     """mask-D: one-hot class map broadcast over the grid == expand()+cat() of discriminators.py:107-110."""
     N, C1, C2, H = 6, 16, 12, 8

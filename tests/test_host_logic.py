@@ -137,3 +137,18 @@ def test_synthetic_batches_follow_the_collate_contract():
     assert torch.equal(torch.cat([p.imgs for p in parts]), b.imgs)
     for p in parts:
         assert int(p.obj_to_img.min()) == 0 and int(p.triples[:, [0, 2]].max()) < p.objs.numel()
+
+
+def test_active_layout_channels():
+    """host index plumbing for the channel-sparse first conv: classes of the image's objects + the dense block."""
+    from scene_generation_amd.utils import active_layout_channels
+    objs = [3, 7, 3, 171, 0, 5]
+    o2i = [0, 0, 0, 1, 1, 2]
+    cl, cc = active_layout_channels(objs, o2i, 3, 172, 4)
+    assert cl.dtype == np.int32 and cc.dtype == np.int32 and cl.shape == (3, 2 + 4)
+    assert cc.tolist() == [6, 6, 5]
+    assert cl[0].tolist() == [3, 7, 172, 173, 174, 175]
+    assert cl[1].tolist() == [0, 171, 172, 173, 174, 175]
+    assert cl[2, :5].tolist() == [5, 172, 173, 174, 175]
+    with pytest.raises(ValueError):
+        active_layout_channels([172], [0], 1, 172, 4)
