@@ -273,10 +273,66 @@ struct LoadGatherKN {
   __device__ __forceinline__ void store(const Stage& st, float* T) const { store_krun<ROWS, MASK>(T, nl_, kr_, st.r, st.ok); }
 };
 
+// n / d for 0 <= n < 2^31 as one v_mul_hi + shift (the k-loop splits a pixel index every tile: a hardware-less
+// integer division costs ~25 VALU instructions, more than the rest of a loader's per-tile work)
+struct FastDiv {
+  unsigned m, s, d;
+  FastDiv() : m(0), s(0), d(1) {}
+  explicit FastDiv(unsigned dd) : m(0), s(0), d(dd) {
+    if (dd > 1) {
+      unsigned sh = 0;
+      while ((1u << sh) < dd) ++sh;
+      m = (unsigned)((((uint64_t)1) << (31 + sh)) / dd + 1);
+      s = sh - 1;
+    }
+  }
+  __device__ __forceinline__ unsigned div(unsigned n) const { return d == 1 ? n : (__umulhi(n, m) >> s); }
+};
+
+// A operand of wgrad, vector form (PQ % 4 == 0, 16-byte aligned base): each thread moves one float4 of four
+// consecutive pixels of one row: 1 global_load_dwordx4 + 1 ds_write_b128 per 4 elements
+template <int BM>
+struct LoadPixKVec {
+  const float* base; int M, Mtot, PQ; FastDiv dPQ;
+  static constexpr int LDS_INTS = 0;
+  static constexpr int Q = (BM * 4 + 255) / 256;
+  struct Stage { float4 r[Q]; unsigned ok; };
+  int m0_, row_, kq_;
+  __device__ __forceinline__ void init(int m0, int tid, int*, int, int) { m0_ = m0; row_ = tid >> 2; kq_ = (tid & 3) * 4; }
+  __device__ __forceinline__ void set_batch(int, int, int) {}
+  __device__ __forceinline__ void prefetch(Stage&, int) const {}
+  __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
+    const int k = k0 + kq_;
+    const bool kok = k < kend;
+    const unsigned kk = kok ? (unsigned)k : 0u;
+    const unsigned img = dPQ.div(kk), pix = kk - img * (unsigned)PQ;
+    const unsigned p0 = img * (unsigned)Mtot * (unsigned)PQ + pix;
+    st.ok = 0;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+      const int m = m0_ + row_ + 64 * i;
+      const bool ok = kok && m < M && (row_ + 64 * i < BM);
+      st.r[i] = *reinterpret_cast<const float4*>(base + (ok ? p0 + (unsigned)m * (unsigned)PQ : 0u));
+      st.ok |= ok ? (1u << i) : 0u;
+    }
+  }
+  __device__ __forceinline__ void store(const Stage& st, float* T) const {
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+      if (row_ + 64 * i < BM) {
+        const bool ok = (st.ok >> i) & 1u;
+        float4 v = st.r[i];
+        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(T + (row_ + 64 * i) * LDK + kq_) = v;
+      }
+    }
+  }
+};
+
 // A operand of wgrad: elem(m, k) = base[(img*Mtot + m)*PQ + pix], k = img*PQ + pix.  Lanes run along k.
 template <int BM, bool MASK = true>
 struct LoadPixK {
-  const float* base; int M, Mtot, PQ;
+  const float* base; int M, Mtot, PQ; FastDiv dPQ;
   static constexpr int LDS_INTS = 0;
   static constexpr int ROWS = BM / 16;
   struct Stage { float r[ROWS]; unsigned ok; };
@@ -287,9 +343,9 @@ struct LoadPixK {
   __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
     const int k = k0 + kl_;
     const bool kok = k < kend;
-    const int kk = kok ? k : 0;
-    const int img = kk / PQ, pix = kk - img * PQ;
-    const unsigned p0 = (unsigned)img * (unsigned)Mtot * (unsigned)PQ + (unsigned)pix;
+    const unsigned kk = kok ? (unsigned)k : 0u;
+    const unsigned img = dPQ.div(kk), pix = kk - img * (unsigned)PQ;
+    const unsigned p0 = img * (unsigned)Mtot * (unsigned)PQ + pix;
     st.ok = 0;
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
@@ -414,6 +470,86 @@ struct LoadGatherNK {
   }
 };
 
+// B operand of wgrad, tap-major column order: the N axis is laid out as (tap, channel) with the channel range padded
+// to whole tiles, so ONE (kh, kw) is shared by a whole workgroup for its whole k-loop.  The source offset of a pixel
+// is then a function of the pixel alone: 16 lanes compute it one k-tile ahead into LDS (prefetch()) and a gathered
+// element costs 1 add + 1 load (the general loader above spends 2 LDS reads, 2 adds and a validity test per
+// element).  EpWgrad un-permutes the columns on the way out.
+template <int BN, bool TWO, bool MASK = true>
+struct LoadTapNK {
+  Gather g; int KS, Ccols, cpad;
+  const int* chan_list; const int* chan_cnt; int L;     // optional per-image active-channel lists (image = blockIdx.z)
+  FastDiv dPQ, dPW;
+  static constexpr int BUF = 2 * BK;                    // off1[16], off2[16]
+  static constexpr int LDS_INTS = 2 * SG_NSUB * BUF;
+  static constexpr int COLS = BN / 16;
+  struct Stage { float r[COLS]; unsigned ok; };
+  int kl_, tid_, nr_, kbeg_, kend_, kh_, kw_;
+  unsigned choff_[COLS], secmask_;
+  int* lds_;
+  __device__ __forceinline__ void set_batch(int, int, int) {}
+  __device__ __forceinline__ void init(int n0, int tid, int* lds, int kbeg, int kend) {
+    kl_ = tid & 15; nr_ = tid >> 4; tid_ = tid; lds_ = lds; kbeg_ = kbeg; kend_ = kend;
+    const int t = n0 / cpad, c0 = n0 - t * cpad;
+    kh_ = t / KS; kw_ = t - kh_ * KS;
+    const unsigned shw = (unsigned)(g.SH * g.SW);
+    const int* list = chan_list ? chan_list + (size_t)blockIdx.z * L : nullptr;
+    const int ncols = chan_list ? chan_cnt[blockIdx.z] : Ccols;
+    secmask_ = 0;
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) {
+      const int cj = c0 + nr_ + 16 * j;
+      const int cc = cj < ncols ? cj : 0;             // column tail: any valid channel, the epilogue never stores it
+      const int c = list ? list[cc] : cc;
+      const bool second = TWO && c >= g.C1;
+      const unsigned cs = (unsigned)(second ? c - g.C1 : c);
+      choff_[j] = (second && g.bcast2) ? cs : cs * shw;
+      secmask_ |= second ? (1u << j) : 0u;
+    }
+  }
+  __device__ __forceinline__ int* buf_of(int k0) const { return lds_ + (((k0 - kbeg_) / BK) % (2 * SG_NSUB)) * BUF; }
+  __device__ __forceinline__ void prefetch(Stage&, int k0) const {
+    if (tid_ < BK) {
+      int* buf = buf_of(k0);
+      const int k = k0 + tid_;
+      const bool kok = k < kend_;
+      const unsigned kk = kok ? (unsigned)k : 0u;
+      const unsigned img = dPQ.div(kk), pix = kk - img * (unsigned)(g.PH * g.PW);
+      const unsigned ph = dPW.div(pix), pw = pix - ph * (unsigned)g.PW;
+      const int ih = axis_offset((int)ph * g.stride - g.pad, kh_, g.LH, g.reflect, g.ushift);
+      const int iw = axis_offset((int)pw * g.stride - g.pad, kw_, g.LW, g.reflect, g.ushift);
+      const bool valid = kok && (ih | iw) >= 0;
+      const unsigned shw = (unsigned)(g.SH * g.SW);
+      const unsigned tp = (unsigned)(ih * g.SW + iw);
+      buf[tid_] = valid ? (int)(img * (unsigned)g.C1 * shw + tp) : -1;
+      if (TWO) buf[BK + tid_] = (int)(g.bcast2 ? img * (unsigned)g.C2 : img * (unsigned)g.C2 * shw + tp);
+    }
+  }
+  __device__ __forceinline__ void load(Stage& st, int k0, int) const {
+    const int* buf = buf_of(k0);
+    const int o1 = buf[kl_];
+    const bool ok = !MASK || o1 >= 0;
+    const unsigned b1 = ok ? (unsigned)o1 : 0u;         // invalid pixel: element 0 of the channel plane, zeroed in store()
+    const unsigned b2 = (TWO && ok) ? (unsigned)buf[BK + kl_] : 0u;
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) {
+      if (TWO) {
+        const bool second = (secmask_ >> j) & 1u;
+        const float* base = second ? g.src2 : g.src1;
+        st.r[j] = base[(second ? b2 : b1) + choff_[j]];
+      } else {
+        st.r[j] = g.src1[b1 + choff_[j]];
+      }
+    }
+    st.ok = ok ? 1u : 0u;
+  }
+  __device__ __forceinline__ void store(const Stage& st, float* T) const {
+    const bool ok = !MASK || st.ok != 0u;
+#pragma unroll
+    for (int j = 0; j < COLS; ++j) T[(nr_ + 16 * j) * LDK + kl_] = ok ? st.r[j] : 0.f;
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // Epilogues.  Accumulator register r of a 32x32 tile <-> row (r&3)+8*(r>>2)+4*(lane>>5), col lane&31.
 // ------------------------------------------------------------------------------------------------
@@ -461,6 +597,30 @@ struct EpRowMajor {  // out[z][m*ldc + n] ; bias per column n
         for (int r = 0; r < 16; ++r) {
           const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           if (m < M) o[(size_t)m * ldc + n] = sg_apply_act(acc[i][j][r] + b, act, slope);
+        }
+      }
+    }
+  }
+};
+
+struct EpWgrad {     // tap-major virtual column n = t*cpad + cj  ->  out[z][m*ldc + cj*KS2 + t]
+  float* out; int M, Ccols, cpad, KS2, ldc; size_t zstride;
+  __device__ __forceinline__ void set_limit(int) {}
+  template <int TM, int TN>
+  __device__ __forceinline__ void store(f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int z) const {
+    float* o0 = out + (size_t)z * zstride;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nbase + j * 32 + (lane & 31);
+      const int t = n / cpad, cj = n - t * cpad;
+      if (cj >= Ccols || t >= KS2) continue;
+      float* o = o0 + (size_t)cj * KS2 + t;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (m < M) o[(size_t)m * ldc] = acc[i][j][r];
         }
       }
     }
@@ -608,7 +768,6 @@ inline int pick_tile(int M, int N) {
 // thread-local launch modifiers (set by the sparse entry points around a regular dispatch)
 thread_local BatchInfo t_batch = {0, 0, nullptr, 0, 0};
 struct Sparse { const int* list; const int* cnt; int L; };   // per-image ascending active-channel lists
-thread_local Sparse t_sp = {nullptr, nullptr, 0};
 thread_local int t_fixed_kchunk = 0;        // >0: grid.z = ceil(K / chunk) with exactly this chunk (one image per z)
 
 template <class CFG, class AL, class BL, class EP>
@@ -857,77 +1016,122 @@ __global__ void sparse_wgrad_reduce_kernel(const float* slabs, const int* inv, f
 inline size_t sparse_wgrad_ws(int NB, int M, int C, int L, int KS2) {
   return (size_t)NB * M * L * KS2 * sizeof(float) + (size_t)NB * C * sizeof(int);
 }
-inline int wgrad_splits(int M, int Ncols, int Kpix) {
-  const long tiles = (long)sg_cdiv(M, M <= 32 ? 32 : 64) * sg_cdiv(Ncols, M <= 32 ? 128 : 64);
-  int s = (int)((768 + tiles - 1) / tiles);
+// launch plan of a weight-gradient GEMM (shared by the workspace query and the launcher)
+struct NkPlan { int tile; bool tap; int cpad; int splits; };
+inline NkPlan nk_plan(int M, int C, int KS2, int Kpix, bool two) {
+  NkPlan p;
+  p.tap = C >= 48 || two;                                   // tap-major columns pad C to whole tiles: too wasteful for RGB inputs
+  p.tile = M <= 32 ? 2 : 1;
+  if (M > 64 && p.tap) {
+    // 128x128 tiles issue ~0.7x the instructions per MFMA of 64x64 tiles, but pad M and C to multiples of 128
+    const double w128 = (double)sg_cdiv(M, 128) * 128 * sg_cdiv(C, 128) * 128;
+    const double w64 = (double)sg_cdiv(M, 64) * 64 * sg_cdiv(C, 64) * 64;
+    if (w128 * 0.7 < w64) p.tile = 0;
+  }
+  const int BMt = p.tile == 0 ? 128 : (p.tile == 1 ? 64 : 32), BNt = p.tile == 1 ? 64 : 128;
+  p.cpad = p.tap ? sg_cdiv(C, BNt) * BNt : 0;
+  const long tiles = (long)sg_cdiv(M, BMt) * (p.tap ? (long)KS2 * (p.cpad / BNt) : (long)sg_cdiv((long)C * KS2, BNt));
+  const int target = p.tile == 0 ? 768 : 1024;       // resident workgroups on 256 CUs
+  int s = (int)((target + tiles - 1) / tiles);
   const int maxs = Kpix / (BK * 8) > 0 ? Kpix / (BK * 8) : 1;
   if (s > maxs) s = maxs;
   if (s > 64) s = 64;
-  return s < 1 ? 1 : s;
+  p.splits = s < 1 ? 1 : s;
+  return p;
 }
 
+// general (c, tap)-ordered loader: only for few-channel inputs (RGB crops / images)
 template <int KS>
-int run_nk(const float* A, int M, int Mtot, const Gather& g, int NB, float* out, void* ws, size_t ws_bytes,
-           double flops, hipStream_t s, const Sparse* sp = nullptr) {
-  const int PQ = g.PH * g.PW;
-  const int Kpix = NB * PQ;
-  // channel-sparse input (see run_kn_sparse): one k-chunk per image, compact columns, per-image slabs that
-  // sparse_wgrad_reduce_kernel scatters back to the dense gradient in a fixed order
-  const int Ncols = (sp ? sp->L : g.C1 + g.C2) * KS * KS;
-  int splits = sp ? NB : wgrad_splits(M, Ncols, Kpix);
-  const size_t mn = (size_t)M * Ncols;
-  if (!sp && splits > 1 && ws_bytes < mn * sizeof(float) * (size_t)splits) splits = (int)(ws_bytes / (mn * sizeof(float)));
-  if (splits < 2 && !sp) splits = 1;
-  int kchunk = sp ? PQ : sg_cdiv(sg_cdiv(Kpix, splits), 64) * 64;      // multiple of every BKT
-  splits = sg_cdiv(Kpix, kchunk);
-  if (sp) { t_sp = *sp; t_fixed_kchunk = PQ; flops = 2.0 * M * (double)Ncols * Kpix; }
-  float* dst = (splits > 1 || sp) ? reinterpret_cast<float*>(ws) : out;
-  EpRowMajor ep{dst, nullptr, M, Ncols, Ncols, SG_ACT_NONE, 0.f, mn};
-  const int tile = M <= 32 ? 2 : ((long)sg_cdiv(M, 128) * sg_cdiv(Ncols, 128) >= 384 ? 0 : 1);
-  {
-    SgProfScope prof(sg_igemm_kind(2, KS, tile), s, flops, 0);
-    const bool two = g.C2 > 0;
-    const int tBM = tile == 0 ? 128 : (tile == 1 ? 64 : 32);
-    // mask-free: reflection padding, full M tiles, whole 16-pixel k-tiles (split chunks are multiples of 64)
-    const bool nomask = !two && g.reflect && (M % tBM == 0) && (Kpix % BK == 0) && (!sp || PQ % BK == 0);
-#define SG_NK_LAUNCH(CFGT, BMv, BNv)                                                               \
-  do {                                                                                             \
-    if (two) { launch_cfg<CFGT>(LoadPixK<BMv>{A, M, Mtot, PQ}, LoadGatherNK<BNv, KS, true>{g, Ncols, t_sp.list, t_sp.cnt, t_sp.L}, ep, M, Ncols, Kpix, splits, s); } \
-    else if (nomask) { launch_cfg<CFGT>(LoadPixK<BMv, false>{A, M, Mtot, PQ}, LoadGatherNK<BNv, KS, false, false>{g, Ncols, t_sp.list, t_sp.cnt, t_sp.L}, ep, M, Ncols, Kpix, splits, s); } \
-    else { launch_cfg<CFGT>(LoadPixK<BMv>{A, M, Mtot, PQ}, LoadGatherNK<BNv, KS, false>{g, Ncols, t_sp.list, t_sp.cnt, t_sp.L}, ep, M, Ncols, Kpix, splits, s); }    \
-  } while (0)
-    if (tile == 2) SG_NK_LAUNCH(Cfg32, 32, 128);
-    else if (tile == 0) SG_NK_LAUNCH(Cfg128, 128, 128);
-    else SG_NK_LAUNCH(Cfg64, 64, 64);
-#undef SG_NK_LAUNCH
+void launch_nk_general(int tile, const float* A, int M, int Mtot, int PQ, const Gather& g, int Ncols, const EpRowMajor& ep,
+                       int Kpix, int splits, hipStream_t s) {
+  const FastDiv dPQ((unsigned)PQ);
+  if (tile == 2)
+    launch_cfg<Cfg32>(LoadPixK<32>{A, M, Mtot, PQ, dPQ}, LoadGatherNK<128, KS, false>{g, Ncols, nullptr, nullptr, 0}, ep, M,
+                      Ncols, Kpix, splits, s);
+  else
+    launch_cfg<Cfg64>(LoadPixK<64>{A, M, Mtot, PQ, dPQ}, LoadGatherNK<64, KS, false>{g, Ncols, nullptr, nullptr, 0}, ep, M,
+                      Ncols, Kpix, splits, s);
+}
+
+template <class CFG, int BMv, int BNv>
+void launch_nk_tap(const float* A, int M, int Mtot, int PQ, bool vecA, const Gather& g, int KS, int Ccols, int cpad,
+                   const Sparse* sp, bool nomask, const EpWgrad& ep, int Kpix, int splits, hipStream_t s) {
+  const FastDiv dPQ((unsigned)PQ), dPW((unsigned)g.PW);
+  const int* sl = sp ? sp->list : nullptr; const int* sc = sp ? sp->cnt : nullptr; const int L = sp ? sp->L : 0;
+  const int Nv = KS * KS * cpad;
+  const bool two = g.C2 > 0;
+#define SG_TAP_B(TWOv, MASKv) LoadTapNK<BNv, TWOv, MASKv>{g, KS, Ccols, cpad, sl, sc, L, dPQ, dPW}
+  if (vecA) {
+    const LoadPixKVec<BMv> al{A, M, Mtot, PQ, dPQ};
+    if (two) launch_cfg<CFG>(al, SG_TAP_B(true, true), ep, M, Nv, Kpix, splits, s);
+    else if (nomask) launch_cfg<CFG>(al, SG_TAP_B(false, false), ep, M, Nv, Kpix, splits, s);
+    else launch_cfg<CFG>(al, SG_TAP_B(false, true), ep, M, Nv, Kpix, splits, s);
+  } else {
+    const LoadPixK<BMv> al{A, M, Mtot, PQ, dPQ};
+    if (two) launch_cfg<CFG>(al, SG_TAP_B(true, true), ep, M, Nv, Kpix, splits, s);
+    else if (nomask) launch_cfg<CFG>(al, SG_TAP_B(false, false), ep, M, Nv, Kpix, splits, s);
+    else launch_cfg<CFG>(al, SG_TAP_B(false, true), ep, M, Nv, Kpix, splits, s);
   }
-  if (sp) {
-    t_sp = Sparse{nullptr, nullptr, 0}; t_fixed_kchunk = 0;
-    const int C = g.C1 + g.C2;
-    int* inv = reinterpret_cast<int*>(reinterpret_cast<float*>(ws) + (size_t)NB * mn);
-    hipLaunchKernelGGL(sparse_inv_kernel, dim3(sg_cdiv(C, 256), NB), dim3(256), 0, s, sp->list, sp->cnt, sp->L, C, inv);
-    const size_t n = (size_t)M * C * KS * KS;
-    hipLaunchKernelGGL(sparse_wgrad_reduce_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, (const int*)inv,
-                       out, M, C, KS * KS, sp->L, NB);
-    return 0;
-  }
-  if (splits > 1) {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(sg_cdiv(mn, 256)), dim3(256), 0, s, (const float*)ws, out, mn,
-                       splits);
-  }
-  return 0;
+#undef SG_TAP_B
 }
 
 int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, float* out, void* ws, size_t ws_bytes,
               double flops, hipStream_t s, const Sparse* sp = nullptr) {
-  switch (KS) {
-    case 1: return run_nk<1>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s, sp);
-    case 3: return run_nk<3>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s, sp);
-    case 4: return run_nk<4>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s, sp);
-    case 7: return run_nk<7>(A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s, sp);
+  const int PQ = g.PH * g.PW, KS2 = KS * KS;
+  const int Kpix = NB * PQ;
+  const int C = g.C1 + g.C2;
+  // channel-sparse input (see run_kn_sparse): one k-chunk per image, compact columns, per-image slabs that
+  // sparse_wgrad_reduce_kernel scatters back to the dense gradient in a fixed order
+  const int Ccols = sp ? sp->L : C;
+  const int Ncols = Ccols * KS2;
+  NkPlan pl = nk_plan(M, Ccols, KS2, Kpix, g.C2 > 0);
+  if (sp) pl.tap = true;
+  if (sp && pl.cpad == 0) pl.cpad = sg_cdiv(Ccols, pl.tile == 1 ? 64 : 128) * (pl.tile == 1 ? 64 : 128);
+  int splits = sp ? NB : pl.splits;
+  const size_t mn = (size_t)M * Ncols;
+  if (!sp && splits > 1 && ws_bytes < mn * sizeof(float) * (size_t)splits) splits = (int)(ws_bytes / (mn * sizeof(float)));
+  if (!sp && splits < 2) splits = 1;
+  const int kchunk = sp ? PQ : sg_cdiv(sg_cdiv(Kpix, splits), 64) * 64;      // multiple of every BKT
+  splits = sg_cdiv(Kpix, kchunk);
+  if (sp) { t_fixed_kchunk = PQ; flops = 2.0 * M * (double)Ncols * Kpix; }
+  float* dst = (splits > 1 || sp) ? reinterpret_cast<float*>(ws) : out;
+  {
+    SgProfScope prof(sg_igemm_kind(2, KS, pl.tile), s, flops, 0);
+    if (pl.tap) {
+      const EpWgrad ep{dst, M, Ccols, pl.cpad, KS2, Ncols, mn};
+      const bool vecA = (PQ % 4 == 0) && aligned16(A);
+      // mask-free gather: reflection padding and whole 16-pixel k-tiles (split chunks are multiples of 64)
+      const bool nomask = g.reflect && (Kpix % BK == 0) && (!sp || PQ % BK == 0);
+      switch (pl.tile) {
+        case 0: launch_nk_tap<Cfg128, 128, 128>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
+        case 1: launch_nk_tap<Cfg64, 64, 64>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
+        default: launch_nk_tap<Cfg32, 32, 128>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
+      }
+    } else {
+      const EpRowMajor ep{dst, nullptr, M, Ncols, Ncols, SG_ACT_NONE, 0.f, mn};
+      switch (KS) {
+        case 1: launch_nk_general<1>(pl.tile, A, M, Mtot, PQ, g, Ncols, ep, Kpix, splits, s); break;
+        case 3: launch_nk_general<3>(pl.tile, A, M, Mtot, PQ, g, Ncols, ep, Kpix, splits, s); break;
+        case 4: launch_nk_general<4>(pl.tile, A, M, Mtot, PQ, g, Ncols, ep, Kpix, splits, s); break;
+        case 7: launch_nk_general<7>(pl.tile, A, M, Mtot, PQ, g, Ncols, ep, Kpix, splits, s); break;
+        default: return -1;
+      }
+    }
   }
-  return -1;
+  t_fixed_kchunk = 0;
+  if (sp) {
+    int* inv = reinterpret_cast<int*>(reinterpret_cast<float*>(ws) + (size_t)NB * mn);
+    hipLaunchKernelGGL(sparse_inv_kernel, dim3(sg_cdiv(C, 256), NB), dim3(256), 0, s, sp->list, sp->cnt, sp->L, C, inv);
+    const size_t n = (size_t)M * C * KS2;
+    hipLaunchKernelGGL(sparse_wgrad_reduce_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, (const int*)inv,
+                       out, M, C, KS2, sp->L, NB);
+    return 0;
+  }
+  if (splits > 1)
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(sg_cdiv(mn, 256)), dim3(256), 0, s, (const float*)ws, out, mn, splits);
+  return 0;
 }
+
 
 int check_desc(const sgConvDesc* d, const char* who) {
   SG_ARG_CHECK(d != nullptr, "%s: null desc", who);
@@ -945,8 +1149,9 @@ int check_desc(const sgConvDesc* d, const char* who) {
   return 0;
 }
 
-inline size_t wgrad_ws(int M, int Ncols, int Kpix) {
-  return (size_t)wgrad_splits(M, Ncols, Kpix) * (size_t)M * Ncols * sizeof(float);
+
+inline size_t wgrad_ws(int M, int C, int KS2, int Kpix, bool two) {
+  return (size_t)nk_plan(M, C, KS2, Kpix, two).splits * (size_t)M * C * KS2 * sizeof(float);
 }
 
 }  // namespace
@@ -969,8 +1174,8 @@ extern "C" size_t sg_conv2d_ws_bytes(const sgConvDesc* d, int kind) {
   if (kind == 1) return wbytes + kt + sl;          // dgrad: transposed weights + k-split table + split-K slabs
   const int M = d->Cout > (d->C1 + d->C2) ? d->Cout : (d->C1 + d->C2);
   const int Kp = d->N * (d->OH * d->OW > d->H * d->W ? d->OH * d->OW : d->H * d->W);
-  size_t a = wgrad_ws(d->Cout, (d->C1 + d->C2) * d->KS * d->KS, d->N * d->OH * d->OW);
-  size_t b = wgrad_ws(d->C1 + d->C2, d->Cout * d->KS * d->KS, d->N * d->H * d->W);
+  size_t a = wgrad_ws(d->Cout, d->C1 + d->C2, d->KS * d->KS, d->N * d->OH * d->OW, d->C2 > 0);
+  size_t b = wgrad_ws(d->C1 + d->C2, d->Cout, d->KS * d->KS, d->N * d->H * d->W, false);
   (void)M; (void)Kp;
   const size_t cs = sg_channel_sum_ws_bytes(d->Cout);
   a = a > b ? a : b;
