@@ -164,7 +164,7 @@ class MultiscaleDiscriminator(nn.Module):
             model = [getattr(self, 'scale' + str(num_D - 1 - i) + '_layer' + str(j)) for j in range(self.n_layers + 2)]
             result.append(self.singleD_forward(model, a, b))
             if i != (num_D - 1):
-                a = self.downsample(a)
+                a = ops.carry_hints(a, self.downsample(a))      # pooling keeps all-zero layout channels all-zero
                 b = self.downsample(b) if b is not None else None
         return result
 

@@ -102,9 +102,15 @@ class Model(nn.Module):
                                        grad_from_channel=self.num_objs, **kw)
         # per image only the one-hot planes of its own classes + the representation block are non-zero: the
         # generator's first conv (204 -> 64 channels, 7x7, full resolution) skips the rest
-        chan_list, chan_cnt = active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size)
-        gt_layout._sg_sparse = (torch.from_numpy(chan_list).to(gt_layout.device, non_blocking=True),
-                                torch.from_numpy(chan_cnt).to(gt_layout.device, non_blocking=True))
+        dev = gt_layout.device
+        sparse = tuple(torch.from_numpy(a).to(dev, non_blocking=True)
+                       for a in active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size))
+        # same lists + the 3 image channels the image discriminator concatenates behind the layout
+        sparse_img = tuple(torch.from_numpy(a).to(dev, non_blocking=True)
+                           for a in active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size, extra=3))
+        for lay in (gt_layout, pred_layout, wrong_layout):
+            lay._sg_sparse = sparse
+            lay._sg_sparse_cat = {3: sparse_img}
         imgs_pred = self.layout_to_image(gt_layout)
         return imgs_pred, boxes_pred, masks_pred, gt_layout, pred_layout, wrong_layout
 

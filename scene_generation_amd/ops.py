@@ -183,6 +183,22 @@ class Conv2dFn(Function):
         return gx1, gx2, gw, gb, None, None, None, None, None, None, None, None
 
 
+_HINTS = ('_sg_sparse', '_sg_sparse_cat', '_sg_grad_from')
+
+
+def carry_hints(src, dst, grad_from=False):
+    """copy the layout hints (per-image active channels, constant channel block) to a tensor derived from ``src`` by an
+    op that keeps all-zero channels all-zero (detach, average pooling)"""
+    for k in _HINTS:
+        if (k != '_sg_grad_from' or grad_from) and hasattr(src, k):
+            setattr(dst, k, getattr(src, k))
+    return dst
+
+
+def detach_keep(t):
+    return carry_hints(t, t.detach(), grad_from=True)
+
+
 def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, upsample=1, act=ACT_NONE, slope=0.0, x2=None):
     """``x._sg_grad_from = c`` (set by masks_to_layout) promises that nobody needs d/dx[:, :c]: the data gradient is then
     only computed for channels >= c (the rest is returned as zeros).  ``x._sg_sparse = (chan_list, chan_cnt)`` (set by the
@@ -191,7 +207,10 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, upsample=1, act
     grad_from = int(getattr(x, '_sg_grad_from', 0))
     if not (0 < grad_from < x.size(1)):
         grad_from = 0
-    sparse = getattr(x, '_sg_sparse', None) if x2 is None else None
+    if x2 is None:
+        sparse = getattr(x, '_sg_sparse', None)
+    else:          # channel-concatenated second source (the image next to the layout): lists that include its channels
+        sparse = getattr(x, '_sg_sparse_cat', {}).get(x2.size(1)) if x2.dim() == 4 else None
     if sparse is not None and not (2 * sparse[0].size(1) <= x.size(1)):
         sparse = None                      # not sparse enough to pay for the per-image weight compaction
     return Conv2dFn.apply(x, x2, weight, bias, stride, pad, reflect, upsample, act, float(slope), grad_from, sparse)

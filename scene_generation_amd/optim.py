@@ -16,6 +16,7 @@ from . import ops
 
 class FlatParams:
     """Re-homes ``params`` into one flat buffer (+ a flat gradient buffer).  Device-agnostic host logic."""
+    ALIGN = 64          # elements
 
     def __init__(self, params):
         self.params = [p for p in params]
@@ -25,9 +26,10 @@ class FlatParams:
         self.offsets, off = [], 0
         for p in self.params:
             self.offsets.append(off)
-            off += p.numel()
+            # 256-byte aligned slices: the conv kernels read weights with 16-byte vector loads only when aligned
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.numel = off
-        self.flat = torch.empty(off, dtype=dt, device=dev)
+        self.flat = torch.zeros(off, dtype=dt, device=dev)     # alignment gaps stay zero under Adam (zero gradient)
         self.grad = torch.zeros(off, dtype=dt, device=dev)
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
@@ -38,6 +40,10 @@ class FlatParams:
     def grad_view(self, i):
         p, o = self.params[i], self.offsets[i]
         return self.grad[o:o + p.numel()].view(p.shape)
+
+    def packed(self, buf):
+        """``buf`` (the flat parameter / gradient / moment buffer) without the alignment gaps, in parameter order"""
+        return torch.cat([buf[o:o + p.numel()] for p, o in zip(self.params, self.offsets)])
 
     def attach_grads(self):
         """(re)point every p.grad at its slice of the flat buffer; autograd then accumulates IN PLACE."""

@@ -193,7 +193,7 @@ class Trainer:
             if self.netD is not None:
                 with torch.no_grad():               # "train textures" pass: only detached features are used
                     pred_real = self.netD(layout, imgs)
-                img_pred_fake = self.netD(layout.detach(), imgs_pred)
+                img_pred_fake = self.netD(ops.detach_keep(layout), imgs_pred)
                 L.add_loss(self.criterionGAN(img_pred_fake, True), 'g_gan_img_loss', args.d_img_weight)
                 if args.d_img_features_weight > 0:
                     L.add_loss(self.calculate_features_loss(img_pred_fake, pred_real), 'g_gan_features_loss_img',
@@ -265,7 +265,7 @@ class Trainer:
         self.train_generator(imgs, imgs_pred, masks, masks_pred, layout, objs, boxes, boxes_pred, obj_to_img, use_gt)
         self.train_mask_discriminator(masks, masks_pred.detach(), objs)
         self.train_obj_discriminator(imgs, imgs_pred.detach(), objs, boxes, boxes.detach(), obj_to_img)
-        self.train_image_discriminator(imgs, imgs_pred.detach(), layout.detach(), layout_wrong.detach())
+        self.train_image_discriminator(imgs, imgs_pred.detach(), ops.detach_keep(layout), ops.detach_keep(layout_wrong))
         return model_out
 
     def write_losses(self, checkpoint, t):

@@ -129,13 +129,14 @@ class VectorPool:
         return [] if n == 0 else list(self.pool[cls, :n].cpu())
 
 
-def active_layout_channels(objs, obj_to_img, num_images, num_objs, dense):
+def active_layout_channels(objs, obj_to_img, num_images, num_objs, dense, extra=0):
     """Per-image list of layout channels that can be non-zero.
 
     The layout vectors are ``[one_hot(obj class) | representation]`` (model.py:165-168 of the reference), so image n
     only has the one-hot planes of the classes of its own objects plus the ``dense`` trailing channels non-zero.
     Host-side index plumbing on the (tiny) object lists; returns ``(chan_list [N, L] int32, chan_cnt [N] int32)`` as
-    numpy arrays, lists ascending and padded with the first entry.
+    numpy arrays, lists ascending and padded with the first entry.  ``extra`` more channels right after the layout's
+    (a channel-concatenated image, trainer.py:232-244) are always active.
     """
     import numpy as np
     per_img = [set() for _ in range(num_images)]
@@ -143,6 +144,7 @@ def active_layout_channels(objs, obj_to_img, num_images, num_objs, dense):
         if not (0 <= c < num_objs):
             raise ValueError('object class %d outside [0, %d)' % (c, num_objs))
         per_img[i].add(int(c))
+    dense = dense + extra
     L = max(len(p) for p in per_img) + dense if per_img else dense
     chan_list = np.zeros((num_images, L), dtype=np.int32)
     chan_cnt = np.zeros((num_images,), dtype=np.int32)

@@ -57,7 +57,7 @@ def _worker(rank, world, port, bucket_bytes, q):
         fp.grad.zero_()
         _loss(model, shard_batch(_batch(), rank, world)).backward()
         red.wait()
-    q.put((rank, fp.grad.detach().numpy().copy(), fp.flat.detach().numpy().copy(), len(red.buckets)))   # by value
+    q.put((rank, fp.packed(fp.grad).detach().numpy().copy(), fp.packed(fp.flat).detach().numpy().copy(), len(red.buckets)))   # by value
     dist.barrier()
     dist.destroy_process_group()
 

@@ -115,13 +115,15 @@ def test_conv2d(hip, case):
     close(gb.grad, rb.grad, 5e-5, 'gb')
 
 
-@pytest.mark.parametrize('N,C,dense,H,Cout,KS,stride,pad,reflect', [
-    (5, 40, 6, 16, 64, 7, 1, 3, True),      # generator stem: mask-free 64x64 tiles
-    (3, 30, 4, 11, 24, 3, 1, 1, False),     # ragged everything, zero padding
-    (4, 24, 3, 9, 8, 4, 2, 2, False),       # strided, 32-row tile, images of 25 pixels
-    (2, 64, 8, 32, 128, 3, 1, 1, True),
+@pytest.mark.parametrize('N,C,dense,H,Cout,KS,stride,pad,reflect,C2', [
+    (5, 40, 6, 16, 64, 7, 1, 3, True, 0),      # generator stem: mask-free 64x64 tiles
+    (3, 30, 4, 11, 24, 3, 1, 1, False, 0),     # ragged everything, zero padding
+    (4, 24, 3, 9, 8, 4, 2, 2, False, 0),       # strided, 32-row tile, images of 25 pixels
+    (2, 64, 8, 32, 128, 3, 1, 1, True, 0),
+    (3, 40, 5, 17, 64, 4, 2, 2, False, 3),     # image-D first conv: layout | image, odd output grid (9x9)
+    (2, 36, 4, 16, 16, 4, 2, 2, False, 3),
 ])
-def test_conv2d_channel_sparse(hip, N, C, dense, H, Cout, KS, stride, pad, reflect):
+def test_conv2d_channel_sparse(hip, N, C, dense, H, Cout, KS, stride, pad, reflect, C2):
     """sg_conv2d_fwd_sparse / sg_conv2d_wgrad_sparse == the dense conv when every unlisted channel is zero."""
     from scene_generation_amd.utils import active_layout_channels
     num_objs = C - dense
@@ -136,22 +138,32 @@ def test_conv2d_channel_sparse(hip, N, C, dense, H, Cout, KS, stride, pad, refle
     for n in range(N):
         keep[n, torch.from_numpy(cl[n, :cc[n]]).long()] = 1
     x = x * keep.view(N, C, 1, 1)
-    w, b = det((Cout, C, KS, KS), 52, 0.2), det((Cout,), 53, 0.2)
+    x2 = det((N, C2, H, H), 55) if C2 else None
+    w, b = det((Cout, C + C2, KS, KS), 52, 0.2), det((Cout,), 53, 0.2)
     xr, wr, br = [t.clone().requires_grad_() for t in (x, w, b)]
+    x2r = x2.clone().requires_grad_() if C2 else None
+    xin = torch.cat([xr, x2r], 1) if C2 else xr
     if reflect:
-        yr = F.conv2d(F.pad(xr, (pad,) * 4, mode='reflect'), wr, br, stride=stride)
+        yr = F.conv2d(F.pad(xin, (pad,) * 4, mode='reflect'), wr, br, stride=stride)
     else:
-        yr = F.conv2d(xr, wr, br, stride=stride, padding=pad)
+        yr = F.conv2d(xin, wr, br, stride=stride, padding=pad)
     yr = F.relu(yr)
     gy = det(tuple(yr.shape), 54)
     yr.backward(gy)
     xg, wg, bg = [t.to(DEV).requires_grad_() for t in (x, w, b)]
-    xg._sg_sparse = (torch.from_numpy(cl).to(DEV), torch.from_numpy(cc).to(DEV))
+    x2g = x2.to(DEV).requires_grad_() if C2 else None
+    if C2:
+        cl, cc = active_layout_channels(objs, o2i, N, num_objs, dense, extra=C2)
+        xg._sg_sparse_cat = {C2: (torch.from_numpy(cl).to(DEV), torch.from_numpy(cc).to(DEV))}
+    else:
+        xg._sg_sparse = (torch.from_numpy(cl).to(DEV), torch.from_numpy(cc).to(DEV))
     assert 2 * cl.shape[1] <= C
-    yg = hip.conv2d(xg, wg, bg, stride=stride, pad=pad, reflect=reflect, act=1)
+    yg = hip.conv2d(xg, wg, bg, stride=stride, pad=pad, reflect=reflect, act=1, x2=x2g)
     yg.backward(gy.to(DEV))
     close(yg, yr, 3e-5, 'y')
     close(xg.grad, xr.grad, 5e-5, 'gx')
+    if C2:
+        close(x2g.grad, x2r.grad, 5e-5, 'gx2')
     close(wg.grad, wr.grad, 5e-5, 'gw')
     close(bg.grad, br.grad, 5e-5, 'gb')
 

@@ -106,7 +106,8 @@ def test_flat_params_rehoming_and_inplace_grad_accumulation():
     m = fill_deterministic(torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.ReLU(), torch.nn.Linear(4, 2)))
     before = [p.detach().clone() for p in m.parameters()]
     fp = FlatParams(m.parameters())
-    assert fp.numel == sum(p.numel() for p in m.parameters())
+    assert fp.numel >= sum(p.numel() for p in m.parameters())
+    assert all(o % FlatParams.ALIGN == 0 for o in fp.offsets)      # aligned slices => vector weight loads
     for p, b in zip(m.parameters(), before):
         assert torch.equal(p, b)
         assert p.data_ptr() >= fp.flat.data_ptr() and p.data_ptr() < fp.flat.data_ptr() + fp.numel * 4
@@ -117,7 +118,7 @@ def test_flat_params_rehoming_and_inplace_grad_accumulation():
     ref = fill_deterministic(torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.ReLU(), torch.nn.Linear(4, 2)))
     (ref(torch.ones(3, 5)).sum() * 2).backward()
     flat_ref = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
-    assert torch.allclose(fp.grad, flat_ref)
+    assert torch.allclose(fp.packed(fp.grad), flat_ref)
 
 
 def test_synthetic_batches_follow_the_collate_contract():
