@@ -160,6 +160,7 @@ struct Gather {
   int PH, PW;                            // pixel grid the OTHER index runs over (output grid)
   int stride, sshift, pad, reflect;
   int bcast2;                            // src2 is [img][C2], broadcast over the spatial grid
+  int pstep, ph0, pw0;                   // the pixel grid is the sub-lattice (pstep*i + ph0, pstep*j + pw0) of the full one
 };
 
 // offset of tap (kh, kw) inside one stored channel plane for anchor (ah, aw); -1 = contributes zero
@@ -232,7 +233,8 @@ struct LoadGatherKN {
     const int phw = g.PH * g.PW;
     const int img = nn / phw;
     const int pix = nn - img * phw;
-    const int ph = pix / g.PW, pw = pix - ph * g.PW;
+    const int pi = pix / g.PW;
+    const int ph = pi * g.pstep + g.ph0, pw = (pix - pi * g.PW) * g.pstep + g.pw0;
     int ah, aw;
     if (MODE == 0) { ah = ph * g.stride - g.pad; aw = pw * g.stride - g.pad; }
     else { ah = ph + g.pad; aw = pw + g.pad; }
@@ -555,6 +557,8 @@ struct LoadTapNK {
 // ------------------------------------------------------------------------------------------------
 struct EpNCHW {     // out[z][img][m][pix], n = img*PHW + pix ; bias per row m (z = split-K slab, raw partials)
   float* out; const float* bias; int PHW, Mtot, M, Npix, act; float slope; size_t zstride;
+  // optional scatter of a pixel sub-lattice into the full grid (parity-decomposed strided transposed gathers)
+  int PWs, step, h0, w0, PWf, PHWf;
   __device__ __forceinline__ void set_limit(int n) { Npix = n; }
   template <int TM, int TN>
   __device__ __forceinline__ void store(f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int z) const {
@@ -562,8 +566,14 @@ struct EpNCHW {     // out[z][img][m][pix], n = img*PHW + pix ; bias per row m (
     for (int j = 0; j < TN; ++j) {
       const int n = nbase + j * 32 + (lane & 31);
       if (n >= Npix) continue;
-      const int img = n / PHW, pix = n - img * PHW;
-      float* o = out + (size_t)z * zstride + (size_t)img * Mtot * PHW + pix;
+      const int img = n / PHW;
+      int pix = n - img * PHW, plane = PHW;
+      if (step > 1) {
+        const int i = pix / PWs;
+        pix = (i * step + h0) * PWf + (pix - i * PWs) * step + w0;
+        plane = PHWf;
+      }
+      float* o = out + (size_t)z * zstride + (size_t)img * Mtot * plane + pix;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -572,7 +582,7 @@ struct EpNCHW {     // out[z][img][m][pix], n = img*PHW + pix ; bias per row m (
           if (m < M) {
             float v = acc[i][j][r];
             if (bias) v += bias[m];
-            o[(size_t)m * PHW] = sg_apply_act(v, act, slope);
+            o[(size_t)m * plane] = sg_apply_act(v, act, slope);
           }
         }
       }
@@ -822,7 +832,7 @@ Gather make_gather(const float* s1, const float* s2, int C1, int C2, int SH, int
   g.src1 = s1; g.src2 = s2; g.C1 = C1; g.C2 = C2; g.SH = SH; g.SW = SW;
   g.ushift = ups == 2 ? 1 : 0; g.LH = SH << g.ushift; g.LW = SW << g.ushift;
   g.PH = PH; g.PW = PW; g.stride = stride; g.sshift = stride == 2 ? 1 : 0; g.pad = pad; g.reflect = reflect;
-  g.bcast2 = 0;
+  g.bcast2 = 0; g.pstep = 1; g.ph0 = 0; g.pw0 = 0;
   return g;
 }
 
@@ -887,8 +897,8 @@ int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* b
                        (unsigned)(g.SH * g.SW), g.bcast2, nomask ? 1 : 0);
   }
   const size_t nout = (size_t)M * Npix;
-  EpNCHW ep{out, bias, g.PH * g.PW, Mtot, M, Npix, act, slope, 0};
-  if (splits > 1) ep = EpNCHW{slabs, nullptr, g.PH * g.PW, Mtot, M, Npix, SG_ACT_NONE, 0.f, nout};
+  EpNCHW ep{out, bias, g.PH * g.PW, Mtot, M, Npix, act, slope, 0, 0, 1, 0, 0, 0, 0};
+  if (splits > 1) ep = EpNCHW{slabs, nullptr, g.PH * g.PW, Mtot, M, Npix, SG_ACT_NONE, 0.f, nout, 0, 1, 0, 0, 0, 0};
   {
     SgProfScope prof(sg_igemm_kind(MODE, KS, tile), s, flops, 0);
     switch (tile) {
@@ -960,7 +970,7 @@ int run_kn_sparse(const float* W, int M, int K, const Gather& g, int NB, const f
     hipLaunchKernelGGL(build_sparse_fwd_kernel, dim3(sg_cdiv(work, 256), NB), dim3(256), 0, s, W, M, K, KS2, g.C1, g.C2,
                        (unsigned)(g.SH * g.SW), g.bcast2, sp.list, sp.cnt, sp.L, Kc, Kpad, Wc, ktab, kcnt, nomask ? 1 : 0);
   }
-  EpNCHW ep{out, bias, PHW, M, M, Npix, act, slope, 0};
+  EpNCHW ep{out, bias, PHW, M, M, Npix, act, slope, 0, 0, 1, 0, 0, 0, 0};
   // flops actually issued: the padded compact K of every image (bench.py prices the dominant kernel with this)
   const double flops = 2.0 * M * (double)Kc * Npix;
   t_batch = BatchInfo{PHW, NB, kcnt, M * Kc, Kpad};
@@ -974,6 +984,88 @@ int run_kn_sparse(const float* W, int M, int K, const Gather& g, int NB, const f
   }
   t_batch = BatchInfo{0, 0, nullptr, 0, 0};
   return 0;
+}
+
+// ---- stride-2 transposed gathers (dgrad of a strided conv, forward of a transposed conv) -------------------
+// An output pixel (ph, pw) only receives taps with kh == (ph + pad) and kw == (pw + pad) modulo the stride: run as
+// one dense problem, 3 of 4 gathered taps are structural zeros.  Instead: one GEMM per parity class (a, b) over the
+// pixels of that class, with a compact weight matrix / k-table that lists only the class's taps -- 4x fewer MACs.
+struct TapList { int n; int t[16]; };
+
+// A[m][r*nt + i] = W[(r*B + m0 + m)*R + taps[i]]   (W = [reduction dim][B][R] in memory)
+__global__ void permute_sub_kernel(const float* W, float* A, int Rdim, int B, int m0, int M, int R, TapList tl) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t K = (size_t)Rdim * tl.n;
+  if (i >= (size_t)M * K) return;
+  const int m = (int)(i / K);
+  const int k = (int)(i - (size_t)m * K);
+  const int r = k / tl.n, ti = k - r * tl.n;
+  A[i] = W[((size_t)r * B + m0 + m) * R + tl.t[ti]];
+}
+__global__ void build_ktab_sub_kernel(KEntry* tab, int K, int Kpad, unsigned shw, int KS2, TapList tl) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= Kpad) return;
+  KEntry e;
+  if (k < K) {
+    const int r = k / tl.n, ti = k - r * tl.n;
+    e.choff = (unsigned)r * shw; e.tapsel = (unsigned)tl.t[ti];
+  } else {
+    e.choff = 0u; e.tapsel = (unsigned)KS2;
+  }
+  tab[k] = e;
+}
+
+template <int KS>
+int run_kn_parity(const float* W, int Rdim, int B, int m0, int M, const Gather& g, int NB, const float* bias, float* out,
+                  int Mtot, int act, float slope, double flops, void* ws, size_t ws_bytes, hipStream_t s) {
+  constexpr int KS2 = KS * KS;
+  float* wbase = reinterpret_cast<float*>(ws);
+  KEntry* kbase = reinterpret_cast<KEntry*>(wbase + (size_t)M * Rdim * KS2);
+  size_t woff = 0, koff = 0;
+  const unsigned shw = (unsigned)(g.SH * g.SW);
+  for (int a = 0; a < 2; ++a) {
+    for (int b = 0; b < 2; ++b) {
+      TapList tl; tl.n = 0;
+      for (int kh = a; kh < KS; kh += 2)
+        for (int kw = b; kw < KS; kw += 2) tl.t[tl.n++] = kh * KS + kw;
+      const int ph0 = ((a - g.pad) % 2 + 2) % 2, pw0 = ((b - g.pad) % 2 + 2) % 2;
+      const int PHa = g.PH > ph0 ? (g.PH - ph0 + 1) / 2 : 0, PWb = g.PW > pw0 ? (g.PW - pw0 + 1) / 2 : 0;
+      if (PHa * PWb == 0) continue;
+      const int K = Rdim * tl.n, Kpad = sg_cdiv(K, 64) * 64 + 128;
+      float* A = wbase + woff;
+      KEntry* ktab = kbase + koff;
+      woff += (size_t)M * K; koff += (size_t)Kpad;
+      hipLaunchKernelGGL(permute_sub_kernel, dim3(sg_cdiv((size_t)M * K, 256)), dim3(256), 0, s, W, A, Rdim, B, m0, M, KS2, tl);
+      hipLaunchKernelGGL(build_ktab_sub_kernel, dim3(sg_cdiv(Kpad, 256)), dim3(256), 0, s, ktab, K, Kpad, shw, KS2, tl);
+      Gather gs = g;
+      gs.PH = PHa; gs.PW = PWb; gs.pstep = 2; gs.ph0 = ph0; gs.pw0 = pw0;
+      const int Npix = NB * PHa * PWb;
+      const EpNCHW ep{out, bias, PHa * PWb, Mtot, M, Npix, act, slope, 0, PWb, 2, ph0, pw0, g.PW, g.PH * g.PW};
+      const bool vec = (K % 4 == 0) && aligned16(A);
+      int tile = pick_tile(M, Npix);
+      if (!vec && tile == 0) tile = 1;
+      SgProfScope prof(sg_igemm_kind(1, KS, tile), s, flops * (4.0 * tl.n * PHa * PWb) / ((double)KS2 * g.PH * g.PW), 0);
+      switch (tile) {
+        case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, 1>(A, K, M, true, gs, Npix, ktab, ep, 1, false, s); break;
+        case 1: launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, 1>(A, K, M, vec, gs, Npix, ktab, ep, 1, false, s); break;
+        default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, 1>(A, K, M, vec, gs, Npix, ktab, ep, 1, false, s); break;
+      }
+    }
+  }
+  (void)ws_bytes;
+  return 0;
+}
+inline size_t parity_ws(int M, int Rdim, int KS2) {
+  return (size_t)M * Rdim * KS2 * sizeof(float) + 4 * ((size_t)(sg_cdiv((size_t)Rdim * KS2, 64) * 64 + 128 + 64) * sizeof(KEntry));
+}
+int run_kn_parity_ks(int KS, const float* W, int Rdim, int B, int m0, int M, const Gather& g, int NB, const float* bias,
+                     float* out, int Mtot, int act, float slope, double flops, void* ws, size_t ws_bytes, hipStream_t s) {
+  switch (KS) {
+    case 3: return run_kn_parity<3>(W, Rdim, B, m0, M, g, NB, bias, out, Mtot, act, slope, flops, ws, ws_bytes, s);
+    case 4: return run_kn_parity<4>(W, Rdim, B, m0, M, g, NB, bias, out, Mtot, act, slope, flops, ws, ws_bytes, s);
+    case 7: return run_kn_parity<7>(W, Rdim, B, m0, M, g, NB, bias, out, Mtot, act, slope, flops, ws, ws_bytes, s);
+  }
+  return -1;
 }
 
 template <int MODE>
@@ -1163,7 +1255,7 @@ extern "C" size_t sg_conv2d_ws_bytes(const sgConvDesc* d, int kind) {
   if (!d) return 0;
   const size_t wbytes = (size_t)d->Cout * (d->C1 + d->C2) * d->KS * d->KS * sizeof(float);
   const int Kmax = (d->Cout > d->C1 + d->C2 ? d->Cout : d->C1 + d->C2) * d->KS * d->KS;
-  const size_t kt = ktab_bytes(Kmax);
+  const size_t kt = 4 * (ktab_bytes(Kmax) + 64 * sizeof(KEntry));   // up to four parity-class tables
   const int Cin = d->C1 + d->C2, R = d->KS * d->KS;
   const size_t sl_f = kn_slab_bytes(d->Cout, d->N * d->OH * d->OW, Cin * R);                 // conv fwd / convT fwd
   const int GH = d->H * d->upsample + (d->pad_reflect ? 2 * d->pad : 0), GW = d->W * d->upsample + (d->pad_reflect ? 2 * d->pad : 0);
@@ -1207,9 +1299,6 @@ extern "C" int sg_conv2d_dgrad(const sgConvDesc* d, const float* gy, const float
   SG_ARG_CHECK(ws_bytes >= (size_t)d->Cout * Cin * R * sizeof(float) + ktab_bytes(d->Cout * R),
                "sg_conv2d_dgrad: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  float* wt = reinterpret_cast<float*>(ws);      // [Cin][Cout][R]
-  const size_t nw = (size_t)d->Cout * Cin * R;
-  hipLaunchKernelGGL(permute_w_kernel, dim3(sg_cdiv(nw, 256)), dim3(256), 0, s, w, wt, d->Cout, Cin, R);
   // gradient w.r.t. the logical (upsampled, reflect-padded) input grid
   const int GH = d->H * d->upsample + (d->pad_reflect ? 2 * d->pad : 0);
   const int GW = d->W * d->upsample + (d->pad_reflect ? 2 * d->pad : 0);
@@ -1218,6 +1307,16 @@ extern "C" int sg_conv2d_dgrad(const sgConvDesc* d, const float* gy, const float
   const int M = c_end - c_begin, K = d->Cout * R;
   // algorithmic flops of a dgrad = those of the forward conv restricted to the requested input channels
   const double flops = 2.0 * M * (double)d->Cout * R * d->N * d->OH * d->OW;
+  if (d->stride == 2 && d->KS >= 3) {          // parity classes: only the taps that can hit each output pixel
+    SG_ARG_CHECK(ws_bytes >= parity_ws(M, d->Cout, R), "sg_conv2d_dgrad: workspace too small");
+    int rc = run_kn_parity_ks(d->KS, w, d->Cout, Cin, c_begin, M, g, d->N, nullptr, gx, M, SG_ACT_NONE, 0.f, flops, ws,
+                              ws_bytes, s);
+    SG_LAUNCH_CHECK("sg_conv2d_dgrad");
+    return rc;
+  }
+  float* wt = reinterpret_cast<float*>(ws);      // [Cin][Cout][R]
+  const size_t nw = (size_t)d->Cout * Cin * R;
+  hipLaunchKernelGGL(permute_w_kernel, dim3(sg_cdiv(nw, 256)), dim3(256), 0, s, w, wt, d->Cout, Cin, R);
   int rc = run_kn_ks<1>(d->KS, wt + (size_t)c_begin * K, M, K, g, d->N, nullptr, gx, M, SG_ACT_NONE, 0.f, flops,
                         wt + nw, ws_bytes - nw * sizeof(float), s);
   SG_LAUNCH_CHECK("sg_conv2d_dgrad");
@@ -1301,11 +1400,18 @@ extern "C" int sg_convT2d_fwd(const sgConvDesc* d, const float* x, const float* 
   SG_ARG_CHECK(ws_bytes >= (size_t)d->Cout * Cin * R * sizeof(float) + ktab_bytes(Cin * R),
                "sg_convT2d_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
+  Gather g = make_gather(x, nullptr, Cin, 0, d->H, d->W, 1, d->OH, d->OW, d->stride, d->pad, 0);
+  const double flops = 2.0 * d->Cout * Cin * R * (double)d->N * d->H * d->W;
+  if (d->stride == 2 && d->KS >= 3) {
+    SG_ARG_CHECK(ws_bytes >= parity_ws(d->Cout, Cin, R), "sg_convT2d_fwd: workspace too small");
+    int rc = run_kn_parity_ks(d->KS, w, Cin, d->Cout, 0, d->Cout, g, d->N, bias, y, d->Cout, SG_ACT_NONE, 0.f, flops, ws,
+                              ws_bytes, s);
+    SG_LAUNCH_CHECK("sg_convT2d_fwd");
+    return rc;
+  }
   float* wt = reinterpret_cast<float*>(ws);      // [Cout][Cin][R]
   const size_t nw = (size_t)d->Cout * Cin * R;
   hipLaunchKernelGGL(permute_w_kernel, dim3(sg_cdiv(nw, 256)), dim3(256), 0, s, w, wt, Cin, d->Cout, R);
-  Gather g = make_gather(x, nullptr, Cin, 0, d->H, d->W, 1, d->OH, d->OW, d->stride, d->pad, 0);
-  const double flops = 2.0 * d->Cout * Cin * R * (double)d->N * d->H * d->W;
   int rc = run_kn_ks<1>(d->KS, wt, d->Cout, Cin * R, g, d->N, bias, y, d->Cout, SG_ACT_NONE, 0.f, flops, wt + nw,
                         ws_bytes - nw * sizeof(float), s);
   SG_LAUNCH_CHECK("sg_convT2d_fwd");
