@@ -770,8 +770,11 @@ inline int pick_tile(int M, int N) {
   if (force == -2) { const char* e = getenv("SG_TILE"); force = e ? atoi(e) : -1; }
   if (force >= 0) return force;
   if (M <= 32) return 2;
+  // measured (tools/bench_conv.py): 128x128 tiles win when M is large (>= 512 rows, split-K fills the chip) or when
+  // there are enough of them anyway; 64x64 tiles otherwise
   const long t128 = (long)sg_cdiv(M, 128) * sg_cdiv(N, 128);
-  if (M >= 96 && t128 >= 384) return 0;
+  const bool low_waste = sg_cdiv(M, 128) * 128 * 20 <= M * 23 && N >= 512;
+  if (M >= 96 && low_waste && (M >= 512 || t128 >= 384)) return 0;
   return 1;
 }
 
@@ -862,10 +865,16 @@ inline int kn_tiles(int M, int Npix) {
   return t == 0 ? sg_cdiv(M, 128) * sg_cdiv(Npix, 128) : (t == 1 ? sg_cdiv(M, 64) * sg_cdiv(Npix, 64) : sg_cdiv(Npix, 128));
 }
 inline int kn_splits(int M, int Npix, int K) {
+  static int force = -2;
+  if (force == -2) { const char* e = getenv("SG_SPLITS"); force = e ? atoi(e) : -1; }
+  if (force > 0) return force;
   const int tiles = kn_tiles(M, Npix);
-  if (tiles >= 256 || K < 2048) return 1;
-  int sp = 512 / tiles;
-  if (sp > K / 512) sp = K / 512;
+  // workgroups wanted in flight: ~6 per CU of the 64x64 / 32x128 kernels, 3 per CU (the register limit) of 128x128
+  const int target = pick_tile(M, Npix) == 0 ? 1024 : 1536;
+  if (tiles * 4 >= target * 3 || K < 2048) return 1;
+  int sp = (target + tiles / 2) / tiles;
+  if (sp > 2 && (sp & 1)) ++sp;                 // odd split counts measured 10 % slower than their even neighbours
+  if (sp > K / 1024) sp = K / 1024;
   if (sp > 8) sp = 8;
   return sp < 2 ? 1 : sp;
 }
@@ -1043,7 +1052,7 @@ int run_kn_parity(const float* W, int Rdim, int B, int m0, int M, const Gather& 
       const EpNCHW ep{out, bias, PHa * PWb, Mtot, M, Npix, act, slope, 0, PWb, 2, ph0, pw0, g.PW, g.PH * g.PW};
       const bool vec = (K % 4 == 0) && aligned16(A);
       int tile = pick_tile(M, Npix);
-      if (!vec && tile == 0) tile = 1;
+      if (tile == 0 && (!vec || (long)sg_cdiv(M, 128) * sg_cdiv(Npix, 128) < 384)) tile = 1;   // no split-K here
       SgProfScope prof(sg_igemm_kind(1, KS, tile), s, flops * (4.0 * tl.n * PHa * PWb) / ((double)KS2 * g.PH * g.PW), 0);
       switch (tile) {
         case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, 1>(A, K, M, true, gs, Npix, ktab, ep, 1, false, s); break;
