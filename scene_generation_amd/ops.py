@@ -4,6 +4,7 @@ PyTorch-ROCm is used here as plumbing only: device allocation (torch.empty), the
 the current HIP stream.  Every forward/backward below is one or a few hand-written gfx950 kernel
 launches through ctypes; there is no eager/CPU fallback -- a CPU tensor raises.
 """
+import contextlib
 import ctypes
 
 import torch
@@ -128,8 +129,9 @@ class Conv2dFn(Function):
             g2 = torch.empty_like(gy)
             _call('sg_act_bwd', _p(y), _p(gy), _p(g2), gy.numel(), act, slope, s)
             gy = g2
-        need_x1, need_x2, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and x2 is not None, ctx.needs_input_grad[2]
-        need_b = has_bias and ctx.needs_input_grad[3]
+        need_x1, need_x2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and x2 is not None
+        need_w = ctx.needs_input_grad[2] and _wants_grad(weight)
+        need_b = has_bias and ctx.needs_input_grad[3] and need_w
         gx1 = gx2 = gw = gb = None
         dev = gy.device
         if need_x1 or need_x2:
@@ -181,6 +183,26 @@ class Conv2dFn(Function):
                 ws = workspace(wsb, dev)
                 _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb, s)
         return gx1, gx2, gw, gb, None, None, None, None, None, None, None, None
+
+
+_SKIP_PARAM_GRADS = set()
+
+
+@contextlib.contextmanager
+def skip_param_grads(params):
+    """While active, backward passes do not compute (nor accumulate) gradients of ``params`` even though they require
+    grad: lets a discriminator forward recorded during the generator step be re-used by the discriminator step
+    (the reference re-runs the identical forward, trainer.py:302-325) without paying for weight gradients twice."""
+    ids = {p.data_ptr() for p in params}
+    _SKIP_PARAM_GRADS.update(ids)
+    try:
+        yield
+    finally:
+        _SKIP_PARAM_GRADS.difference_update(ids)
+
+
+def _wants_grad(t):
+    return t is not None and t.data_ptr() not in _SKIP_PARAM_GRADS
 
 
 _HINTS = ('_sg_sparse', '_sg_sparse_cat', '_sg_grad_from')

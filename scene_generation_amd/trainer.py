@@ -168,9 +168,17 @@ class Trainer:
     # ---- step functions ----
     def train_generator(self, imgs, imgs_pred, masks, masks_pred, layout, objs, boxes, boxes_pred, obj_to_img,
                         use_gt):
+        """trainer.py:205-263.  The mask / image discriminator forwards recorded here are the same computation the
+        discriminator steps repeat on detached inputs (same weights: no discriminator is updated in between,
+        train.py:205-215; InstanceNorm has no running statistics), so they are kept in ``self._shared`` and the D steps
+        back-propagate through them instead of re-running them.  Their parameters are excluded from THIS backward
+        (the reference computes and then discards those gradients, trainer.py:262 vs :298,323).  The object
+        discriminator has BatchNorm running statistics that every forward updates, so it is not shared."""
         args = self.args
         self.generator_losses = L = LossManager()
-        with _frozen(self.obj_discriminator, self.mask_discriminator, self.netD):
+        self._shared = shared = {}
+        d_shared = [p for m in (self.mask_discriminator, self.netD) if m is not None for p in m.parameters()]
+        with _frozen(self.obj_discriminator), ops.skip_param_grads(d_shared):
             if use_gt:
                 if args.l1_pixel_loss_weight > 0:
                     L.add_loss(ops.l1(imgs_pred, imgs), 'L1_pixel_loss', args.l1_pixel_loss_weight)
@@ -183,25 +191,28 @@ class Trainer:
             if self.mask_discriminator is not None:
                 one_hot_obj = ops.one_hot(objs, self.num_obj)
                 scores_fake = self.mask_discriminator(masks_pred.unsqueeze(1), one_hot_obj)
+                shared['mask_fake'] = scores_fake
                 L.add_loss(self.criterionGAN(scores_fake, True), 'g_gan_mask_obj_loss', args.d_mask_weight)
                 if args.d_mask_features_weight > 0:
-                    with torch.no_grad():           # real features are detached anyway (trainer.py:339)
-                        scores_real = self.mask_discriminator(masks.float().unsqueeze(1), one_hot_obj)
+                    scores_real = self.mask_discriminator(masks.float().unsqueeze(1), one_hot_obj)
+                    shared['mask_real'] = scores_real
                     L.add_loss(self.calculate_features_loss(scores_fake, scores_real), 'g_mask_features_loss',
-                               args.d_mask_features_weight)
+                               args.d_mask_features_weight)      # real features enter detached (trainer.py:339)
 
             if self.netD is not None:
-                with torch.no_grad():               # "train textures" pass: only detached features are used
-                    pred_real = self.netD(layout, imgs)
-                img_pred_fake = self.netD(ops.detach_keep(layout), imgs_pred)
+                lay = ops.detach_keep(layout)       # no gradient reaches the layout through D (trainer.py:246-248)
+                img_pred_fake = self.netD(lay, imgs_pred)
+                shared['img_fake'] = img_pred_fake
                 L.add_loss(self.criterionGAN(img_pred_fake, True), 'g_gan_img_loss', args.d_img_weight)
                 if args.d_img_features_weight > 0:
+                    pred_real = self.netD(lay, imgs)            # "train textures" pass
+                    shared['img_real'] = pred_real
                     L.add_loss(self.calculate_features_loss(img_pred_fake, pred_real), 'g_gan_features_loss_img',
                                args.d_img_features_weight)
 
             L.set_value('total_loss', L.total_loss)
             self.optimizer.zero_grad()
-            L.total_loss.backward()
+            L.total_loss.backward(retain_graph=bool(shared))
         self.optimizer.step()
 
     def train_obj_discriminator(self, imgs, imgs_pred, objs, boxes, boxes_pred, obj_to_img):
@@ -220,25 +231,39 @@ class Trainer:
     def train_mask_discriminator(self, masks, masks_pred, objs):
         if self.mask_discriminator is not None:
             self.d_mask_losses = L = LossManager()
+            shared = getattr(self, '_shared', {})
             one_hot_obj = ops.one_hot(objs, self.num_obj)
-            scores_fake = self.mask_discriminator(masks_pred.unsqueeze(1), one_hot_obj)
-            scores_real = self.mask_discriminator(masks.float().unsqueeze(1), one_hot_obj)
+            scores_fake = shared.pop('mask_fake', None)
+            if scores_fake is None:
+                scores_fake = self.mask_discriminator(masks_pred.unsqueeze(1), one_hot_obj)
+            scores_real = shared.pop('mask_real', None)
+            if scores_real is None:
+                scores_real = self.mask_discriminator(masks.float().unsqueeze(1), one_hot_obj)
             L.add_loss(self.criterionGAN(scores_fake, False), 'fake_loss', 0.5)
             L.add_loss(self.criterionGAN(scores_real, True), 'real_loss', 0.5)
             self.optimizer_d_mask.zero_grad()
-            L.total_loss.backward()
+            # inputs=: a shared forward still hangs off the generator's graph; only the discriminator leaves are wanted
+            torch.autograd.backward(L.total_loss, inputs=list(self.mask_discriminator.parameters()))
             self.optimizer_d_mask.step()
 
     def train_image_discriminator(self, imgs, imgs_pred, layout, layout_wrong):
         if self.netD is not None:
             self.d_img_losses = L = LossManager()
+            shared = getattr(self, '_shared', {})
             alpha = (1 / 2) * (.5)
-            L.add_loss(self.criterionGAN(self.discriminate(layout, imgs_pred), False), 'fake_image_loss', alpha)
+            pred_fake = shared.pop('img_fake', None)
+            if pred_fake is None:
+                pred_fake = self.discriminate(layout, imgs_pred)
+            pred_real = shared.pop('img_real', None)
+            if pred_real is None:
+                pred_real = self.discriminate(layout, imgs)
+            L.add_loss(self.criterionGAN(pred_fake, False), 'fake_image_loss', alpha)
             L.add_loss(self.criterionGAN(self.discriminate(layout_wrong, imgs), False), 'wrong_texture_loss', alpha)
-            L.add_loss(self.criterionGAN(self.discriminate(layout, imgs), True), 'd_img_gan_real_loss', 0.5)
+            L.add_loss(self.criterionGAN(pred_real, True), 'd_img_gan_real_loss', 0.5)
             self.optimizer_d_img.zero_grad()
-            L.total_loss.backward()
+            torch.autograd.backward(L.total_loss, inputs=list(self.netD.parameters()))
             self.optimizer_d_img.step()
+            self._shared = {}
 
     def discriminate(self, input_label, test_image):
         return self.netD(input_label, test_image)        # cat((label, image), 1) folded into the first conv
