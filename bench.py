@@ -36,6 +36,8 @@ def parse():
     p.add_argument('--cpu_baseline', default='auto', choices=['auto', 'off'])
     p.add_argument('--cpu_images', type=int, default=4)
     p.add_argument('--no_prof', action='store_true')
+    p.add_argument('--no_share_d_forward', action='store_true',
+                   help='re-run the mask/image discriminator forwards in the D steps like the reference does')
     return p.parse_args()
 
 
@@ -87,6 +89,7 @@ def main():
     torch.manual_seed(1234)                       # same initial weights on every rank (also broadcast in Trainer)
     tr = Trainer(args, make_vocab(), device=dev, distributed=world > 1)
     tr.model.layout_objects_hint = 9
+    tr.share_d_forward = not a.no_share_d_forward
     # two pre-staged batches per rank (different data per rank: weak scaling), resident in HBM
     batches = [batch_to(make_batch(N=B, min_objs=3, max_objs=8, size=S, seed=1000 * rank + i), dev) for i in range(2)]
     hosts = [(b.objs.tolist(), b.obj_to_img.tolist()) for b in batches]
@@ -130,7 +133,8 @@ def main():
         'config': {'workload': 'BASELINE configs[1]: COCO-Stuff-shaped %dx%d, <=8 objects/img (+__image__), batch %d '
                                'per GPU, full G+D train step (G fwd/bwd + 3 D steps + 4 Adam%s), reference default '
                                'widths, VGG loss off' % (S, S, B, ' + RCCL grad all-reduce' if world > 1 else ''),
-                   'global_batch': B * world, 'image_size': S, 'parallelism': 'dp%d' % world},
+                   'global_batch': B * world, 'image_size': S, 'parallelism': 'dp%d' % world,
+                   'share_d_forward': not a.no_share_d_forward},
     }
     if rank == 0:
         if not a.no_prof:

@@ -177,6 +177,7 @@ class Trainer:
         args = self.args
         self.generator_losses = L = LossManager()
         self._shared = shared = {}
+        share = getattr(self, 'share_d_forward', True)
         d_shared = [p for m in (self.mask_discriminator, self.netD) if m is not None for p in m.parameters()]
         with _frozen(self.obj_discriminator), ops.skip_param_grads(d_shared):
             if use_gt:
@@ -191,22 +192,28 @@ class Trainer:
             if self.mask_discriminator is not None:
                 one_hot_obj = ops.one_hot(objs, self.num_obj)
                 scores_fake = self.mask_discriminator(masks_pred.unsqueeze(1), one_hot_obj)
-                shared['mask_fake'] = scores_fake
+                if share:
+                    shared['mask_fake'] = scores_fake
                 L.add_loss(self.criterionGAN(scores_fake, True), 'g_gan_mask_obj_loss', args.d_mask_weight)
                 if args.d_mask_features_weight > 0:
-                    scores_real = self.mask_discriminator(masks.float().unsqueeze(1), one_hot_obj)
-                    shared['mask_real'] = scores_real
+                    with (contextlib.nullcontext() if share else torch.no_grad()):
+                        scores_real = self.mask_discriminator(masks.float().unsqueeze(1), one_hot_obj)
+                    if share:
+                        shared['mask_real'] = scores_real
                     L.add_loss(self.calculate_features_loss(scores_fake, scores_real), 'g_mask_features_loss',
                                args.d_mask_features_weight)      # real features enter detached (trainer.py:339)
 
             if self.netD is not None:
                 lay = ops.detach_keep(layout)       # no gradient reaches the layout through D (trainer.py:246-248)
                 img_pred_fake = self.netD(lay, imgs_pred)
-                shared['img_fake'] = img_pred_fake
+                if share:
+                    shared['img_fake'] = img_pred_fake
                 L.add_loss(self.criterionGAN(img_pred_fake, True), 'g_gan_img_loss', args.d_img_weight)
                 if args.d_img_features_weight > 0:
-                    pred_real = self.netD(lay, imgs)            # "train textures" pass
-                    shared['img_real'] = pred_real
+                    with (contextlib.nullcontext() if share else torch.no_grad()):
+                        pred_real = self.netD(lay, imgs)        # "train textures" pass
+                    if share:
+                        shared['img_real'] = pred_real
                     L.add_loss(self.calculate_features_loss(img_pred_fake, pred_real), 'g_gan_features_loss_img',
                                args.d_img_features_weight)
 
