@@ -168,6 +168,13 @@ int sg_masks_to_layout_fwd(const float* vecs, const float* boxes, const void* ma
                            const int32_t* seg_off, float* out, int N, int O, int D, int M, int H, int W, int avg,
                            int max_per_image /* hint: objects per image the LDS tile is provisioned for; 0 = default */,
                            sgStream stream);
+/* test-mode compositing (layout.py:87-92,157-169): per image, objects are visited in ascending mass
+ * (sum over d,h,w of vecs[o,d]*sampled_mask_o[h,w]; ties by index) and a pixel takes vecs[o]*sampled_mask_o of the
+ * first visited object whose sampled mask exceeds 0.5 (zero if none).  Inference only: no backward. */
+size_t sg_masks_to_layout_test_ws_bytes(int O);
+int sg_masks_to_layout_test_fwd(const float* vecs, const float* boxes, const void* masks, int masks_i64,
+                                const int32_t* seg_off, float* out, void* ws, size_t ws_bytes, int N, int O, int D, int M,
+                                int H, int W, int avg, sgStream stream);
 /* g_vecs[o, d] for d in [d_begin, D) (columns below d_begin are zero-filled) */
 int sg_masks_to_layout_bwd_vecs(const float* gout, const float* boxes, const void* masks, int masks_i64,
                                 const int64_t* obj_to_img, const int32_t* seg_off, float* g_vecs, int N, int O, int D,

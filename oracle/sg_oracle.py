@@ -87,17 +87,33 @@ def _box_grid(boxes, H, W):
 
 
 def masks_to_layout(vecs, boxes, masks, obj_to_img, H, W=None, pooling='sum', test_mode=False):
-    """layout.py:64-93 (train branch of _pool_samples, layout.py:131-155,172-183)."""
+    """layout.py:64-93 (both branches of _pool_samples, layout.py:131-183)."""
     O, D = vecs.shape
     M = masks.size(1)
     assert masks.shape == (O, M, M)
     W = H if W is None else W
-    if test_mode:
-        raise NotImplementedError('test-mode compositing is SURVEY 8f rank 1 (next)')
     gx, gy = _box_grid(boxes, H, W)
     S = bilinear_sample(masks.to(vecs.dtype).view(O, 1, M, M), gx, gy)[:, 0]      # (O,H,W); masks.float() in fp32
     N, starts, ends, counts = _segments(obj_to_img)
     out = vecs.new_zeros(N, D, H, W)
+    if test_mode:
+        # layout.py:87-92,157-169: per image the objects are visited in ascending "mass" (sum of the sampled
+        # vecs (x) mask tensor); a pixel belongs to the first visited object whose sampled mask exceeds 0.5
+        import numpy as np
+        for n in range(N):
+            lo, hi = int(starts[n]), int(ends[n])
+            samples = [vecs[o].view(D, 1, 1) * S[o].view(1, H, W) for o in range(lo, hi)]
+            mass = [float(t.sum()) for t in samples]
+            taken = vecs.new_zeros(H, W)
+            for j in np.argsort(mass):
+                m = (taken == 0).to(vecs.dtype) * (S[lo + j] > 0.5).to(vecs.dtype)
+                taken = taken + m
+                out[n] = out[n] + samples[j] * m
+        if pooling == 'avg':
+            out = out / counts.clamp(min=1).to(out).view(N, 1, 1, 1)
+        elif pooling != 'sum':
+            raise ValueError('Invalid pooling "%s"' % pooling)
+        return out
     for n in range(N):
         acc = None
         for o in range(int(starts[n]), int(ends[n])):                        # ascending o
@@ -683,8 +699,14 @@ class Model(nn.Module):
         noise = self.noise_override if self.noise_override is not None else \
             torch.randn((1, self.mask_noise_dim), dtype=obj_vecs.dtype, device=obj_vecs.device)
         mask_vecs = torch.cat([obj_vecs, noise.repeat(O, 1)], dim=1)
-        crops = crop_bbox_batch(imgs, boxes, obj_to_img, self.object_size)
-        obj_repr = self.repr_net(self.image_encoder(crops))
+        if features is None:
+            crops = crop_bbox_batch(imgs, boxes, obj_to_img, self.object_size)
+            obj_repr = self.repr_net(self.image_encoder(crops))
+        else:                                               # inference only (model.py:158-163)
+            obj_repr = self.repr_net(mask_vecs)
+            for ind, feature in enumerate(features):
+                if feature is not None:
+                    obj_repr[ind, :] = feature
         one_hot = torch.zeros(O, self.num_objs, dtype=obj_repr.dtype).scatter_(1, objs.view(-1, 1), 1.0)
         layout_vecs = torch.cat([one_hot, obj_repr], dim=1)
         wrong = self.fake_pool.query(objs, obj_repr)
@@ -692,7 +714,6 @@ class Model(nn.Module):
 
     def forward(self, gt_imgs, objs, triples, obj_to_img, boxes_gt=None, masks_gt=None, attributes=None,
                 test_mode=False, use_gt_box=False, features=None):
-        assert not test_mode, 'inference branch is SURVEY 8f (next)'
         O = objs.size(0)
         obj_vecs, _ = self.scene_graph_to_vectors(objs, triples, attributes)
         box_vecs, mask_vecs, layout_vecs, wrong_vecs = self.create_components_vecs(
@@ -700,6 +721,11 @@ class Model(nn.Module):
         boxes_pred = self.box_net(box_vecs)
         masks_pred = self.mask_net(mask_vecs.view(O, -1, 1, 1)).squeeze(1).sigmoid()
         H, W = self.image_size
+        if test_mode:                                       # model.py:111-117
+            boxes = boxes_gt if use_gt_box else boxes_pred
+            masks = masks_gt if masks_gt is not None else masks_pred
+            pred_layout = masks_to_layout(layout_vecs, boxes, masks, obj_to_img, H, W, test_mode=True)
+            return self.layout_to_image(pred_layout), boxes_pred, masks_pred, None, pred_layout, None
         gt_layout = masks_to_layout(layout_vecs, boxes_gt, masks_gt, obj_to_img, H, W)
         pred_layout = masks_to_layout(layout_vecs, boxes_gt, masks_pred, obj_to_img, H, W)
         wrong_layout = masks_to_layout(wrong_vecs, boxes_gt, masks_gt, obj_to_img, H, W)

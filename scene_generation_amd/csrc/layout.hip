@@ -281,6 +281,85 @@ __global__ void pool_scatter_kernel(float* __restrict__ pool, const float* __res
   if (slot >= 0) pool[((size_t)cls * P + slot) * R + r] = vec[i];
 }
 
+
+// ---- test-mode compositing (layout.py:87-92,157-169) ---------------------------------------------------------
+// The reference visits the objects of an image in ascending "mass" (sum over the sampled vecs (x) mask tensor, a host
+// loop with one .item() per object and numpy argsort) and gives every pixel to the first visited object whose
+// sampled mask exceeds 0.5.  Here: mass per object (factored: sum(vecs) * sum(sampled mask), fp64), rank inside the
+// image, then one pass over the pixels.  No host round trip.
+template <bool I64>
+__global__ void __launch_bounds__(256) layout_mass_kernel(const float* __restrict__ vecs, const float* __restrict__ boxes,
+                                                         const void* __restrict__ masks, double* __restrict__ mass, int D,
+                                                         int M, int H, int W) {
+  __shared__ double red[256];
+  const size_t o = blockIdx.x;
+  const float x0 = boxes[o * 4 + 0], y0 = boxes[o * 4 + 1], x1 = boxes[o * 4 + 2], y1 = boxes[o * 4 + 3];
+  double s = 0.0;
+  for (int p = threadIdx.x; p < H * W; p += 256) {
+    const int h = p / W, w = p - h * W;
+    const Tap ty = make_tap(box_coord(lin01(h, H), y0, y1), M);
+    const Tap tx = make_tap(box_coord(lin01(w, W), x0, x1), M);
+    s += (double)sample_mask<I64>(masks, o, M, ty, tx);
+  }
+  double v = 0.0;
+  for (int d = threadIdx.x; d < D; d += 256) v += (double)vecs[o * D + d];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+  const double S = red[0];
+  __syncthreads();
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) { if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k]; __syncthreads(); }
+  if (threadIdx.x == 0) mass[o] = S * red[0];
+}
+
+// order[seg[n] + r] = local index of the object visited r-th in image n (ascending mass, ties by index, NaN last)
+__global__ void layout_order_kernel(const double* __restrict__ mass, const int32_t* __restrict__ seg,
+                                    int32_t* __restrict__ order) {
+  const int n = blockIdx.x;
+  const int beg = seg[n], cnt = seg[n + 1] - beg;
+  for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+    const double mj = mass[beg + j];
+    const bool nj = mj != mj;
+    int r = 0;
+    for (int k = 0; k < cnt; ++k) {
+      const double mk = mass[beg + k];
+      const bool nk = mk != mk;
+      const bool before = nj ? (!nk || k < j) : (!nk && (mk < mj || (mk == mj && k < j)));
+      r += before ? 1 : 0;
+    }
+    order[beg + r] = j;
+  }
+}
+
+template <bool I64>
+__global__ void __launch_bounds__(256) layout_test_fwd_kernel(const float* __restrict__ vecs, const float* __restrict__ boxes,
+                                                             const void* __restrict__ masks, const int32_t* __restrict__ seg,
+                                                             const int32_t* __restrict__ order, float* __restrict__ out,
+                                                             int D, int M, int H, int W, int avg) {
+  const int n = blockIdx.y;
+  const int beg = seg[n], cnt = seg[n + 1] - beg;
+  const int HW = H * W;
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  if (px >= HW) return;
+  const int h = px / W, w = px - h * W;
+  const float Y = lin01(h, H), X = lin01(w, W);
+  int win = -1;
+  float sv = 0.f;
+  for (int r = 0; r < cnt; ++r) {
+    const size_t o = (size_t)(beg + order[beg + r]);
+    const Tap ty = make_tap(box_coord(Y, boxes[o * 4 + 1], boxes[o * 4 + 3]), M);
+    const Tap tx = make_tap(box_coord(X, boxes[o * 4 + 0], boxes[o * 4 + 2]), M);
+    const float v = sample_mask<I64>(masks, o, M, ty, tx);
+    if (v > 0.5f) { win = (int)o; sv = v; break; }
+  }
+  if (avg) sv /= (float)(cnt > 1 ? cnt : 1);
+  float* op = out + (size_t)n * D * HW + px;
+  const float* vr = vecs + (size_t)(win < 0 ? 0 : win) * D;
+  for (int d = 0; d < D; ++d) op[(size_t)d * HW] = win < 0 ? 0.f : vr[d] * sv;
+}
+
 }  // namespace
 
 extern "C" int sg_segment_offsets(const int64_t* obj_to_img, int O, int N, int32_t* seg_off, sgStream stream) {
@@ -321,6 +400,34 @@ extern "C" int sg_masks_to_layout_fwd(const float* vecs, const float* boxes, con
   else { if (use_vec == 4) LAUNCH_LAYOUT(false, 4); else LAUNCH_LAYOUT(false, 1); }
 #undef LAUNCH_LAYOUT
   SG_LAUNCH_CHECK("sg_masks_to_layout_fwd");
+  return 0;
+}
+
+extern "C" size_t sg_masks_to_layout_test_ws_bytes(int O) { return (size_t)(O > 0 ? O : 1) * (sizeof(double) + sizeof(int32_t)) + 16; }
+
+extern "C" int sg_masks_to_layout_test_fwd(const float* vecs, const float* boxes, const void* masks, int masks_i64,
+                                           const int32_t* seg_off, float* out, void* ws, size_t ws_bytes, int N, int O, int D,
+                                           int M, int H, int W, int avg, sgStream stream) {
+  SG_ARG_CHECK(vecs && boxes && masks && seg_off && out && ws && N > 0 && O > 0 && D > 0 && M > 0 && H > 0 && W > 0,
+               "sg_masks_to_layout_test_fwd: bad arguments");
+  SG_ARG_CHECK(ws_bytes >= sg_masks_to_layout_test_ws_bytes(O), "sg_masks_to_layout_test_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  double* mass = reinterpret_cast<double*>(ws);
+  int32_t* order = reinterpret_cast<int32_t*>(mass + O);
+  SgProfScope prof(SG_K_LAYOUT_FWD, s, 0, 4.0 * N * D * (double)H * W);
+  const dim3 grid(sg_cdiv(H * W, 256), N);
+  if (masks_i64) {
+    hipLaunchKernelGGL((layout_mass_kernel<true>), dim3(O), dim3(256), 0, s, vecs, boxes, masks, mass, D, M, H, W);
+    hipLaunchKernelGGL(layout_order_kernel, dim3(N), dim3(64), 0, s, (const double*)mass, seg_off, order);
+    hipLaunchKernelGGL((layout_test_fwd_kernel<true>), grid, dim3(256), 0, s, vecs, boxes, masks, seg_off,
+                       (const int32_t*)order, out, D, M, H, W, avg);
+  } else {
+    hipLaunchKernelGGL((layout_mass_kernel<false>), dim3(O), dim3(256), 0, s, vecs, boxes, masks, mass, D, M, H, W);
+    hipLaunchKernelGGL(layout_order_kernel, dim3(N), dim3(64), 0, s, (const double*)mass, seg_off, order);
+    hipLaunchKernelGGL((layout_test_fwd_kernel<false>), grid, dim3(256), 0, s, vecs, boxes, masks, seg_off,
+                       (const int32_t*)order, out, D, M, H, W, avg);
+  }
+  SG_LAUNCH_CHECK("sg_masks_to_layout_test_fwd");
   return 0;
 }
 

@@ -33,8 +33,6 @@ def masks_to_layout(vecs, boxes, masks, obj_to_img, H, W=None, pooling='sum', te
     the max()/validation sync; ``grad_from_channel`` tells backward that vecs[:, :c] is constant (the one-hot
     block, model.py:165-168); ``max_per_image`` sizes the LDS tile.
     """
-    if test_mode:
-        raise NotImplementedError('test-mode compositing (layout.py:157-169) is the next scope row (SURVEY 8f rank 1)')
     if pooling not in ('sum', 'avg'):
         raise ValueError('Invalid pooling "%s"' % pooling)
     O, D = vecs.size()
@@ -44,6 +42,8 @@ def masks_to_layout(vecs, boxes, masks, obj_to_img, H, W=None, pooling='sum', te
         W = H
     N = _num_images(obj_to_img, num_images, validate)
     seg = ops.segment_offsets(obj_to_img, N)
+    if test_mode:      # layout.py:87-92,157-169: front-to-back compositing in ascending-mass order, on the device
+        return ops.masks_to_layout_test(vecs, boxes, masks, seg, N, H, W, pooling == 'avg')
     out = ops.MasksToLayoutFn.apply(vecs, boxes, masks, seg, N, H, W, pooling == 'avg', int(grad_from_channel),
                                     int(max_per_image))
     if grad_from_channel > 0:

@@ -75,13 +75,11 @@ class Model(nn.Module):
 
     def forward(self, gt_imgs, objs, triples, obj_to_img, boxes_gt=None, masks_gt=None, attributes=None,
                 test_mode=False, use_gt_box=False, features=None):
-        if test_mode:
-            raise NotImplementedError('Model.forward(test_mode=True) (model.py:111-117) is SURVEY 8f rank 1 (next)')
         O = objs.size(0)
-        N = gt_imgs.size(0)
         objs_h, o2i_h = self.objs_host, self.obj_to_img_host
         if objs_h is None or o2i_h is None:      # one sync (the reference's pool does objs.tolist(), utils.py:104)
             objs_h, o2i_h = torch.stack((objs, obj_to_img)).tolist()
+        N = gt_imgs.size(0) if gt_imgs is not None else max(o2i_h) + 1
         obj_vecs, pred_vecs = self.scene_graph_to_vectors(objs, triples, attributes)
         box_vecs, mask_vecs, scene_layout_vecs, wrong_layout_vecs = \
             self.create_components_vecs(gt_imgs, boxes_gt, obj_to_img, objs, obj_vecs, features, objs_host=objs_h)
@@ -93,6 +91,15 @@ class Model(nn.Module):
 
         H, W = self.image_size
         kw = dict(num_images=N, validate=False, max_per_image=self.layout_objects_hint)
+        if test_mode:                                      # model.py:111-117
+            boxes = boxes_gt if use_gt_box else boxes_pred
+            masks = masks_gt if masks_gt is not None else masks_pred
+            pred_layout = masks_to_layout(scene_layout_vecs, boxes, masks, obj_to_img, H, W, test_mode=True,
+                                          num_images=N, validate=False)
+            pred_layout._sg_sparse = tuple(
+                torch.from_numpy(a).to(pred_layout.device, non_blocking=True)
+                for a in active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size))
+            return self.layout_to_image(pred_layout), boxes_pred, masks_pred, None, pred_layout, None
         gt_layout = masks_to_layout(scene_layout_vecs, boxes_gt, masks_gt, obj_to_img, H, W, test_mode=False,
                                     grad_from_channel=self.num_objs, **kw)
         # pred_layout feeds no loss (train.py:203,219); back-propagating through its masks raises loudly
@@ -130,8 +137,6 @@ class Model(nn.Module):
         return obj_vecs, pred_vecs
 
     def create_components_vecs(self, imgs, boxes, obj_to_img, objs, obj_vecs, features, objs_host=None):
-        if features is not None:
-            raise NotImplementedError('inference-time feature injection (model.py:158-163) is SURVEY 8f (next)')
         O = objs.size(0)
         box_vecs = obj_vecs
         if self.noise_override is not None:
@@ -140,8 +145,16 @@ class Model(nn.Module):
             noise = torch.randn((1, self.mask_noise_dim), dtype=obj_vecs.dtype, device=obj_vecs.device)
         mask_vecs = ops.concat_cols(obj_vecs, noise.expand(O, self.mask_noise_dim))
 
-        crops = crop_bbox_batch(imgs, boxes, obj_to_img, self.object_size)
-        obj_repr = self.repr_net(self.image_encoder(crops))
+        if features is None:
+            crops = crop_bbox_batch(imgs, boxes, obj_to_img, self.object_size)
+            obj_repr = self.repr_net(self.image_encoder(crops))
+        else:                                                # only at inference time (model.py:158-163)
+            obj_repr = self.repr_net(mask_vecs)
+            rows = [i for i, f in enumerate(features) if f is not None]
+            if rows:
+                obj_repr = obj_repr.clone()
+                obj_repr[torch.tensor(rows, device=obj_repr.device)] = torch.stack(
+                    [torch.as_tensor(features[i], dtype=obj_repr.dtype).to(obj_repr.device).view(-1) for i in rows])
 
         one_hot_obj = ops.one_hot(objs, self.num_objs)
         layout_vecs = ops.concat_cols(one_hot_obj, obj_repr)

@@ -755,6 +755,25 @@ class MasksToLayoutFn(Function):
         return gv, None, None, None, None, None, None, None, None, None
 
 
+def masks_to_layout_test(vecs, boxes, masks, seg_off, N, H, W, avg):
+    """test-mode compositing (layout.py:87-92,157-169); inference only, returns a tensor without history."""
+    if torch.is_grad_enabled() and (vecs.requires_grad or masks.requires_grad or boxes.requires_grad):
+        raise NotImplementedError('masks_to_layout(test_mode=True) is inference-only (the reference composites through '
+                                  '.item()/numpy argsort, layout.py:161-162): run it under torch.no_grad()')
+    vecs, boxes = _f32(vecs.detach(), 'vecs'), _f32(boxes.detach(), 'boxes')
+    masks = _dev(masks.detach(), 'masks')
+    if masks.dtype not in (torch.int64, torch.float32):
+        raise TypeError('masks must be int64 or float32')
+    masks = masks if masks.is_contiguous() else masks.contiguous()
+    O, D = vecs.shape
+    out = torch.empty(N, D, H, W, dtype=torch.float32, device=vecs.device)
+    wsb = _L().sg_masks_to_layout_test_ws_bytes(O)
+    ws = workspace(wsb, vecs.device)
+    _call('sg_masks_to_layout_test_fwd', _p(vecs), _p(boxes), _p(masks), 1 if masks.dtype == torch.int64 else 0, _p(seg_off),
+          _p(out), _p(ws), wsb, N, O, D, masks.size(1), H, W, 1 if avg else 0, _stream())
+    return out
+
+
 class CropBBoxFn(Function):
     """crop_bbox_batch (bilinear.py:26-41,67-130): gather forward, scatter-add backward w.r.t. feats."""
 

@@ -393,6 +393,53 @@ def test_masks_to_layout_vs_oracle(hip, cfg):
         assert float(vg.grad[:, :20].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('case', ['demo_16', 'demo_64', 'i64_m32', 'f32_m16', 'f32_m8_avg', 'many'])
+def test_masks_to_layout_test_mode_golden(hip, golden, case):
+    """front-to-back compositing in ascending-mass order (layout.py:87-92,157-169), reference goldens."""
+    from scene_generation_amd.layout import masks_to_layout
+    g = golden('layout_test_' + case)
+    with torch.no_grad():
+        out = masks_to_layout(torch.from_numpy(g['vecs']).to(DEV), torch.from_numpy(g['boxes']).to(DEV),
+                              torch.from_numpy(g['masks']).to(DEV), torch.from_numpy(g['obj_to_img']).to(DEV),
+                              int(g['H']), int(g['W']), pooling='avg' if int(g['avg']) else 'sum', test_mode=True)
+    close(out, g['out'], 1e-5, 'test-mode layout')
+
+
+def test_masks_to_layout_test_mode_vs_oracle_config2_shape(hip):
+    from scene_generation_amd.layout import masks_to_layout
+    b = make_batch(N=6, min_objs=3, max_objs=8, size=128, mask_size=32, num_objs=30, seed=11)
+    vecs = det((b.objs.numel(), 30 + 8), 83) + 0.55
+    for masks in (b.masks, torch.rand(b.masks.shape, generator=torch.Generator().manual_seed(6))):
+        want = O.masks_to_layout(vecs, b.boxes, masks, b.obj_to_img, 128, test_mode=True)
+        with torch.no_grad():
+            got = masks_to_layout(vecs.to(DEV), b.boxes.to(DEV), masks.to(DEV), b.obj_to_img.to(DEV), 128, test_mode=True)
+        close(got, want, 1e-5, 'test-mode layout')
+    with pytest.raises(NotImplementedError):          # inference only
+        masks_to_layout(vecs.to(DEV).requires_grad_(), b.boxes.to(DEV), b.masks.to(DEV), b.obj_to_img.to(DEV), 128,
+                        test_mode=True)
+
+
+def test_model_inference_forward_golden(hip, golden):
+    """Model.forward(test_mode=True[, features]) in eval mode == the reference (model.py:111-117,158-163)."""
+    from test_oracle_golden import inference_model, inference_cases
+    from scene_generation_amd.model import Model
+    from scene_generation_amd.synthetic import batch_to
+    g = golden('model_test_mode')
+    m, batch = inference_model(Model)
+    m = m.to(DEV)
+    imgs, objs, boxes, masks, triples, o2i, _, attributes = batch_to(batch, DEV)
+    for tag, kw in inference_cases(batch, g):
+        kw = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+        m.noise_override = torch.from_numpy(g[tag + '_noise']).to(DEV)
+        with torch.no_grad():
+            out = m(imgs, objs, triples, o2i, attributes=attributes, test_mode=True, **kw)
+        assert out[3] is None and out[5] is None
+        close(out[1], g[tag + '_boxes_pred'], 2e-5, tag + ' boxes')
+        close(out[2], g[tag + '_masks_pred'], 2e-5, tag + ' masks')
+        close(out[4], g[tag + '_pred_layout'], 2e-5, tag + ' layout')
+        close(out[0], g[tag + '_imgs_pred'], 1e-4, tag + ' imgs')
+
+
 @pytest.mark.parametrize('case', ['sorted_8', 'perm_8', 'perm_32'])
 def test_crop_golden(hip, golden, case):
     from scene_generation_amd.bilinear import crop_bbox_batch

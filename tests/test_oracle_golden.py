@@ -233,3 +233,57 @@ def test_c_oracle_crop(golden, case):
     g = golden('crop_' + case)
     out = CO.crop_bbox_batch(T(g['feats']), T(g['boxes']), T(g['idx']), int(g['HH']))
     close(out, g['out'], 1e-5, 'crop (C)')
+
+
+# ---- test-mode compositing + inference forward ---------------------------------
+TEST_LAYOUT_CASES = ['demo_16', 'demo_64', 'i64_m32', 'f32_m16', 'f32_m8_avg', 'many']
+
+
+@pytest.mark.parametrize('case', TEST_LAYOUT_CASES)
+def test_masks_to_layout_test_mode_vs_reference(golden, case):
+    g = golden('layout_test_' + case)
+    pooling = 'avg' if int(g['avg']) else 'sum'
+    out = O.masks_to_layout(T(g['vecs']), T(g['boxes']), T(g['masks']), T(g['obj_to_img']), int(g['H']), int(g['W']),
+                            pooling=pooling, test_mode=True)
+    close(out, g['out'], 1e-5, 'test-mode layout')
+
+
+def inference_model(cls):
+    C, P, A = 12, 4, 35
+    m = cls(make_vocab(C, P, A), image_size=(32, 32), gconv_hidden_dim=64, gconv_num_layers=3, mask_size=8,
+            mlp_normalization='none', appearance_normalization='batch', activation='leakyrelu-0.2',
+            n_downsample_global=2, use_attributes=True, pool_size=2)
+    fill_deterministic(m)
+    with torch.no_grad():       # same override as tools/make_golden.py (non-degenerate predicted boxes)
+        m.box_net[2].weight.mul_(0.05)
+        m.box_net[2].bias.copy_(torch.tensor([0.1, 0.15, 0.6, 0.7]))
+    m.eval()
+    batch = make_batch(N=3, min_objs=2, max_objs=4, size=32, mask_size=8, num_objs=C, num_preds=P, num_attributes=A,
+                       seed=321)
+    return m, batch
+
+
+def inference_cases(batch, g):
+    imgs, objs, boxes, masks, triples, o2i, _, attributes = batch
+    O_ = objs.size(0)
+    from tools_det import det
+    feats = [det((32,), 70 + i).abs() if i % 2 == 0 else None for i in range(O_)]
+    return [('gtbox_gtmask', dict(boxes_gt=boxes, masks_gt=masks, use_gt_box=True)),
+            ('predbox_predmask', dict(boxes_gt=boxes, masks_gt=None, use_gt_box=False)),
+            ('features', dict(boxes_gt=boxes, masks_gt=masks, use_gt_box=True, features=feats))]
+
+
+def test_model_inference_forward_vs_reference(golden):
+    """Model.forward(test_mode=True[, features=...]) (model.py:111-117,158-163) in eval mode."""
+    g = golden('model_test_mode')
+    m, batch = inference_model(O.Model)
+    imgs, objs, boxes, masks, triples, o2i, _, attributes = batch
+    for tag, kw in inference_cases(batch, g):
+        m.noise_override = T(g[tag + '_noise'])
+        with torch.no_grad():
+            out = m(imgs, objs, triples, o2i, attributes=attributes, test_mode=True, **kw)
+        assert out[3] is None and out[5] is None
+        close(out[1], g[tag + '_boxes_pred'], 2e-5, tag + ' boxes')
+        close(out[2], g[tag + '_masks_pred'], 2e-5, tag + ' masks')
+        close(out[4], g[tag + '_pred_layout'], 2e-5, tag + ' layout')
+        close(out[0], g[tag + '_imgs_pred'], 5e-5, tag + ' imgs')

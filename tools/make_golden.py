@@ -361,6 +361,73 @@ def golden_step():
     npz('state_dict_keys_full', **inv)
 
 
+def golden_testmode():
+    """masks_to_layout(test_mode=True) (layout.py:87-92,157-169) and Model.forward(test_mode=True,
+    features=...) (model.py:111-117,158-163) of the reference, reduced widths."""
+    from scene_generation.layout import masks_to_layout
+    from scene_generation.model import Model
+    vecs, boxes, masks, o2i = demo_layout_inputs()
+    for H in (16, 64):
+        out = masks_to_layout(vecs, boxes, masks, o2i, H, test_mode=True)
+        npz('layout_test_demo_%d' % H, vecs=vecs, boxes=boxes, masks=masks, obj_to_img=o2i, out=out, H=H, W=H, avg=0)
+    g = torch.Generator().manual_seed(5)
+    for name, M, H, W, dtype, pooling, counts in [('i64_m32', 32, 24, 24, 'i64', 'sum', [3, 1, 4]),
+                                                  ('f32_m16', 16, 20, 28, 'f32', 'sum', [5, 2]),
+                                                  ('f32_m8_avg', 8, 16, 16, 'f32', 'avg', [2, 6, 1]),
+                                                  ('many', 16, 32, 32, 'i64', 'sum', [17, 9])]:
+        O = sum(counts)
+        o2i = torch.cat([torch.full((c,), i, dtype=torch.long) for i, c in enumerate(counts)])
+        D = 7
+        vecs = det((O, D), 61) + 0.6          # mostly positive so the masses are well separated
+        x0 = torch.rand(O, generator=g) * 0.5
+        y0 = torch.rand(O, generator=g) * 0.5
+        boxes = torch.stack([x0, y0, x0 + 0.15 + 0.45 * torch.rand(O, generator=g),
+                             y0 + 0.15 + 0.45 * torch.rand(O, generator=g)], 1)
+        boxes[0] = torch.tensor([0., 0., 1., 1.])          # an __image__-like full box behind everything else
+        if dtype == 'i64':
+            masks = (torch.rand(O, M, M, generator=g) < 0.7).long()
+            masks[0] = 1
+        else:
+            masks = torch.rand(O, M, M, generator=g)
+        out = masks_to_layout(vecs, boxes, masks, o2i, H, W, pooling=pooling, test_mode=True)
+        npz('layout_test_' + name, vecs=vecs, boxes=boxes, masks=masks, obj_to_img=o2i, out=out, H=H, W=W,
+            avg=int(pooling == 'avg'))
+    # inference forward
+    C, P, A = 12, 4, 35
+    vocab = make_vocab(C, P, A)
+    with fake_cuda():
+        model = Model(vocab, image_size=(32, 32), gconv_hidden_dim=64, gconv_num_layers=3, mask_size=8,
+                      mlp_normalization='none', appearance_normalization='batch', activation='leakyrelu-0.2',
+                      n_downsample_global=2, use_attributes=True, pool_size=2)
+    fill_deterministic(model)
+    with torch.no_grad():       # the closed-form fill predicts degenerate boxes (x0 == x1 -> NaN layout): make them boxes
+        model.box_net[2].weight.mul_(0.05)
+        model.box_net[2].bias.copy_(torch.tensor([0.1, 0.15, 0.6, 0.7]))
+    model.eval()
+    batch = make_batch(N=3, min_objs=2, max_objs=4, size=32, mask_size=8, num_objs=C, num_preds=P, num_attributes=A,
+                       seed=321)
+    imgs, objs, boxes, masks, triples, o2i, _, attributes = batch
+    O = objs.size(0)
+    arrs = {}
+    for tag, kw in [('gtbox_gtmask', dict(boxes_gt=boxes, masks_gt=masks, use_gt_box=True)),
+                    ('predbox_predmask', dict(boxes_gt=boxes, masks_gt=None, use_gt_box=False)),
+                    ('features', dict(boxes_gt=boxes, masks_gt=masks, use_gt_box=True,
+                                      features=[det((32,), 70 + i).abs() if i % 2 == 0 else None for i in range(O)]))]:
+        torch.manual_seed(4242)
+        noise = torch.randn((1, 64))
+        torch.manual_seed(4242)
+        with torch.no_grad():
+            out = model(imgs, objs, triples, o2i, attributes=attributes, test_mode=True, **kw)
+        imgs_pred, boxes_pred, masks_pred, gt_layout, pred_layout, wrong_layout = out
+        assert gt_layout is None and wrong_layout is None
+        arrs[tag + '_noise'] = noise
+        arrs[tag + '_imgs_pred'] = imgs_pred
+        arrs[tag + '_boxes_pred'] = boxes_pred
+        arrs[tag + '_masks_pred'] = masks_pred
+        arrs[tag + '_pred_layout'] = pred_layout
+    npz('model_test_mode', seed=321, **arrs)
+
+
 def golden_args():
     """flag names + defaults of the reference parser (args.py:10-109)"""
     import json
@@ -372,6 +439,6 @@ def golden_args():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     install_shims()
-    which = sys.argv[1:] or ['gconv', 'layout', 'crop', 'modules', 'losses', 'step', 'args']
+    which = sys.argv[1:] or ['gconv', 'layout', 'crop', 'modules', 'losses', 'step', 'testmode', 'args']
     for w in which:
         globals()['golden_' + w]()
