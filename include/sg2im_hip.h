@@ -66,6 +66,13 @@ int sg_conv2d_fwd(const sgConvDesc* d, const float* x1, const float* x2, const f
  * logical input: Hg = H*upsample + (pad_reflect ? 2*pad : 0).  Fold with sg_pad_upsample_bwd. */
 int sg_conv2d_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, int c_begin, int c_end,
                     void* ws, size_t ws_bytes, sgStream stream);
+/* Data gradient w.r.t. the ACTUAL [N, c_end-c_begin, H, W] input of ReflectionPad2d(1) + 3x3 stride-1 conv (the
+   ResnetBlock convs, reference layers.py:251-270): the reflection fold is applied to gy (one pre-folded copy per tap)
+   instead of computing the gradient on the padded (H+2)x(W+2) grid and folding it with sg_pad_upsample_bwd. */
+int sg_conv2d_dgrad_folded_supported(const sgConvDesc* d);
+size_t sg_conv2d_dgrad_folded_ws_bytes(const sgConvDesc* d);
+int sg_conv2d_dgrad_folded(const sgConvDesc* d, const float* gy, const float* w, float* gx, int c_begin, int c_end,
+                           void* ws, size_t ws_bytes, sgStream stream);
 /* gw[Cout, C1+C2, KS, KS] (+ gb[Cout] if non-null) */
 int sg_conv2d_wgrad(const sgConvDesc* d, const float* gy, const float* x1, const float* x2, float* gw, float* gb,
                     void* ws, size_t ws_bytes, sgStream stream);

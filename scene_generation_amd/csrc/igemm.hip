@@ -195,7 +195,7 @@ __device__ __forceinline__ int tap_offset(const Gather& g, int ah, int aw, int k
 struct KEntry { unsigned choff; unsigned tapsel; };     // channel-plane offset ; tap row | second-source << 8
 
 __global__ void build_ktab_kernel(KEntry* tab, int K, int Kpad, int KS2, int C1, int C2, unsigned shw, int bcast2,
-                                  int tail_valid) {
+                                  int tail_valid, unsigned variant_stride) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= Kpad) return;
   KEntry e;
@@ -203,7 +203,7 @@ __global__ void build_ktab_kernel(KEntry* tab, int K, int Kpad, int KS2, int C1,
     const int c = k / KS2, t = k - c * KS2;
     const bool second = C2 > 0 && c >= C1;
     const unsigned cc = (unsigned)(second ? c - C1 : c);
-    e.choff = (second && bcast2) ? cc : cc * shw;
+    e.choff = ((second && bcast2) ? cc : cc * shw) + (unsigned)t * variant_stride;
     e.tapsel = (unsigned)t | (second ? 256u : 0u);
   } else {
     // k >= K: either the all-invalid tap row, or (mask-free kernels) any valid element: the A operand is zero there
@@ -781,6 +781,7 @@ inline int pick_tile(int M, int N) {
 // thread-local launch modifiers (set by the sparse entry points around a regular dispatch)
 thread_local BatchInfo t_batch = {0, 0, nullptr, 0, 0};
 struct Sparse { const int* list; const int* cnt; int L; };   // per-image ascending active-channel lists
+thread_local unsigned t_variant_stride = 0;   // >0: tap t of the k-table reads from source copy t (see reflect_variants_kernel)
 thread_local int t_fixed_kchunk = 0;        // >0: grid.z = ceil(K / chunk) with exactly this chunk (one image per z)
 
 template <class CFG, class AL, class BL, class EP>
@@ -815,6 +816,36 @@ __global__ void slab_reduce_nchw_kernel(const float* ws, float* out, size_t n, i
   for (int z = 0; z < S; ++z) v += ws[(size_t)z * n + i];
   if (bias) v += bias[(i / PHW) % Mtot];
   out[i] = sg_apply_act(v, act, slope);
+}
+
+// ReflectionPad2d(1) + 3x3 conv, data gradient without the padded grid.  The gradient of the padded input folds back as
+//   gx[i] = sum_k w[k] gy[i+1-k]  +  [i==1] w[0] gy[0]  +  [i==H-2] w[2] gy[H-1]        (per axis)
+// i.e. tap 0 at pixel 1 sees gy[2]+gy[0], tap 2 at pixel H-2 sees gy[H-3]+gy[H-1].  Materialising one pre-folded copy
+// of gy per tap turns the whole thing into a plain zero-padded transposed gather over the H x W grid (the padded
+// formulation computes (H+2)(W+2)/(HW) = 56 % more pixels at 8x8).
+__global__ void reflect_variants_kernel(const float* __restrict__ gy, float* __restrict__ V, size_t planes, int H, int W,
+                                        size_t VS) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t HW = (size_t)H * W;
+  if (idx >= planes * HW) return;
+  const size_t plane = idx / HW;
+  const int p = (int)(idx - plane * HW);
+  const int a = p / W, b = p - a * W;
+  const float* g = gy + plane * HW;
+  const float v00 = g[p];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int ra = (kh == 0 && a == 2) ? 0 : ((kh == 2 && a == H - 3) ? H - 1 : -1);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int cb = (kw == 0 && b == 2) ? 0 : ((kw == 2 && b == W - 3) ? W - 1 : -1);
+      float v = v00;
+      if (ra >= 0) v += g[ra * W + b];
+      if (cb >= 0) v += g[a * W + cb];
+      if (ra >= 0 && cb >= 0) v += g[ra * W + cb];
+      V[(size_t)(kh * 3 + kw) * VS + idx] = v;
+    }
+  }
 }
 
 // Wt[b][a][r] = W[a][b][r]
@@ -903,7 +934,7 @@ int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* b
   {
     const int Kpad = sg_cdiv(K, 64) * 64 + 128;      // the k-loop prefetches entries up to two tiles past the end
     hipLaunchKernelGGL(build_ktab_kernel, dim3(sg_cdiv(Kpad, 256)), dim3(256), 0, s, ktab, K, Kpad, KS * KS, g.C1, g.C2,
-                       (unsigned)(g.SH * g.SW), g.bcast2, nomask ? 1 : 0);
+                       (unsigned)(g.SH * g.SW), g.bcast2, nomask ? 1 : 0, t_variant_stride);
   }
   const size_t nout = (size_t)M * Npix;
   EpNCHW ep{out, bias, g.PH * g.PW, Mtot, M, Npix, act, slope, 0, 0, 1, 0, 0, 0, 0};
@@ -1329,6 +1360,46 @@ extern "C" int sg_conv2d_dgrad(const sgConvDesc* d, const float* gy, const float
   int rc = run_kn_ks<1>(d->KS, wt + (size_t)c_begin * K, M, K, g, d->N, nullptr, gx, M, SG_ACT_NONE, 0.f, flops,
                         wt + nw, ws_bytes - nw * sizeof(float), s);
   SG_LAUNCH_CHECK("sg_conv2d_dgrad");
+  return rc;
+}
+
+// ---- dgrad w.r.t. the ACTUAL input of a reflect-padded 3x3 conv (ResnetBlock, layers.py:251-270) -----------------
+static bool dgrad_folded_ok(const sgConvDesc* d) {
+  return d && d->pad_reflect && d->pad == 1 && d->KS == 3 && d->stride == 1 && d->upsample == 1 && d->C2 == 0 &&
+         d->H >= 3 && d->W >= 3 && d->OH == d->H && d->OW == d->W &&
+         9.0 * d->N * d->Cout * d->OH * d->OW < 2147483647.0;
+}
+extern "C" int sg_conv2d_dgrad_folded_supported(const sgConvDesc* d) { return dgrad_folded_ok(d) ? 1 : 0; }
+extern "C" size_t sg_conv2d_dgrad_folded_ws_bytes(const sgConvDesc* d) {
+  if (!dgrad_folded_ok(d)) return 0;
+  return sg_conv2d_ws_bytes(d, 1) + 9 * (size_t)d->N * d->Cout * d->OH * d->OW * sizeof(float) + 256 +
+         kn_slab_bytes(d->C1, d->N * d->H * d->W, d->Cout * 9);
+}
+extern "C" int sg_conv2d_dgrad_folded(const sgConvDesc* d, const float* gy, const float* w, float* gx, int c_begin, int c_end,
+                                      void* ws, size_t ws_bytes, sgStream stream) {
+  if (check_desc(d, "sg_conv2d_dgrad_folded")) return -1;
+  SG_ARG_CHECK(dgrad_folded_ok(d), "sg_conv2d_dgrad_folded: unsupported desc (needs ReflectionPad(1) + 3x3, stride 1)");
+  const int Cin = d->C1, R = 9;
+  SG_ARG_CHECK(gy && w && gx && ws, "sg_conv2d_dgrad_folded: null pointer");
+  SG_ARG_CHECK(0 <= c_begin && c_begin < c_end && c_end <= Cin, "sg_conv2d_dgrad_folded: bad channel range");
+  SG_ARG_CHECK(ws_bytes >= sg_conv2d_dgrad_folded_ws_bytes(d), "sg_conv2d_dgrad_folded: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* wt = reinterpret_cast<float*>(ws);      // [Cin][Cout][R]
+  const size_t nw = (size_t)d->Cout * Cin * R;
+  hipLaunchKernelGGL(permute_w_kernel, dim3(sg_cdiv(nw, 256)), dim3(256), 0, s, w, wt, d->Cout, Cin, R);
+  float* V = wt + ((nw + 63) / 64) * 64;         // nine pre-folded copies of gy
+  const size_t VS = (size_t)d->N * d->Cout * d->OH * d->OW;
+  hipLaunchKernelGGL(reflect_variants_kernel, dim3(sg_cdiv(VS, 256)), dim3(256), 0, s, gy, V, (size_t)d->N * d->Cout, d->OH,
+                     d->OW, VS);
+  Gather g = make_gather(V, nullptr, d->Cout, 0, d->OH, d->OW, 1, d->H, d->W, 1, 1, 0);
+  const int M = c_end - c_begin, K = d->Cout * R;
+  const double flops = 2.0 * M * (double)d->Cout * R * d->N * d->OH * d->OW;
+  char* rest = reinterpret_cast<char*>(V + 9 * VS);
+  t_variant_stride = (unsigned)VS;
+  int rc = run_kn_ks<1>(3, wt + (size_t)c_begin * K, M, K, g, d->N, nullptr, gx, M, SG_ACT_NONE, 0.f, flops, rest,
+                        ws_bytes - (size_t)(rest - reinterpret_cast<char*>(ws)), s);
+  t_variant_stride = 0;
+  SG_LAUNCH_CHECK("sg_conv2d_dgrad_folded");
   return rc;
 }
 

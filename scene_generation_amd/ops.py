@@ -141,7 +141,15 @@ class Conv2dFn(Function):
             GH = d.H * d.upsample + (2 * d.pad if d.pad_reflect else 0)
             GW = d.W * d.upsample + (2 * d.pad if d.pad_reflect else 0)
 
+            folded = x2 is None and _L().sg_conv2d_dgrad_folded_supported(ctypes.byref(d))
+
             def dgrad(c0, c1):
+                if folded:       # ReflectionPad(1)+3x3: gradient straight on the H x W grid (no padded grid, no fold pass)
+                    out = torch.empty(d.N, c1 - c0, d.H, d.W, dtype=torch.float32, device=dev)
+                    fb = _L().sg_conv2d_dgrad_folded_ws_bytes(ctypes.byref(d))
+                    _call('sg_conv2d_dgrad_folded', ctypes.byref(d), _p(gy), _p(weight), _p(out), c0, c1,
+                          _p(workspace(fb, dev)), fb, s)
+                    return out
                 g = torch.empty(d.N, c1 - c0, GH, GW, dtype=torch.float32, device=dev)
                 _call('sg_conv2d_dgrad', ctypes.byref(d), _p(gy), _p(weight), _p(g), c0, c1, _p(ws), wsb, s)
                 if fold:
