@@ -148,14 +148,17 @@ int sg_instnorm_fwd(const float* x, const float* skip, float* y, float* mean, fl
                     int act, float slope, sgStream stream);
 int sg_instnorm_bwd(const float* x, const float* gy, const float* mean, const float* rstd, float* gx, int NC, int HW,
                     int act, float slope, sgStream stream);
-/* training: batch stats (biased var) + running-stat update (unbiased var, momentum) + num_batches_tracked++ */
+/* training: batch stats (biased var) + running-stat update (unbiased var, momentum) + num_batches_tracked++;
+   ws (sg_batchnorm_ws_bytes) holds the per-slice partial statistics of the multi-workgroup reduction */
+size_t sg_batchnorm_ws_bytes(int N, int C, int HW);
 int sg_batchnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
                      float* save_rstd, float* running_mean, float* running_var, int64_t* num_batches, int N, int C,
-                     int HW, float eps, float momentum, int training, int act, float slope, sgStream stream);
+                     int HW, float eps, float momentum, int training, int act, float slope, void* ws, size_t ws_bytes,
+                     sgStream stream);
 /* beta is needed to rebuild the pre-activation gamma*z+beta for the fused activation mask */
 int sg_batchnorm_bwd(const float* x, const float* gy, const float* gamma, const float* beta, const float* save_mean,
                      const float* save_rstd, float* gx, float* ggamma, float* gbeta, int N, int C, int HW, int training,
-                     int act, float slope, sgStream stream);
+                     int act, float slope, void* ws, size_t ws_bytes, sgStream stream);
 int sg_avgpool3s2_fwd(const float* x, float* y, int NC, int H, int W, int OH, int OW, sgStream stream);
 int sg_avgpool3s2_bwd(const float* gy, float* gx, int NC, int H, int W, int OH, int OW, sgStream stream);
 int sg_gap_fwd(const float* x, float* y, int NC, int HW, sgStream stream);

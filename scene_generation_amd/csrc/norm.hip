@@ -75,87 +75,187 @@ __global__ void __launch_bounds__(256) instnorm_bwd_kernel(const float* __restri
 }
 
 // ---------------- BatchNorm2d: one block per channel ---------------------------------------------
-__global__ void __launch_bounds__(512) batchnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ y,
-                                                           float* __restrict__ save_mean, float* __restrict__ save_rstd,
-                                                           float* __restrict__ rmean, float* __restrict__ rvar,
-                                                           int64_t* __restrict__ nbt, int N, int C, int HW, float eps,
-                                                           float momentum, int training, int act, float slope) {
+// ---- BatchNorm2d (+ fused activation), three stages so that a 64..256-channel layer fills the chip ---------------------
+//  stats : grid (C, S)  -- slice z of channel c covers a contiguous range of the (n, p) index space
+//  final : one thread per channel combines the S partials in fixed order (Chan's parallel-variance update)
+//  apply : elementwise over every (n, c) plane
+// (the first version ran ONE workgroup per channel with three passes: ~1 TB/s at 128 channels)
+struct BnIter {             // walks i -> (n, p) without a division per element
+  int n, p, HW;
+  __device__ __forceinline__ BnIter(long i, int HW_) : HW(HW_) { n = (int)(i / HW_); p = (int)(i - (long)n * HW_); }
+  __device__ __forceinline__ void step(int d) { p += d; while (p >= HW) { p -= HW; ++n; } }
+};
+
+__global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int N, int C,
+                                                      int HW, int S) {
   __shared__ float red[16];
-  const int c = blockIdx.x;
-  const int cnt = N * HW;
-  float mean, rstd;
-  if (training) {
-    float s = 0.f;
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-      const int n = i / HW, p = i - n * HW;
-      s += x[((size_t)n * C + c) * HW + p];
-    }
-    s = sg_block_sum(s, red);
-    mean = s / (float)cnt;
-    float q = 0.f;
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-      const int n = i / HW, p = i - n * HW;
-      const float d = x[((size_t)n * C + c) * HW + p] - mean;
+  const int c = blockIdx.x, z = blockIdx.y;
+  const long cnt = (long)N * HW;
+  const long chunk = (cnt + S - 1) / S;
+  const long beg = z * chunk, end = beg + chunk < cnt ? beg + chunk : cnt;
+  const float m = (float)(end > beg ? end - beg : 0);
+  float s = 0.f;
+  {
+    BnIter it(beg + threadIdx.x, HW);
+    for (long i = beg + threadIdx.x; i < end; i += 256, it.step(256)) s += x[((size_t)it.n * C + c) * HW + it.p];
+  }
+  s = sg_block_sum(s, red);
+  const float mean = m > 0.f ? s / m : 0.f;
+  float q = 0.f;
+  {
+    BnIter it(beg + threadIdx.x, HW);
+    for (long i = beg + threadIdx.x; i < end; i += 256, it.step(256)) {
+      const float d = x[((size_t)it.n * C + c) * HW + it.p] - mean;
       q += d * d;
     }
-    q = sg_block_sum(q, red);
-    const float var = q / (float)cnt;
-    rstd = 1.f / sqrtf(var + eps);
-    if (threadIdx.x == 0) {
-      save_mean[c] = mean; save_rstd[c] = rstd;
-      if (rmean) {
-        const float unb = cnt > 1 ? q / (float)(cnt - 1) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
-      }
-      if (nbt && c == 0) nbt[0] += 1;
-    }
-  } else {
-    mean = rmean[c];
-    rstd = 1.f / sqrtf(rvar[c] + eps);
-    if (threadIdx.x == 0) { save_mean[c] = mean; save_rstd[c] = rstd; }
   }
-  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-    const int n = i / HW, p = i - n * HW;
-    const size_t off = ((size_t)n * C + c) * HW + p;
-    y[off] = sg_apply_act((x[off] - mean) * rstd * ga + be, act, slope);
+  q = sg_block_sum(q, red);
+  if (threadIdx.x == 0) {
+    float* o = part + ((size_t)c * S + z) * 3;
+    o[0] = m; o[1] = mean; o[2] = q;
   }
 }
 
-__global__ void __launch_bounds__(512) batchnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const float* __restrict__ save_mean,
-                                                           const float* __restrict__ save_rstd, float* __restrict__ gx,
-                                                           float* __restrict__ ggamma, float* __restrict__ gbeta, int N,
-                                                           int C, int HW, int training, int act, float slope) {
+__global__ void bn_final_kernel(const float* __restrict__ part, float* __restrict__ save_mean, float* __restrict__ save_rstd,
+                                float* __restrict__ rmean, float* __restrict__ rvar, int64_t* __restrict__ nbt, int C, int S,
+                                float eps, float momentum, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (!training) {
+    save_mean[c] = rmean[c];
+    save_rstd[c] = 1.f / sqrtf(rvar[c] + eps);
+    return;
+  }
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int z = 0; z < S; ++z) {
+    const float* p = part + ((size_t)c * S + z) * 3;
+    const float nb = p[0];
+    if (nb <= 0.f) continue;
+    const float d = p[1] - mean, nt = n + nb;
+    mean += d * (nb / nt);
+    m2 += p[2] + d * d * (n * nb / nt);
+    n = nt;
+  }
+  const float var = m2 / n;
+  save_mean[c] = mean;
+  save_rstd[c] = 1.f / sqrtf(var + eps);
+  if (rmean) {
+    const float unb = n > 1.f ? m2 / (n - 1.f) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+  }
+  if (nbt && c == 0) nbt[0] += 1;
+}
+
+// y = act((x - mean[c]) * rstd[c] * gamma[c] + beta[c]); one workgroup = 1024 consecutive elements of one plane
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, float* __restrict__ y, int C, int HW,
+                                                      int act, float slope) {
+  const int plane = blockIdx.y, c = plane % C;
+  const float mu = mean[c], a = rstd[c] * (gamma ? gamma[c] : 1.f), b = beta ? beta[c] : 0.f;
+  const size_t base = (size_t)plane * HW;
+  const int p0 = blockIdx.x * 1024 + threadIdx.x * 4;
+  if ((HW & 3) == 0) {
+    if (p0 < HW) {
+      float4 v = *reinterpret_cast<const float4*>(x + base + p0);
+      v.x = sg_apply_act((v.x - mu) * a + b, act, slope); v.y = sg_apply_act((v.y - mu) * a + b, act, slope);
+      v.z = sg_apply_act((v.z - mu) * a + b, act, slope); v.w = sg_apply_act((v.w - mu) * a + b, act, slope);
+      *reinterpret_cast<float4*>(y + base + p0) = v;
+    }
+  } else {
+    for (int e = 0; e < 4; ++e) {
+      const int p = blockIdx.x * 1024 + e * 256 + threadIdx.x;
+      if (p < HW) y[base + p] = sg_apply_act((x[base + p] - mu) * a + b, act, slope);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          float* __restrict__ part, int N, int C, int HW, int S, int act,
+                                                          float slope) {
   __shared__ float red[16];
-  const int c = blockIdx.x;
-  const int cnt = N * HW;
-  const float mean = save_mean[c], rstd = save_rstd[c];
-  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  const int c = blockIdx.x, z = blockIdx.y;
+  const long cnt = (long)N * HW;
+  const long chunk = (cnt + S - 1) / S;
+  const long beg = z * chunk, end = beg + chunk < cnt ? beg + chunk : cnt;
+  const float mu = mean[c], rs = rstd[c], ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
   float s1 = 0.f, s2 = 0.f;
-  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-    const int n = i / HW, p = i - n * HW;
-    const size_t off = ((size_t)n * C + c) * HW + p;
-    const float z = (x[off] - mean) * rstd;
-    const float g = gy[off] * act_grad_from_pre(z * ga + be, act, slope);
-    s1 += g; s2 += g * z;
+  BnIter it(beg + threadIdx.x, HW);
+  for (long i = beg + threadIdx.x; i < end; i += 256, it.step(256)) {
+    const size_t off = ((size_t)it.n * C + c) * HW + it.p;
+    const float zv = (x[off] - mu) * rs;
+    const float g = gy[off] * act_grad_from_pre(zv * ga + be, act, slope);
+    s1 += g; s2 += g * zv;
   }
   s1 = sg_block_sum(s1, red);
   s2 = sg_block_sum(s2, red);
-  if (threadIdx.x == 0) { if (gbeta) gbeta[c] = s1; if (ggamma) ggamma[c] = s2; }
-  const float inv = 1.f / (float)cnt;
+  if (threadIdx.x == 0) { part[((size_t)c * S + z) * 2] = s1; part[((size_t)c * S + z) * 2 + 1] = s2; }
+}
+
+__global__ void bn_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ sums, float* __restrict__ ggamma,
+                                    float* __restrict__ gbeta, int C, int S) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int z = 0; z < S; ++z) { s1 += part[((size_t)c * S + z) * 2]; s2 += part[((size_t)c * S + z) * 2 + 1]; }
+  sums[2 * c] = s1; sums[2 * c + 1] = s2;
+  if (gbeta) gbeta[c] = s1;
+  if (ggamma) ggamma[c] = s2;
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ sums, float* __restrict__ gx, int C,
+                                                          int HW, float inv_cnt, int training, int act, float slope) {
+  const int plane = blockIdx.y, c = plane % C;
+  const float mu = mean[c], rs = rstd[c], ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
   // eval mode: the statistics are constants, so only the affine map is differentiated
-  const float m1 = training ? s1 * inv : 0.f, m2 = training ? s2 * inv : 0.f;
-  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-    const int n = i / HW, p = i - n * HW;
-    const size_t off = ((size_t)n * C + c) * HW + p;
-    const float z = (x[off] - mean) * rstd;
-    const float g = gy[off] * act_grad_from_pre(z * ga + be, act, slope);
-    gx[off] = ga * rstd * (g - m1 - z * m2);
+  const float m1 = training ? sums[2 * c] * inv_cnt : 0.f, m2 = training ? sums[2 * c + 1] * inv_cnt : 0.f;
+  const size_t base = (size_t)plane * HW;
+  for (int e = 0; e < 4; ++e) {
+    const int p = blockIdx.x * 1024 + e * 256 + threadIdx.x;
+    if (p < HW) {
+      const float zv = (x[base + p] - mu) * rs;
+      const float g = gy[base + p] * act_grad_from_pre(zv * ga + be, act, slope);
+      gx[base + p] = ga * rs * (g - m1 - zv * m2);
+    }
   }
+}
+
+// small planes (BatchNorm1d: HW == 1): one thread per element
+__global__ void bn_apply_flat_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ y,
+                                     size_t total, int C, int HW, int act, float slope) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)((i / HW) % C);
+  y[i] = sg_apply_act((x[i] - mean[c]) * rstd[c] * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f), act, slope);
+}
+__global__ void bn_bwd_apply_flat_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                         const float* __restrict__ sums, float* __restrict__ gx, size_t total, int C, int HW,
+                                         float inv_cnt, int training, int act, float slope) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)((i / HW) % C);
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f, rs = rstd[c];
+  const float m1 = training ? sums[2 * c] * inv_cnt : 0.f, m2 = training ? sums[2 * c + 1] * inv_cnt : 0.f;
+  const float zv = (x[i] - mean[c]) * rs;
+  const float g = gy[i] * act_grad_from_pre(zv * ga + be, act, slope);
+  gx[i] = ga * rs * (g - m1 - zv * m2);
+}
+
+inline int bn_slices(int N, int C, int HW) {
+  long cnt = (long)N * HW;
+  int S = (1024 + C - 1) / C;
+  const long maxS = cnt / 1024 > 0 ? cnt / 1024 : 1;      // at least 1024 elements per slice
+  if (S > maxS) S = (int)maxS;
+  return S < 1 ? 1 : S;
 }
 
 // per-channel sum over (N, HW): two deterministic stages -- grid (C, S) partial sums over contiguous chunks of the
@@ -375,32 +475,58 @@ extern "C" int sg_instnorm_bwd(const float* x, const float* gy, const float* mea
   return 0;
 }
 
+extern "C" size_t sg_batchnorm_ws_bytes(int N, int C, int HW) {
+  return ((size_t)C * bn_slices(N, C, HW) * 3 + 2 * (size_t)C) * sizeof(float) + 64;
+}
+
 extern "C" int sg_batchnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* save_mean,
                                 float* save_rstd, float* running_mean, float* running_var, int64_t* num_batches, int N,
-                                int C, int HW, float eps, float momentum, int training, int act, float slope,
-                                sgStream stream) {
+                                int C, int HW, float eps, float momentum, int training, int act, float slope, void* ws,
+                                size_t ws_bytes, sgStream stream) {
   SG_ARG_CHECK(x && y && save_mean && save_rstd && N > 0 && C > 0 && HW > 0, "sg_batchnorm_fwd: bad arguments");
   SG_ARG_CHECK(training || (running_mean && running_var), "sg_batchnorm_fwd: eval mode needs running stats");
+  SG_ARG_CHECK(!training || (ws && ws_bytes >= sg_batchnorm_ws_bytes(N, C, HW)), "sg_batchnorm_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   SgProfScope prof(SG_K_BATCHNORM, s, 0, (double)N * C * HW * 16.0);
-  hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3(C), dim3(512), 0, s, x, gamma, beta, y, save_mean, save_rstd,
-                     running_mean, running_var, num_batches, N, C, HW, eps, momentum, training, act, slope);
+  const int S = bn_slices(N, C, HW);
+  float* part = reinterpret_cast<float*>(ws);
+  if (training) hipLaunchKernelGGL(bn_stats_kernel, dim3(C, S), dim3(256), 0, s, x, part, N, C, HW, S);
+  hipLaunchKernelGGL(bn_final_kernel, dim3(sg_cdiv(C, 64)), dim3(64), 0, s, (const float*)part, save_mean, save_rstd,
+                     running_mean, running_var, num_batches, C, S, eps, momentum, training);
+  if (HW >= 256)
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(sg_cdiv(HW, 1024), N * C), dim3(256), 0, s, x, gamma, beta,
+                       (const float*)save_mean, (const float*)save_rstd, y, C, HW, act, slope);
+  else
+    hipLaunchKernelGGL(bn_apply_flat_kernel, dim3(sg_cdiv((size_t)N * C * HW, 256)), dim3(256), 0, s, x, gamma, beta,
+                       (const float*)save_mean, (const float*)save_rstd, y, (size_t)N * C * HW, C, HW, act, slope);
   SG_LAUNCH_CHECK("sg_batchnorm_fwd");
   return 0;
 }
 
 extern "C" int sg_batchnorm_bwd(const float* x, const float* gy, const float* gamma, const float* beta,
                                 const float* save_mean, const float* save_rstd, float* gx, float* ggamma, float* gbeta,
-                                int N, int C, int HW, int training, int act, float slope, sgStream stream) {
+                                int N, int C, int HW, int training, int act, float slope, void* ws, size_t ws_bytes,
+                                sgStream stream) {
   SG_ARG_CHECK(x && gy && save_mean && save_rstd && gx && N > 0 && C > 0 && HW > 0, "sg_batchnorm_bwd: bad arguments");
+  SG_ARG_CHECK(ws && ws_bytes >= sg_batchnorm_ws_bytes(N, C, HW), "sg_batchnorm_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   SgProfScope prof(SG_K_BATCHNORM, s, 0, (double)N * C * HW * 20.0);
-  hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(C), dim3(512), 0, s, x, gy, gamma, beta, save_mean, save_rstd, gx,
-                     ggamma, gbeta, N, C, HW, training, act, slope);
+  const int S = bn_slices(N, C, HW);
+  float* part = reinterpret_cast<float*>(ws);
+  float* sums = part + (size_t)C * S * 3;
+  hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(C, S), dim3(256), 0, s, x, gy, gamma, beta, save_mean, save_rstd, part, N, C,
+                     HW, S, act, slope);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(sg_cdiv(C, 64)), dim3(64), 0, s, (const float*)part, sums, ggamma, gbeta, C, S);
+  if (HW >= 256)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(sg_cdiv(HW, 1024), N * C), dim3(256), 0, s, x, gy, gamma, beta, save_mean,
+                       save_rstd, (const float*)sums, gx, C, HW, 1.f / ((float)N * HW), training, act, slope);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_flat_kernel, dim3(sg_cdiv((size_t)N * C * HW, 256)), dim3(256), 0, s, x, gy, gamma, beta,
+                       save_mean, save_rstd, (const float*)sums, gx, (size_t)N * C * HW, C, HW, 1.f / ((float)N * HW),
+                       training, act, slope);
   SG_LAUNCH_CHECK("sg_batchnorm_bwd");
   return 0;
 }
-
 extern "C" size_t sg_channel_sum_ws_bytes(int C) { return (size_t)C * 64 * sizeof(float); }
 
 extern "C" int sg_channel_sum(const float* g, float* out, int N, int C, int HW, void* ws, size_t ws_bytes,

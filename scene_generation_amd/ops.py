@@ -426,8 +426,9 @@ class BatchNormFn(Function):
         y = torch.empty_like(x)
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
+        wsb = _L().sg_batchnorm_ws_bytes(N, C, HW)
         _call('sg_batchnorm_fwd', _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(rmean), _p(rvar), _p(nbt),
-              N, C, HW, eps, momentum, 1 if training else 0, act, slope, _stream())
+              N, C, HW, eps, momentum, 1 if training else 0, act, slope, _p(workspace(wsb, x.device)), wsb, _stream())
         ctx.cfg = (N, C, HW, act, slope, 1 if training else 0)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         return y
@@ -440,8 +441,9 @@ class BatchNormFn(Function):
         gx = torch.empty_like(x)
         gg = torch.empty(C, dtype=torch.float32, device=x.device) if gamma is not None else None
         gb = torch.empty(C, dtype=torch.float32, device=x.device) if beta is not None else None
+        wsb = _L().sg_batchnorm_ws_bytes(N, C, HW)
         _call('sg_batchnorm_bwd', _p(x), _p(gy), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(gx), _p(gg), _p(gb), N, C, HW,
-              training, act, slope, _stream())
+              training, act, slope, _p(workspace(wsb, x.device)), wsb, _stream())
         return gx, gg, gb, None, None, None, None, None, None, None, None
 
 
