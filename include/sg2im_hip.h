@@ -88,6 +88,14 @@ int sg_conv2d_fwd_sparse(const sgConvDesc* d, const float* x1, const float* x2, 
 int sg_conv2d_wgrad_sparse(const sgConvDesc* d, const float* gy, const float* x1, const float* x2,
                            const int32_t* chan_list, const int32_t* chan_cnt, int L, float* gw, float* gb,
                            void* ws, size_t ws_bytes, sgStream stream);
+/* Direct (vector-ALU) kernels for ReflectionPad2d(3) + Conv2d(C, Cout <= 4, 7) [+ act]: the generator's RGB head
+   (reference generators.py:88-90).  Same results as sg_conv2d_fwd / sg_conv2d_wgrad (gb via sg_channel_sum). */
+int sg_conv2d_smallm_supported(const sgConvDesc* d);
+size_t sg_conv2d_smallm_ws_bytes(const sgConvDesc* d);
+int sg_conv2d_smallm_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                         float slope, sgStream stream);
+int sg_conv2d_smallm_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, void* ws, size_t ws_bytes,
+                           sgStream stream);
 /* nn.ConvTranspose2d(k3,s2,p1,op1) : w [Cin, Cout, KS, KS]; desc.H,W = input size, OH,OW = output size */
 int sg_convT2d_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y,
                    void* ws, size_t ws_bytes, sgStream stream);

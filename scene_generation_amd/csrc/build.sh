@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OBJS=()
-for f in runtime igemm norm graph layout loss; do
+for f in runtime igemm smallm norm graph layout loss; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ common.h -nt $f.o ] || [ ../../include/sg2im_hip.h -nt $f.o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -c $f.hip -o $f.o "$@" &
   fi

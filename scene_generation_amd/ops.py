@@ -99,7 +99,10 @@ class Conv2dFn(Function):
         bcast = 1 if (x2 is not None and x2.dim() == 2) else 0      # [N, C2] broadcast over H x W
         d = _conv_desc(N, C1, C2, H, W, Cout, KS, stride, pad, reflect, upsample, OH, OW, 0, bcast)
         y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=x1.device)
-        if sparse is not None:      # (chan_list [N, L] int32, chan_cnt [N] int32): see sg_conv2d_fwd_sparse
+        ctx.smallm = x2 is None and sparse is None and bool(_L().sg_conv2d_smallm_supported(ctypes.byref(d)))
+        if ctx.smallm:              # <= 4 output channels (the RGB head): direct vector-ALU kernel, no MFMA tile waste
+            _call('sg_conv2d_smallm_fwd', ctypes.byref(d), _p(x1), _p(weight), _p(bias), _p(y), act, slope, _stream())
+        elif sparse is not None:    # (chan_list [N, L] int32, chan_cnt [N] int32): see sg_conv2d_fwd_sparse
             clist, ccnt = sparse
             assert clist.dtype == torch.int32 and ccnt.dtype == torch.int32 and clist.size(0) == N == ccnt.numel()
             L = int(clist.size(1))
@@ -174,7 +177,13 @@ class Conv2dFn(Function):
             if need_w:
                 gw = torch.empty_like(weight)
                 gb = torch.empty(d.Cout, dtype=torch.float32, device=dev) if need_b else None
-                if ctx.sparse is not None:
+                if ctx.smallm:
+                    wsb = max(_L().sg_conv2d_smallm_ws_bytes(ctypes.byref(d)), _L().sg_channel_sum_ws_bytes(d.Cout))
+                    ws = workspace(wsb, dev)
+                    _call('sg_conv2d_smallm_wgrad', ctypes.byref(d), _p(gy), _p(x1), _p(gw), _p(ws), wsb, s)
+                    if gb is not None:
+                        _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb, s)
+                elif ctx.sparse is not None:
                     clist, ccnt = ctx.sparse
                     L = int(clist.size(1))
                     wsb = _L().sg_conv2d_sparse_ws_bytes(ctypes.byref(d), L, 2)

@@ -80,6 +80,8 @@ CONV_CASES = [
     (5, 24, 0, 8, 8, 1, 1, 1, 0, False, 1, 0),         # 1x1 head, Cout=1
     (5, 1, 0, 16, 16, 8, 3, 2, 1, False, 1, 2),        # mask-D first conv (K=9)
     (2, 64, 0, 16, 16, 3, 7, 1, 3, True, 1, 3),        # last G conv + tanh, Cout=3
+    (3, 10, 0, 21, 20, 2, 7, 1, 3, True, 1, 3),        # direct small-M kernel: ragged tiles, Cout=2
+    (2, 6, 0, 40, 136, 4, 7, 1, 3, True, 1, 0),        # direct small-M kernel: two column blocks, Cout=4
     (4, 130, 0, 8, 8, 140, 3, 1, 1, True, 1, 0),       # multi-tile M/N, ragged
     (2, 128, 0, 32, 32, 128, 3, 1, 1, False, 1, 0),    # big enough for the 128x128 tile
 ]
