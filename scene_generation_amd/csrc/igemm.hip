@@ -613,24 +613,24 @@ struct EpRowMajor {  // out[z][m*ldc + n] ; bias per column n
   }
 };
 
-struct EpWgrad {     // tap-major virtual column n = t*cpad + cj  ->  out[z][m*ldc + cj*KS2 + t]
-  float* out; int M, Ccols, cpad, KS2, ldc; size_t zstride;
+struct EpWgrad {     // tap-major virtual column n = t*cpad + cj  ->  slab[z][m][t][cj] (lanes run along cj: coalesced)
+  float* out; int M, cpad, KS2; size_t zstride;
   __device__ __forceinline__ void set_limit(int) {}
   template <int TM, int TN>
   __device__ __forceinline__ void store(f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int z) const {
     float* o0 = out + (size_t)z * zstride;
+    const size_t ldm = (size_t)KS2 * cpad;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = nbase + j * 32 + (lane & 31);
-      const int t = n / cpad, cj = n - t * cpad;
-      if (cj >= Ccols || t >= KS2) continue;
-      float* o = o0 + (size_t)cj * KS2 + t;
+      if (n >= KS2 * cpad) continue;
+      float* o = o0 + n;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (m < M) o[(size_t)m * ldc] = acc[i][j][r];
+          if (m < M) o[(size_t)m * ldm] = acc[i][j][r];
         }
       }
     }
@@ -670,7 +670,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   if (bi.cols_per_batch > 0) {
     const int tn = bid % tiles_n, batch = tn / tiles_pb;
     n0 = batch * bi.cols_per_batch + (tn - batch * tiles_pb) * BN;
-    kend = min(kend, bi.kcnt[batch]);
+    if (bi.kcnt) kend = min(kend, bi.kcnt[batch]);
     al.set_batch(batch, bi.a_stride, 0);
     bl.set_batch(batch, bi.b_stride, (batch + 1) * bi.cols_per_batch);
     ep.set_limit((batch + 1) * bi.cols_per_batch);
@@ -1130,8 +1130,8 @@ __global__ void sparse_inv_kernel(const int* list, const int* cnt, int L, int C,
   for (int j = 0; j < n; ++j) pos = list[b * L + j] == c ? j : pos;
   inv[b * C + c] = pos;
 }
-// gw[m][c][t] = sum_b slab[b][m][inv[b][c]][t]  (images in ascending order => deterministic)
-__global__ void sparse_wgrad_reduce_kernel(const float* slabs, const int* inv, float* gw, int M, int C, int KS2, int L,
+// gw[m][c][t] = sum_b slab[b][m][t][inv[b][c]]  (images in ascending order => deterministic)
+__global__ void sparse_wgrad_reduce_kernel(const float* slabs, const int* inv, float* gw, int M, int C, int KS2, int cpad,
                                            int NB) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * C * KS2) return;
@@ -1141,12 +1141,26 @@ __global__ void sparse_wgrad_reduce_kernel(const float* slabs, const int* inv, f
   float v = 0.f;
   for (int b = 0; b < NB; ++b) {
     const int j = inv[b * C + c];
-    if (j >= 0) v += slabs[(((size_t)b * M + m) * L + j) * KS2 + t];
+    if (j >= 0) v += slabs[(((size_t)b * M + m) * KS2 + t) * cpad + j];
   }
   gw[i] = v;
 }
+// gw[m][c][t] = sum_z slab[z][m][t][c]: un-permutes the tap-major slabs of the weight-gradient GEMM (the GEMM epilogue
+// writes them coalesced; scattering 4-byte stores at stride KS2*4 from there cost 8x write amplification in HBM)
+__global__ void wgrad_unpermute_reduce_kernel(const float* slabs, float* gw, int M, int C, int KS2, int cpad, int S) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * C * KS2) return;
+  const int t = (int)(i % KS2);
+  const int c = (int)((i / KS2) % C);
+  const int m = (int)(i / ((size_t)KS2 * C));
+  const size_t zs = (size_t)M * KS2 * cpad;
+  const float* p = slabs + ((size_t)m * KS2 + t) * cpad + c;
+  float v = 0.f;
+  for (int z = 0; z < S; ++z) v += p[(size_t)z * zs];
+  gw[i] = v;
+}
 inline size_t sparse_wgrad_ws(int NB, int M, int C, int L, int KS2) {
-  return (size_t)NB * M * L * KS2 * sizeof(float) + (size_t)NB * C * sizeof(int);
+  return (size_t)NB * M * (sg_cdiv(L, 128) * 128) * KS2 * sizeof(float) + (size_t)NB * C * sizeof(int);
 }
 // launch plan of a weight-gradient GEMM (shared by the workspace query and the launcher)
 struct NkPlan { int tile; bool tap; int cpad; int splits; };
@@ -1220,17 +1234,19 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
   if (sp) pl.tap = true;
   if (sp && pl.cpad == 0) pl.cpad = sg_cdiv(Ccols, pl.tile == 1 ? 64 : 128) * (pl.tile == 1 ? 64 : 128);
   int splits = sp ? NB : pl.splits;
-  const size_t mn = (size_t)M * Ncols;
+  // slab size: the tap-major path keeps whole padded channel tiles, [m][t][cpad]
+  const size_t mn = pl.tap ? (size_t)M * KS2 * pl.cpad : (size_t)M * Ncols;
   if (!sp && splits > 1 && ws_bytes < mn * sizeof(float) * (size_t)splits) splits = (int)(ws_bytes / (mn * sizeof(float)));
   if (!sp && splits < 2) splits = 1;
+  SG_ARG_CHECK(!pl.tap || (ws && ws_bytes >= mn * sizeof(float) * (size_t)splits), "wgrad: workspace too small");
   const int kchunk = sp ? PQ : sg_cdiv(sg_cdiv(Kpix, splits), 64) * 64;      // multiple of every BKT
   splits = sg_cdiv(Kpix, kchunk);
   if (sp) { t_fixed_kchunk = PQ; flops = 2.0 * M * (double)Ncols * Kpix; }
-  float* dst = (splits > 1 || sp) ? reinterpret_cast<float*>(ws) : out;
+  float* dst = (splits > 1 || sp || pl.tap) ? reinterpret_cast<float*>(ws) : out;
   {
     SgProfScope prof(sg_igemm_kind(2, KS, pl.tile), s, flops, 0);
     if (pl.tap) {
-      const EpWgrad ep{dst, M, Ccols, pl.cpad, KS2, Ncols, mn};
+      const EpWgrad ep{dst, M, pl.cpad, KS2, mn};
       const bool vecA = (PQ % 4 == 0) && aligned16(A);
       // mask-free gather: reflection padding and whole 16-pixel k-tiles (split chunks are multiples of 64)
       const bool nomask = g.reflect && (Kpix % BK == 0) && (!sp || PQ % BK == 0);
@@ -1251,15 +1267,18 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
     }
   }
   t_fixed_kchunk = 0;
+  const size_t nout = (size_t)M * C * KS2;
   if (sp) {
     int* inv = reinterpret_cast<int*>(reinterpret_cast<float*>(ws) + (size_t)NB * mn);
     hipLaunchKernelGGL(sparse_inv_kernel, dim3(sg_cdiv(C, 256), NB), dim3(256), 0, s, sp->list, sp->cnt, sp->L, C, inv);
-    const size_t n = (size_t)M * C * KS2;
-    hipLaunchKernelGGL(sparse_wgrad_reduce_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, (const int*)inv,
-                       out, M, C, KS2, sp->L, NB);
+    hipLaunchKernelGGL(sparse_wgrad_reduce_kernel, dim3(sg_cdiv(nout, 256)), dim3(256), 0, s, (const float*)ws,
+                       (const int*)inv, out, M, C, KS2, pl.cpad, NB);
     return 0;
   }
-  if (splits > 1)
+  if (pl.tap)
+    hipLaunchKernelGGL(wgrad_unpermute_reduce_kernel, dim3(sg_cdiv(nout, 256)), dim3(256), 0, s, (const float*)ws, out, M, C,
+                       KS2, pl.cpad, splits);
+  else if (splits > 1)
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(sg_cdiv(mn, 256)), dim3(256), 0, s, (const float*)ws, out, mn, splits);
   return 0;
 }
@@ -1283,7 +1302,8 @@ int check_desc(const sgConvDesc* d, const char* who) {
 
 
 inline size_t wgrad_ws(int M, int C, int KS2, int Kpix, bool two) {
-  return (size_t)nk_plan(M, C, KS2, Kpix, two).splits * (size_t)M * C * KS2 * sizeof(float);
+  const NkPlan pl = nk_plan(M, C, KS2, Kpix, two);
+  return (size_t)pl.splits * (size_t)M * KS2 * (pl.tap ? pl.cpad : C) * sizeof(float);
 }
 
 }  // namespace
@@ -1412,7 +1432,7 @@ extern "C" int sg_conv2d_wgrad(const sgConvDesc* d, const float* gy, const float
   Gather g = make_gather(x1, x2, d->C1, d->C2, d->H, d->W, d->upsample, d->OH, d->OW, d->stride, d->pad, d->pad_reflect);
   g.bcast2 = d->x2_broadcast;
   const double flops = 2.0 * d->Cout * (double)(d->C1 + d->C2) * d->KS * d->KS * d->N * d->OH * d->OW;
-  run_nk_ks(d->KS, gy, d->Cout, d->Cout, g, d->N, gw, ws, ws ? ws_bytes : 0, flops, s);
+  if (int rc = run_nk_ks(d->KS, gy, d->Cout, d->Cout, g, d->N, gw, ws, ws ? ws_bytes : 0, flops, s)) return rc;
   SG_LAUNCH_CHECK("sg_conv2d_wgrad");
   if (gb) return sg_channel_sum(gy, gb, d->N, d->Cout, d->OH * d->OW, ws, ws ? ws_bytes : 0, stream);
   return 0;
@@ -1466,7 +1486,7 @@ extern "C" int sg_conv2d_wgrad_sparse(const sgConvDesc* d, const float* gy, cons
   Gather g = make_gather(x1, x2, d->C1, d->C2, d->H, d->W, d->upsample, d->OH, d->OW, d->stride, d->pad, d->pad_reflect);
   g.bcast2 = d->x2_broadcast;
   const Sparse sp{chan_list, chan_cnt, L};
-  run_nk_ks(d->KS, gy, d->Cout, d->Cout, g, d->N, gw, ws, ws_bytes, 0.0, s, &sp);
+  if (int rc = run_nk_ks(d->KS, gy, d->Cout, d->Cout, g, d->N, gw, ws, ws_bytes, 0.0, s, &sp)) return rc;
   SG_LAUNCH_CHECK("sg_conv2d_wgrad_sparse");
   if (gb) return sg_channel_sum(gy, gb, d->N, d->Cout, d->OH * d->OW, ws, ws_bytes, stream);
   return 0;
@@ -1520,8 +1540,9 @@ extern "C" int sg_convT2d_wgrad(const sgConvDesc* d, const float* gy, const floa
   SG_ARG_CHECK(gy && x && gw, "sg_convT2d_wgrad: null pointer");
   hipStream_t s = (hipStream_t)stream;
   Gather g = make_gather(gy, nullptr, d->Cout, 0, d->OH, d->OW, 1, d->H, d->W, d->stride, d->pad, 0);
-  run_nk_ks(d->KS, x, d->C1, d->C1, g, d->N, gw, ws, ws ? ws_bytes : 0,
-            2.0 * d->Cout * (double)d->C1 * d->KS * d->KS * d->N * d->H * d->W, s);
+  if (int rc = run_nk_ks(d->KS, x, d->C1, d->C1, g, d->N, gw, ws, ws ? ws_bytes : 0,
+                         2.0 * d->Cout * (double)d->C1 * d->KS * d->KS * d->N * d->H * d->W, s))
+    return rc;
   SG_LAUNCH_CHECK("sg_convT2d_wgrad");
   if (gb) return sg_channel_sum(gy, gb, d->N, d->Cout, d->OH * d->OW, ws, ws ? ws_bytes : 0, stream);
   return 0;
@@ -1536,6 +1557,20 @@ int run_dense(const A64& a64, const B64& b64, const A32& a32, const B128& b128, 
   return launch_cfg<Cfg64>(a64, b64, ep, M, N, K, 1, s);
 }
 }  // namespace
+
+// probe (not part of the ABI): batched dense GEMM C[m][b*P+p] = sum_k A[b][m][k] * B[b*P+p][k]
+extern "C" int sg_probe_bgemm(const float* A, const float* B, float* C, int M, int K, int P, int nb, int tile, sgStream stream) {
+  hipStream_t s = (hipStream_t)stream;
+  EpRowMajor ep{C, nullptr, M, nb * P, nb * P, SG_ACT_NONE, 0.f, 0};
+  t_batch = BatchInfo{P, nb, nullptr, M * K, 0};
+  if (tile == 0)
+    launch_cfg<Cfg128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, nb * P}, ep, M, nb * P, K, 1, s);
+  else
+    launch_cfg<Cfg64>(LoadKContig<64, true, false>{A, K, M}, LoadKContig<64, true, false>{B, K, nb * P}, ep, M, nb * P, K, 1, s);
+  t_batch = BatchInfo{0, 0, nullptr, 0, 0};
+  SG_LAUNCH_CHECK("sg_probe_bgemm");
+  return 0;
+}
 
 extern "C" int sg_linear_fwd(const float* x, const float* w, const float* b, float* y, int rows, int in_f, int out_f,
                              int act, float slope, sgStream stream) {
