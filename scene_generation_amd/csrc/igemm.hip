@@ -817,6 +817,21 @@ __global__ void slab_reduce_nchw_kernel(const float* ws, float* out, size_t n, i
   if (bias) v += bias[(i / PHW) % Mtot];
   out[i] = sg_apply_act(v, act, slope);
 }
+// float4 form (n % 4 == 0, PHW % 4 == 0: the four lanes of a vector share their channel)
+__global__ void slab_reduce_nchw_vec_kernel(const float4* ws, float4* out, size_t n4, int S, const float* bias, int PHW4,
+                                            int Mtot, int act, float slope) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = ws[i];
+  for (int z = 1; z < S; ++z) {
+    const float4 t = ws[(size_t)z * n4 + i];
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  const float b = bias ? bias[(i / PHW4) % Mtot] : 0.f;
+  v.x = sg_apply_act(v.x + b, act, slope); v.y = sg_apply_act(v.y + b, act, slope);
+  v.z = sg_apply_act(v.z + b, act, slope); v.w = sg_apply_act(v.w + b, act, slope);
+  out[i] = v;
+}
 
 // ReflectionPad2d(1) + 3x3 conv, data gradient without the padded grid.  The gradient of the padded input folds back as
 //   gx[i] = sum_k w[k] gy[i+1-k]  +  [i==1] w[0] gy[0]  +  [i==H-2] w[2] gy[H-1]        (per axis)
@@ -948,8 +963,15 @@ int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* b
     }
   }
   if (splits > 1)
-    hipLaunchKernelGGL(slab_reduce_nchw_kernel, dim3(sg_cdiv(nout, 256)), dim3(256), 0, s, (const float*)slabs, out, nout,
-                       splits, bias, g.PH * g.PW, Mtot, act, slope);
+  {
+    const int PHWo = g.PH * g.PW;
+    if (nout % 4 == 0 && PHWo % 4 == 0 && aligned16(slabs) && aligned16(out))
+      hipLaunchKernelGGL(slab_reduce_nchw_vec_kernel, dim3(sg_cdiv(nout / 4, 256)), dim3(256), 0, s, (const float4*)slabs,
+                         (float4*)out, nout / 4, splits, bias, PHWo / 4, Mtot, act, slope);
+    else
+      hipLaunchKernelGGL(slab_reduce_nchw_kernel, dim3(sg_cdiv(nout, 256)), dim3(256), 0, s, (const float*)slabs, out, nout,
+                         splits, bias, PHWo, Mtot, act, slope);
+  }
   return 0;
 }
 

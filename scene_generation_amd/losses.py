@@ -3,6 +3,7 @@ return 0-dim device tensors -- no ``.item()`` on the step path."""
 import torch.nn as nn
 
 from . import ops
+from .utils import weighted_sum
 
 
 def get_gan_losses(gan_type):
@@ -51,10 +52,8 @@ class GANLoss(nn.Module):
     def __call__(self, input, target_is_real):
         t = self.real_label if target_is_real else self.fake_label
         if isinstance(input[0], list):
-            loss = 0
-            for input_i in input:
-                loss = loss + ops.mse_const(input_i[-1], t)
-            return loss
+            terms = [ops.mse_const(input_i[-1], t) for input_i in input]
+            return terms[0] if len(terms) == 1 else weighted_sum(terms, [1.0] * len(terms))
         return ops.mse_const(input[-1], t)
 
 

@@ -23,7 +23,7 @@ from .losses import get_gan_losses, GANLoss
 from .model import Model
 from .optim import FusedAdam
 from .parallel import GradReducer, broadcast_params
-from .utils import LossManager
+from .utils import LossManager, weighted_sum
 
 
 @contextlib.contextmanager
@@ -277,14 +277,12 @@ class Trainer:
 
     def calculate_features_loss(self, pred_fake, pred_real):
         """trainer.py:331-340."""
-        loss = 0
         nums_d = len(pred_fake)
         feat_weights = 4.0 / len(pred_fake[0])
         D_weights = 1.0 / nums_d
-        for i in range(nums_d):
-            for j in range(len(pred_fake[i]) - 1):
-                loss = loss + (D_weights * feat_weights) * ops.l1(pred_fake[i][j], pred_real[i][j].detach())
-        return loss
+        terms = [ops.l1(pred_fake[i][j], pred_real[i][j].detach())
+                 for i in range(nums_d) for j in range(len(pred_fake[i]) - 1)]
+        return weighted_sum(terms, [D_weights * feat_weights] * len(terms))
 
     def step(self, batch, use_gt=True):
         """One full G+D iteration = train.py:190-215.  ``batch`` = the 8-tuple of coco_collate_fn on the device."""

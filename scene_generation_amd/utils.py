@@ -33,21 +33,54 @@ def bool_flag(s):
     raise ValueError('Invalid value "%s" for bool flag (should be 0 or 1)' % s)
 
 
+_WEIGHT_CACHE = {}
+
+
+def weighted_sum(tensors, weights):
+    """sum_i weights[i] * tensors[i] for scalar tensors as ONE stack + dot (the reference's chain of python-level
+    ``loss = loss + w * term`` costs ~6 tiny kernels per term, forward + backward)."""
+    dev = tensors[0].device
+    key = (str(dev), tuple(float(w) for w in weights))
+    w = _WEIGHT_CACHE.get(key)
+    if w is None:
+        w = _WEIGHT_CACHE[key] = torch.tensor(key[1], dtype=torch.float32, device=dev)
+    return torch.dot(torch.stack([t.reshape(()).float() for t in tensors]), w)
+
+
 class LossManager(object):
+    """utils.py:43-59 of the reference: ``total_loss = sum_i weight_i * loss_i`` and a name -> float dict.  Lazy: no
+    ``.item()`` until somebody reads a value, and the weighted sum is built once when ``total_loss`` is first read."""
+
     def __init__(self):
-        self.total_loss = None
+        self._terms, self._weights = [], []
+        self._total = None
         self._lazy = {}
 
     def add_loss(self, loss, name, weight=1.0, use_loss=True):
-        cur = loss * weight
+        if not isinstance(loss, torch.Tensor):
+            loss = torch.as_tensor(float(loss))
         if use_loss:
-            self.total_loss = cur if self.total_loss is None else self.total_loss + cur
-        self._lazy[name] = cur.detach()
+            self._terms.append(loss)
+            self._weights.append(float(weight))
+            self._total = None
+        self._lazy[name] = (loss.detach(), float(weight))
+
+    @property
+    def total_loss(self):
+        if self._total is None and self._terms:
+            self._total = weighted_sum(self._terms, self._weights)
+        return self._total
 
     @property
     def all_losses(self):
         """name -> python float (materialised on access; this is where the host sync happens)"""
-        return {k: (v.item() if isinstance(v, torch.Tensor) else float(v)) for k, v in self._lazy.items()}
+        out = {}
+        for k, v in self._lazy.items():
+            if isinstance(v, tuple):
+                out[k] = float(v[0].item()) * v[1]
+            else:
+                out[k] = v.item() if isinstance(v, torch.Tensor) else float(v)
+        return out
 
     def set_value(self, name, value):
         self._lazy[name] = value.detach() if isinstance(value, torch.Tensor) else value
