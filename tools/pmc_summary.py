@@ -36,12 +36,12 @@ def main():
     tot_ns = sum(v['_ns'] for v in A.values())
     tot_mfma = sum(v['SQ_VALU_MFMA_BUSY_CYCLES'] for v in A.values())
     tot_gui = sum(v['GRBM_GUI_ACTIVE'] for v in A.values())
-    print('all kernels: %.1f ms/step under PMC | MFMA busy = %.1f %% of (GRBM_GUI_ACTIVE x 1024 SIMDs) | FETCH %.2f GB/step, '
+    print('all kernels: %.1f ms/step under PMC | MFMA busy = %.1f %% of the SIMD-cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs: / 8 x 1024 SIMDs) | FETCH %.2f GB/step, '
           'WRITE %.2f GB/step (raw counter KB -> bytes, uncorrected)' % (
-              tot_ns / 1e6 / steps, 100 * tot_mfma / (tot_gui * 1024 + 1e-9),
+              tot_ns / 1e6 / steps, 100 * tot_mfma / (tot_gui * 128 + 1e-9),
               sum(v['FETCH_SIZE'] for v in B.values()) * 1024 / 1e9 / steps,
               sum(v['WRITE_SIZE'] for v in C.values()) * 1024 / 1e9 / steps))
-    print('| kernel | launches/step | ms/step (pass A) | MFMA busy % of GUI x SIMDs | FETCH MB/launch | WRITE MB/launch | (FETCH+WRITE)/time GB/s |')
+    print('| kernel | launches/step | ms/step (pass A) | MFMA busy % of SIMD-cycles | FETCH MB/launch | WRITE MB/launch | (FETCH+WRITE)/time GB/s |')
     print('|---|---|---|---|---|---|---|')
     for k, v in sorted(A.items(), key=lambda kv: -kv[1]['_ns'])[:top]:
         n = v['_n']
@@ -49,7 +49,7 @@ def main():
         w = C[k]['WRITE_SIZE'] * 1024 / max(C[k]['_n'], 1)
         t = v['_ns'] / n * 1e-9
         print('| %s | %.1f | %.3f | %.1f | %.1f | %.1f | %.0f |' % (
-            k, n / steps, v['_ns'] / 1e6 / steps, 100 * v['SQ_VALU_MFMA_BUSY_CYCLES'] / (v['GRBM_GUI_ACTIVE'] * 1024 + 1e-9),
+            k, n / steps, v['_ns'] / 1e6 / steps, 100 * v['SQ_VALU_MFMA_BUSY_CYCLES'] / (v['GRBM_GUI_ACTIVE'] * 128 + 1e-9),
             f / 1e6, w / 1e6, (f + w) / t / 1e9))
 
 
