@@ -88,6 +88,15 @@ int sg_conv2d_fwd_sparse(const sgConvDesc* d, const float* x1, const float* x2, 
 int sg_conv2d_wgrad_sparse(const sgConvDesc* d, const float* gy, const float* x1, const float* x2,
                            const int32_t* chan_list, const int32_t* chan_cnt, int L, float* gw, float* gb,
                            void* ws, size_t ws_bytes, sgStream stream);
+/* Winograd F(2x2, 3x3) forward / weight gradient for ReflectionPad2d(1) + 3x3 stride-1 convs whose channel counts and
+   tile count N*(H/2)*(W/2) are multiples of 128 (the ResnetBlock convs, reference layers.py:251-270): 2.25x fewer MACs;
+   fp32 throughout, results agree with sg_conv2d_fwd / sg_conv2d_wgrad to fp32 rounding (gb via sg_channel_sum). */
+int sg_conv2d_wino_supported(const sgConvDesc* d);
+size_t sg_conv2d_wino_ws_bytes(const sgConvDesc* d);
+int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                       float slope, void* ws, size_t ws_bytes, sgStream stream);
+int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, void* ws, size_t ws_bytes,
+                         sgStream stream);
 /* Direct (vector-ALU) kernels for ReflectionPad2d(3) + Conv2d(C, Cout <= 4, 7) [+ act]: the generator's RGB head
    (reference generators.py:88-90).  Same results as sg_conv2d_fwd / sg_conv2d_wgrad (gb via sg_channel_sum). */
 int sg_conv2d_smallm_supported(const sgConvDesc* d);

@@ -1570,6 +1570,209 @@ extern "C" int sg_convT2d_wgrad(const sgConvDesc* d, const float* gy, const floa
   return 0;
 }
 
+// ================================================================================================
+// Winograd F(2x2, 3x3) for ReflectionPad2d(1) + 3x3 stride-1 convs with >= 128 channels on both sides (the ResnetBlock
+// convs, layers.py:251-270): forward and weight gradient as 16 batched dense GEMMs over the transformed operands,
+// 2.25x fewer MACs than the direct form.  All operands are laid out k-contiguous, so both GEMM loaders are the
+// mask-free float4 ones.  (The data gradient stays on the direct kernel: its folded form has no padded-grid waste.)
+// ================================================================================================
+namespace {
+
+__device__ __forceinline__ int wino_reflect(int i, int L) { i = i < 0 ? -i : i; return i >= L ? 2 * L - 2 - i : i; }
+
+// V = B^T d B of the 4x4 input patch of tile p = (n, ti, tj); PFAST selects the layout: V[xi][c][p] (1) or V[xi][p][c] (0)
+template <int PFAST>
+__global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int C, int H, int W) {
+  const int TH = H / 2, TW = W / 2;
+  const size_t P = (size_t)N * TH * TW, total = P * C;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const size_t p = PFAST ? idx % P : idx / C;
+  const int c = (int)(PFAST ? idx / P : idx % C);
+  const int n = (int)(p / (TH * TW)), r = (int)(p - (size_t)n * TH * TW), ti = r / TW, tj = r - ti * TW;
+  const float* xp = x + ((size_t)n * C + c) * H * W;
+  float d[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int ih = wino_reflect(2 * ti - 1 + a, H);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) d[a][b] = xp[ih * W + wino_reflect(2 * tj - 1 + b, W)];
+  }
+  float t[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v0 = t[i][0] - t[i][2], v1 = t[i][1] + t[i][2], v2 = t[i][2] - t[i][1], v3 = t[i][1] - t[i][3];
+    const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const size_t xi = (size_t)(i * 4 + j);
+      V[PFAST ? (xi * C + c) * P + p : (xi * P + p) * C + c] = v[j];
+    }
+  }
+}
+
+// U[xi][m][c] = (G g G^T)[xi]
+__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, size_t MC) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= MC) return;
+  const float* g = w + i * 9;
+  float t[4][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
+    t[0][j] = g0; t[1][j] = 0.5f * (g0 + g1 + g2); t[2][j] = 0.5f * (g0 - g1 + g2); t[3][j] = g2;
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const float u[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) U[(size_t)(a * 4 + b) * MC + i] = u[b];
+  }
+}
+
+// y[n][m][2ti+a][2tj+b] = act((A^T Mx A)[a][b] + bias[m]),  Mx[m][xi*P + p]
+__global__ void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias, float* __restrict__ y, int N,
+                                   int M, int H, int W, int act, float slope) {
+  const int TH = H / 2, TW = W / 2;
+  const size_t P = (size_t)N * TH * TW;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * M) return;
+  const size_t p = idx % P;
+  const int m = (int)(idx / P);
+  const float* src = Mx + (size_t)m * 16 * P + p;
+  float q[4][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) q[i >> 2][i & 3] = src[(size_t)i * P];
+  float s[2][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s[0][j] = q[0][j] + q[1][j] + q[2][j]; s[1][j] = q[1][j] - q[2][j] - q[3][j]; }
+  const float b = bias ? bias[m] : 0.f;
+  const int n = (int)(p / (TH * TW)), r = (int)(p - (size_t)n * TH * TW), ti = r / TW, tj = r - ti * TW;
+  float* o = y + (((size_t)n * M + m) * H + 2 * ti) * W + 2 * tj;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const float y0 = s[a][0] + s[a][1] + s[a][2] + b, y1 = s[a][1] - s[a][2] - s[a][3] + b;
+    *reinterpret_cast<float2*>(o + a * W) = make_float2(sg_apply_act(y0, act, slope), sg_apply_act(y1, act, slope));
+  }
+}
+
+// Yt[xi][m][p] = (A dY A^T)[xi] of the 2x2 gradient tile p
+__global__ void wino_gy_kernel(const float* __restrict__ gy, float* __restrict__ Yt, int N, int M, int H, int W) {
+  const int TH = H / 2, TW = W / 2;
+  const size_t P = (size_t)N * TH * TW;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * M) return;
+  const size_t p = idx % P;
+  const int m = (int)(idx / P);
+  const int n = (int)(p / (TH * TW)), r = (int)(p - (size_t)n * TH * TW), ti = r / TW, tj = r - ti * TW;
+  const float* g = gy + (((size_t)n * M + m) * H + 2 * ti) * W + 2 * tj;
+  const float2 r0 = *reinterpret_cast<const float2*>(g), r1 = *reinterpret_cast<const float2*>(g + W);
+  const float t[4][2] = {{r0.x, r0.y}, {r0.x + r1.x, r0.y + r1.y}, {r0.x - r1.x, r0.y - r1.y}, {-r1.x, -r1.y}};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v[4] = {t[i][0], t[i][0] + t[i][1], t[i][0] - t[i][1], -t[i][1]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Yt[((size_t)(i * 4 + j) * M + m) * P + p] = v[j];
+  }
+}
+
+// gw[m][c][3][3] = G^T T G,  T[m][xi*C + c]
+__global__ void wino_wgrad_output_kernel(const float* __restrict__ T, float* __restrict__ gw, int M, int C) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)M * C) return;
+  const int c = (int)(idx % C);
+  const size_t m = idx / C;
+  const float* src = T + m * 16 * C + c;
+  float q[4][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) q[i >> 2][i & 3] = src[(size_t)i * C];
+  float s[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s[0][j] = q[0][j] + 0.5f * (q[1][j] + q[2][j]);
+    s[1][j] = 0.5f * (q[1][j] - q[2][j]);
+    s[2][j] = 0.5f * (q[1][j] + q[2][j]) + q[3][j];
+  }
+  float* o = gw + idx * 9;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    o[a * 3 + 0] = s[a][0] + 0.5f * (s[a][1] + s[a][2]);
+    o[a * 3 + 1] = 0.5f * (s[a][1] - s[a][2]);
+    o[a * 3 + 2] = 0.5f * (s[a][1] + s[a][2]) + s[a][3];
+  }
+}
+
+bool wino_ok(const sgConvDesc* d) {
+  if (!d || !d->pad_reflect || d->pad != 1 || d->KS != 3 || d->stride != 1 || d->upsample != 1 || d->C2 != 0) return false;
+  if (d->H < 4 || d->W < 4 || (d->H & 1) || (d->W & 1) || d->OH != d->H || d->OW != d->W) return false;
+  const long P = (long)d->N * (d->H / 2) * (d->W / 2);
+  return d->C1 % 128 == 0 && d->Cout % 128 == 0 && P % 128 == 0 && 16.0 * P * (d->C1 > d->Cout ? d->C1 : d->Cout) < 2147483647.0 &&
+         16.0 * d->C1 * d->Cout < 2147483647.0;
+}
+
+// C[m][b*cols + j] = sum_k A[b][m][k] * B[b*cols + j][k]   (16 batches, everything a multiple of the 128-tile)
+void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, int K, double flops, hipStream_t s) {
+  EpRowMajor ep{Cout, nullptr, M, 16 * cols, 16 * cols, SG_ACT_NONE, 0.f, 0};
+  t_batch = BatchInfo{cols, 16, nullptr, M * K, 0};
+  {
+    SgProfScope prof(sg_igemm_kind(0, 3, 0), s, flops, 0);
+    launch_cfg<Cfg128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M, 16 * cols,
+                       K, 1, s);
+  }
+  t_batch = BatchInfo{0, 0, nullptr, 0, 0};
+}
+
+}  // namespace
+
+extern "C" int sg_conv2d_wino_supported(const sgConvDesc* d) { return wino_ok(d) ? 1 : 0; }
+
+extern "C" size_t sg_conv2d_wino_ws_bytes(const sgConvDesc* d) {
+  if (!wino_ok(d)) return 0;
+  const size_t P = (size_t)d->N * (d->H / 2) * (d->W / 2), M = d->Cout, C = d->C1;
+  return 16 * (M * C + P * C + M * P) * sizeof(float) + 1024;
+}
+
+extern "C" int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                                  float slope, void* ws, size_t ws_bytes, sgStream stream) {
+  SG_ARG_CHECK(wino_ok(d), "sg_conv2d_wino_fwd: unsupported desc");
+  SG_ARG_CHECK(x && w && y && ws && ws_bytes >= sg_conv2d_wino_ws_bytes(d), "sg_conv2d_wino_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int M = d->Cout, C = d->C1;
+  const size_t P = (size_t)d->N * (d->H / 2) * (d->W / 2);
+  float* U = reinterpret_cast<float*>(ws);
+  float* V = U + 16 * (size_t)M * C;
+  float* Mx = V + 16 * P * C;
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, w, U, (size_t)M * C);
+  hipLaunchKernelGGL(wino_input_kernel<0>, dim3(sg_cdiv(P * C, 256)), dim3(256), 0, s, x, V, d->N, C, d->H, d->W);
+  wino_bgemm(U, V, Mx, M, (int)P, C, 2.0 * M * (double)C * 16.0 * P, s);
+  hipLaunchKernelGGL(wino_output_kernel, dim3(sg_cdiv(P * M, 256)), dim3(256), 0, s, (const float*)Mx, bias, y, d->N, M, d->H,
+                     d->W, act, slope);
+  SG_LAUNCH_CHECK("sg_conv2d_wino_fwd");
+  return 0;
+}
+
+extern "C" int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, void* ws, size_t ws_bytes,
+                                    sgStream stream) {
+  SG_ARG_CHECK(wino_ok(d), "sg_conv2d_wino_wgrad: unsupported desc");
+  SG_ARG_CHECK(gy && x && gw && ws && ws_bytes >= sg_conv2d_wino_ws_bytes(d), "sg_conv2d_wino_wgrad: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int M = d->Cout, C = d->C1;
+  const size_t P = (size_t)d->N * (d->H / 2) * (d->W / 2);
+  float* T = reinterpret_cast<float*>(ws);          // [M][16][C]
+  float* Vp = T + 16 * (size_t)M * C;               // [16][C][P]
+  float* Yt = Vp + 16 * P * C;                      // [16][M][P]
+  hipLaunchKernelGGL(wino_input_kernel<1>, dim3(sg_cdiv(P * C, 256)), dim3(256), 0, s, x, Vp, d->N, C, d->H, d->W);
+  hipLaunchKernelGGL(wino_gy_kernel, dim3(sg_cdiv(P * M, 256)), dim3(256), 0, s, gy, Yt, d->N, M, d->H, d->W);
+  wino_bgemm(Yt, Vp, T, M, C, (int)P, 2.0 * M * (double)C * 16.0 * P, s);
+  hipLaunchKernelGGL(wino_wgrad_output_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, (const float*)T, gw, M, C);
+  SG_LAUNCH_CHECK("sg_conv2d_wino_wgrad");
+  return 0;
+}
+
 // ---- dense layers --------------------------------------------------------------------------------
 namespace {
 template <class A64, class B64, class A32, class B128>

@@ -5,6 +5,7 @@ the current HIP stream.  Every forward/backward below is one or a few hand-writt
 launches through ctypes; there is no eager/CPU fallback -- a CPU tensor raises.
 """
 import contextlib
+import os
 import ctypes
 
 import torch
@@ -100,7 +101,12 @@ class Conv2dFn(Function):
         d = _conv_desc(N, C1, C2, H, W, Cout, KS, stride, pad, reflect, upsample, OH, OW, 0, bcast)
         y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=x1.device)
         ctx.smallm = x2 is None and sparse is None and bool(_L().sg_conv2d_smallm_supported(ctypes.byref(d)))
-        if ctx.smallm:              # <= 4 output channels (the RGB head): direct vector-ALU kernel, no MFMA tile waste
+        ctx.wino = (x2 is None and sparse is None and WINOGRAD and bool(_L().sg_conv2d_wino_supported(ctypes.byref(d))))
+        if ctx.wino:                # ResnetBlock convs: Winograd F(2x2,3x3), 16 batched dense GEMMs
+            wsb = _L().sg_conv2d_wino_ws_bytes(ctypes.byref(d))
+            _call('sg_conv2d_wino_fwd', ctypes.byref(d), _p(x1), _p(weight), _p(bias), _p(y), act, slope,
+                  _p(workspace(wsb, x1.device)), wsb, _stream())
+        elif ctx.smallm:              # <= 4 output channels (the RGB head): direct vector-ALU kernel, no MFMA tile waste
             _call('sg_conv2d_smallm_fwd', ctypes.byref(d), _p(x1), _p(weight), _p(bias), _p(y), act, slope, _stream())
         elif sparse is not None:    # (chan_list [N, L] int32, chan_cnt [N] int32): see sg_conv2d_fwd_sparse
             clist, ccnt = sparse
@@ -177,7 +183,13 @@ class Conv2dFn(Function):
             if need_w:
                 gw = torch.empty_like(weight)
                 gb = torch.empty(d.Cout, dtype=torch.float32, device=dev) if need_b else None
-                if ctx.smallm:
+                if ctx.wino:
+                    wsb = max(_L().sg_conv2d_wino_ws_bytes(ctypes.byref(d)), _L().sg_channel_sum_ws_bytes(d.Cout))
+                    ws = workspace(wsb, dev)
+                    _call('sg_conv2d_wino_wgrad', ctypes.byref(d), _p(gy), _p(x1), _p(gw), _p(ws), wsb, s)
+                    if gb is not None:
+                        _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb, s)
+                elif ctx.smallm:
                     wsb = max(_L().sg_conv2d_smallm_ws_bytes(ctypes.byref(d)), _L().sg_channel_sum_ws_bytes(d.Cout))
                     ws = workspace(wsb, dev)
                     _call('sg_conv2d_smallm_wgrad', ctypes.byref(d), _p(gy), _p(x1), _p(gw), _p(ws), wsb, s)
@@ -201,6 +213,9 @@ class Conv2dFn(Function):
                 _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb, s)
         return gx1, gx2, gw, gb, None, None, None, None, None, None, None, None
 
+
+# Winograd F(2x2,3x3) for the ResnetBlock convs (SG_WINOGRAD=0 keeps them on the direct implicit-GEMM kernels)
+WINOGRAD = os.environ.get('SG_WINOGRAD', '1') != '0'
 
 _SKIP_PARAM_GRADS = set()
 

@@ -84,6 +84,8 @@ CONV_CASES = [
     (2, 6, 0, 40, 136, 4, 7, 1, 3, True, 1, 0),        # direct small-M kernel: two column blocks, Cout=4
     (4, 130, 0, 8, 8, 140, 3, 1, 1, True, 1, 0),       # multi-tile M/N, ragged
     (2, 128, 0, 32, 32, 128, 3, 1, 1, False, 1, 0),    # big enough for the 128x128 tile
+    (8, 128, 0, 8, 8, 128, 3, 1, 1, True, 1, 0),       # Winograd F(2x2,3x3) path (channels, tiles multiples of 128)
+    (2, 256, 0, 16, 16, 128, 3, 1, 1, True, 1, 1),     # Winograd, Cin != Cout, fused ReLU
 ]
 
 
