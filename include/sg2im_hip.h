@@ -97,6 +97,9 @@ int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const float* w, cons
                        float slope, void* ws, size_t ws_bytes, sgStream stream);
 int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, void* ws, size_t ws_bytes,
                          sgStream stream);
+/* gx [N, C1, H, W] (all input channels): Winograd on the padded gradient grid + reflection fold */
+int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, void* ws, size_t ws_bytes,
+                         sgStream stream);
 /* Direct (vector-ALU) kernels for ReflectionPad2d(3) + Conv2d(C, Cout <= 4, 7) [+ act]: the generator's RGB head
    (reference generators.py:88-90).  Same results as sg_conv2d_fwd / sg_conv2d_wgrad (gb via sg_channel_sum). */
 int sg_conv2d_smallm_supported(const sgConvDesc* d);

@@ -1580,23 +1580,40 @@ namespace {
 
 __device__ __forceinline__ int wino_reflect(int i, int L) { i = i < 0 ? -i : i; return i >= L ? 2 * L - 2 - i : i; }
 
-// V = B^T d B of the 4x4 input patch of tile p = (n, ti, tj); PFAST selects the layout: V[xi][c][p] (1) or V[xi][p][c] (0)
+// V = B^T d B of the 4x4 input patch of tile p = (n, ti, tj) on a TH x TW tile grid; the patch starts at (2ti+off, 2tj+off)
+// and is reflected (zero_pad == 0) or zero-extended (zero_pad == 1) outside the plane.  PFAST selects the layout:
+// V[xi][c][p] (1) or V[xi][p][c] (0); rows p in [N*TH*TW, Pstride) are zero padding for the 128-wide GEMM tiles.
 template <int PFAST>
-__global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int C, int H, int W) {
-  const int TH = H / 2, TW = W / 2;
-  const size_t P = (size_t)N * TH * TW, total = P * C;
+__global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int C, int H, int W, int TH, int TW,
+                                  int off, int zero_pad, size_t Pstride) {
+  const size_t P = (size_t)N * TH * TW, total = Pstride * C;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  const size_t p = PFAST ? idx % P : idx / C;
-  const int c = (int)(PFAST ? idx / P : idx % C);
-  const int n = (int)(p / (TH * TW)), r = (int)(p - (size_t)n * TH * TW), ti = r / TW, tj = r - ti * TW;
-  const float* xp = x + ((size_t)n * C + c) * H * W;
+  const size_t p = PFAST ? idx % Pstride : idx / C;
+  const int c = (int)(PFAST ? idx / Pstride : idx % C);
   float d[4][4];
+  if (p < P) {
+    const int n = (int)(p / (TH * TW)), r = (int)(p - (size_t)n * TH * TW), ti = r / TW, tj = r - ti * TW;
+    const float* xp = x + ((size_t)n * C + c) * H * W;
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int ih = wino_reflect(2 * ti - 1 + a, H);
+    for (int a = 0; a < 4; ++a) {
+      const int ih0 = 2 * ti + off + a;
+      const bool rok = !zero_pad || (unsigned)ih0 < (unsigned)H;
+      const int ih = zero_pad ? (rok ? ih0 : 0) : wino_reflect(ih0, H);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) d[a][b] = xp[ih * W + wino_reflect(2 * tj - 1 + b, W)];
+      for (int b = 0; b < 4; ++b) {
+        const int iw0 = 2 * tj + off + b;
+        const bool ok = rok && (!zero_pad || (unsigned)iw0 < (unsigned)W);
+        const int iw = zero_pad ? (ok ? iw0 : 0) : wino_reflect(iw0, W);
+        const float v = xp[ih * W + iw];
+        d[a][b] = ok ? v : 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) d[a][b] = 0.f;
   }
   float t[4][4];
 #pragma unroll
@@ -1610,43 +1627,47 @@ __global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const size_t xi = (size_t)(i * 4 + j);
-      V[PFAST ? (xi * C + c) * P + p : (xi * P + p) * C + c] = v[j];
+      V[PFAST ? (xi * C + c) * Pstride + p : (xi * Pstride + p) * C + c] = v[j];
     }
   }
 }
 
-// U[xi][m][c] = (G g G^T)[xi]
-__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, size_t MC) {
+// U[xi][r][c] = (G g G^T)[xi] with g = w[r][c] (flip == 0) or the 180-degree rotated w[c][r] (flip == 1: the data gradient
+// is a correlation with the flipped, transposed filter)
+__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int R, int Cc, int flip) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= MC) return;
-  const float* g = w + i * 9;
+  const size_t RC = (size_t)R * Cc;
+  if (i >= RC) return;
+  const int c = (int)(i % Cc);
+  const size_t r = i / Cc;
+  const float* g = w + (flip ? ((size_t)c * R + r) * 9 : i * 9);
   float t[4][3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
+    const float g0 = flip ? g[8 - j] : g[j], g1 = flip ? g[5 - j] : g[3 + j], g2 = flip ? g[2 - j] : g[6 + j];
     t[0][j] = g0; t[1][j] = 0.5f * (g0 + g1 + g2); t[2][j] = 0.5f * (g0 - g1 + g2); t[3][j] = g2;
   }
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const float u[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
 #pragma unroll
-    for (int b = 0; b < 4; ++b) U[(size_t)(a * 4 + b) * MC + i] = u[b];
+    for (int b = 0; b < 4; ++b) U[(size_t)(a * 4 + b) * RC + i] = u[b];
   }
 }
 
-// y[n][m][2ti+a][2tj+b] = act((A^T Mx A)[a][b] + bias[m]),  Mx[m][xi*P + p]
+// y[n][m][2ti+a][2tj+b] = act((A^T Mx A)[a][b] + bias[m]),  Mx[m][xi*Pstride + p]
 __global__ void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias, float* __restrict__ y, int N,
-                                   int M, int H, int W, int act, float slope) {
+                                   int M, int H, int W, size_t Pstride, int act, float slope) {
   const int TH = H / 2, TW = W / 2;
   const size_t P = (size_t)N * TH * TW;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= P * M) return;
   const size_t p = idx % P;
   const int m = (int)(idx / P);
-  const float* src = Mx + (size_t)m * 16 * P + p;
+  const float* src = Mx + (size_t)m * 16 * Pstride + p;
   float q[4][4];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) q[i >> 2][i & 3] = src[(size_t)i * P];
+  for (int i = 0; i < 16; ++i) q[i >> 2][i & 3] = src[(size_t)i * Pstride];
   float s[2][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) { s[0][j] = q[0][j] + q[1][j] + q[2][j]; s[1][j] = q[1][j] - q[2][j] - q[3][j]; }
@@ -1730,10 +1751,40 @@ void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, in
 
 extern "C" int sg_conv2d_wino_supported(const sgConvDesc* d) { return wino_ok(d) ? 1 : 0; }
 
+static size_t wino_dgrad_tiles(const sgConvDesc* d) {      // tiles of the (H+2) x (W+2) padded gradient grid, 128-padded
+  const size_t P = (size_t)d->N * (d->H / 2 + 1) * (d->W / 2 + 1);
+  return (P + 127) / 128 * 128;
+}
 extern "C" size_t sg_conv2d_wino_ws_bytes(const sgConvDesc* d) {
   if (!wino_ok(d)) return 0;
-  const size_t P = (size_t)d->N * (d->H / 2) * (d->W / 2), M = d->Cout, C = d->C1;
-  return 16 * (M * C + P * C + M * P) * sizeof(float) + 1024;
+  const size_t P = (size_t)d->N * (d->H / 2) * (d->W / 2), M = d->Cout, C = d->C1, Pd = wino_dgrad_tiles(d);
+  const size_t a = 16 * (M * C + P * C + M * P);
+  const size_t b = 16 * (M * C + Pd * M + C * Pd) + (size_t)d->N * C * (d->H + 2) * (d->W + 2);
+  return (a > b ? a : b) * sizeof(float) + 1024;
+}
+
+// gx [N, C1, H, W]: Winograd over the (H+2) x (W+2) gradient of the reflect-padded input (correlation of the zero-extended
+// gy with the rotated filter), then the reflection fold (sg_pad_upsample_bwd).  1.44x fewer MACs than the direct folded form.
+extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, void* ws, size_t ws_bytes,
+                                    sgStream stream) {
+  SG_ARG_CHECK(wino_ok(d), "sg_conv2d_wino_dgrad: unsupported desc");
+  SG_ARG_CHECK(gy && w && gx && ws && ws_bytes >= sg_conv2d_wino_ws_bytes(d), "sg_conv2d_wino_dgrad: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int M = d->C1, K = d->Cout;                 // rows = input channels, reduction over output channels
+  const int TH = d->H / 2 + 1, TW = d->W / 2 + 1;
+  const size_t Pd = wino_dgrad_tiles(d);
+  float* U = reinterpret_cast<float*>(ws);          // [16][C1][Cout]
+  float* V = U + 16 * (size_t)M * K;                // [16][Pd][Cout]
+  float* Mx = V + 16 * Pd * K;                      // [C1][16][Pd]
+  float* gpad = Mx + 16 * Pd * M;                   // [N][C1][H+2][W+2]
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(sg_cdiv((size_t)M * K, 256)), dim3(256), 0, s, w, U, M, K, 1);
+  hipLaunchKernelGGL(wino_input_kernel<0>, dim3(sg_cdiv(Pd * K, 256)), dim3(256), 0, s, gy, V, d->N, K, d->H, d->W, TH, TW, -2,
+                     1, Pd);
+  wino_bgemm(U, V, Mx, M, (int)Pd, K, 2.0 * M * (double)K * 16.0 * Pd, s);
+  hipLaunchKernelGGL(wino_output_kernel, dim3(sg_cdiv((size_t)d->N * TH * TW * M, 256)), dim3(256), 0, s, (const float*)Mx,
+                     (const float*)nullptr, gpad, d->N, M, d->H + 2, d->W + 2, Pd, SG_ACT_NONE, 0.f);
+  SG_LAUNCH_CHECK("sg_conv2d_wino_dgrad");
+  return sg_pad_upsample_bwd(gpad, gx, d->N * M, d->H, d->W, 1, 1, stream);
 }
 
 extern "C" int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y, int act,
@@ -1746,11 +1797,12 @@ extern "C" int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const flo
   float* U = reinterpret_cast<float*>(ws);
   float* V = U + 16 * (size_t)M * C;
   float* Mx = V + 16 * P * C;
-  hipLaunchKernelGGL(wino_weight_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, w, U, (size_t)M * C);
-  hipLaunchKernelGGL(wino_input_kernel<0>, dim3(sg_cdiv(P * C, 256)), dim3(256), 0, s, x, V, d->N, C, d->H, d->W);
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, w, U, M, C, 0);
+  hipLaunchKernelGGL(wino_input_kernel<0>, dim3(sg_cdiv(P * C, 256)), dim3(256), 0, s, x, V, d->N, C, d->H, d->W, d->H / 2,
+                     d->W / 2, -1, 0, P);
   wino_bgemm(U, V, Mx, M, (int)P, C, 2.0 * M * (double)C * 16.0 * P, s);
   hipLaunchKernelGGL(wino_output_kernel, dim3(sg_cdiv(P * M, 256)), dim3(256), 0, s, (const float*)Mx, bias, y, d->N, M, d->H,
-                     d->W, act, slope);
+                     d->W, P, act, slope);
   SG_LAUNCH_CHECK("sg_conv2d_wino_fwd");
   return 0;
 }
@@ -1765,7 +1817,8 @@ extern "C" int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const 
   float* T = reinterpret_cast<float*>(ws);          // [M][16][C]
   float* Vp = T + 16 * (size_t)M * C;               // [16][C][P]
   float* Yt = Vp + 16 * P * C;                      // [16][M][P]
-  hipLaunchKernelGGL(wino_input_kernel<1>, dim3(sg_cdiv(P * C, 256)), dim3(256), 0, s, x, Vp, d->N, C, d->H, d->W);
+  hipLaunchKernelGGL(wino_input_kernel<1>, dim3(sg_cdiv(P * C, 256)), dim3(256), 0, s, x, Vp, d->N, C, d->H, d->W, d->H / 2,
+                     d->W / 2, -1, 0, P);
   hipLaunchKernelGGL(wino_gy_kernel, dim3(sg_cdiv(P * M, 256)), dim3(256), 0, s, gy, Yt, d->N, M, d->H, d->W);
   wino_bgemm(Yt, Vp, T, M, C, (int)P, 2.0 * M * (double)C * 16.0 * P, s);
   hipLaunchKernelGGL(wino_wgrad_output_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, (const float*)T, gw, M, C);
@@ -1782,20 +1835,6 @@ int run_dense(const A64& a64, const B64& b64, const A32& a32, const B128& b128, 
   return launch_cfg<Cfg64>(a64, b64, ep, M, N, K, 1, s);
 }
 }  // namespace
-
-// probe (not part of the ABI): batched dense GEMM C[m][b*P+p] = sum_k A[b][m][k] * B[b*P+p][k]
-extern "C" int sg_probe_bgemm(const float* A, const float* B, float* C, int M, int K, int P, int nb, int tile, sgStream stream) {
-  hipStream_t s = (hipStream_t)stream;
-  EpRowMajor ep{C, nullptr, M, nb * P, nb * P, SG_ACT_NONE, 0.f, 0};
-  t_batch = BatchInfo{P, nb, nullptr, M * K, 0};
-  if (tile == 0)
-    launch_cfg<Cfg128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, nb * P}, ep, M, nb * P, K, 1, s);
-  else
-    launch_cfg<Cfg64>(LoadKContig<64, true, false>{A, K, M}, LoadKContig<64, true, false>{B, K, nb * P}, ep, M, nb * P, K, 1, s);
-  t_batch = BatchInfo{0, 0, nullptr, 0, 0};
-  SG_LAUNCH_CHECK("sg_probe_bgemm");
-  return 0;
-}
 
 extern "C" int sg_linear_fwd(const float* x, const float* w, const float* b, float* y, int rows, int in_f, int out_f,
                              int act, float slope, sgStream stream) {

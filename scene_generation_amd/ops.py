@@ -153,6 +153,11 @@ class Conv2dFn(Function):
             folded = x2 is None and _L().sg_conv2d_dgrad_folded_supported(ctypes.byref(d))
 
             def dgrad(c0, c1):
+                if ctx.wino and c0 == 0 and c1 == d.C1:     # Winograd on the padded gradient grid + reflection fold
+                    out = torch.empty(d.N, d.C1, d.H, d.W, dtype=torch.float32, device=dev)
+                    fb = _L().sg_conv2d_wino_ws_bytes(ctypes.byref(d))
+                    _call('sg_conv2d_wino_dgrad', ctypes.byref(d), _p(gy), _p(weight), _p(out), _p(workspace(fb, dev)), fb, s)
+                    return out
                 if folded:       # ReflectionPad(1)+3x3: gradient straight on the H x W grid (no padded grid, no fold pass)
                     out = torch.empty(d.N, c1 - c0, d.H, d.W, dtype=torch.float32, device=dev)
                     fb = _L().sg_conv2d_dgrad_folded_ws_bytes(ctypes.byref(d))
