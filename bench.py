@@ -72,11 +72,13 @@ def main():
             raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node %d bench.py '
                              '--gpus %d ...' % (a.gpus, a.gpus))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback in the product path)'
+    if os.environ.get('SG_SHARE_GPU') == '1':        # debugging aid: every rank on GPU 0 (needs SG_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = 'cuda:%d' % local
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(os.environ.get('SG_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
 
     from scene_generation_amd import ops
     from scene_generation_amd.args import parser
