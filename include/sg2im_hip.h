@@ -66,6 +66,16 @@ int sg_conv2d_fwd(const sgConvDesc* d, const float* x1, const float* x2, const f
  * logical input: Hg = H*upsample + (pad_reflect ? 2*pad : 0).  Fold with sg_pad_upsample_bwd. */
 int sg_conv2d_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, int c_begin, int c_end,
                     void* ws, size_t ws_bytes, sgStream stream);
+/* Same gathers with PER-IMAGE weights wimg / gwimg [N, Cout, L, KS, KS] (position j of image n's list <-> channel
+   chan_list[n][j]): the factored form of a conv over a masks_to_layout() layout, whose channels are linear combinations of
+   the per-object sampled-mask planes (layout = sum_o vecs[o] (x) S_o, reference layout.py:85-86), so
+   conv(layout) = sum_o (sum_c vecs[o][c] W[:, c]) * S_o: the "channels" become the <= 9 objects of the image. */
+int sg_conv2d_fwd_perimage(const sgConvDesc* d, const float* x1, const float* x2, const float* wimg, const float* bias,
+                           const int32_t* chan_list, const int32_t* chan_cnt, int L, float* y, int act, float slope,
+                           void* ws, size_t ws_bytes, sgStream stream);
+int sg_conv2d_wgrad_perimage(const sgConvDesc* d, const float* gy, const float* x1, const float* x2,
+                             const int32_t* chan_list, const int32_t* chan_cnt, int L, float* gwimg, void* ws,
+                             size_t ws_bytes, sgStream stream);
 /* Data gradient w.r.t. the ACTUAL [N, c_end-c_begin, H, W] input of ReflectionPad2d(1) + 3x3 stride-1 conv (the
    ResnetBlock convs, reference layers.py:251-270): the reflection fold is applied to gy (one pre-folded copy per tap)
    instead of computing the gradient on the padded (H+2)x(W+2) grid and folding it with sg_pad_upsample_bwd. */

@@ -780,7 +780,9 @@ inline int pick_tile(int M, int N) {
 
 // thread-local launch modifiers (set by the sparse entry points around a regular dispatch)
 thread_local BatchInfo t_batch = {0, 0, nullptr, 0, 0};
-struct Sparse { const int* list; const int* cnt; int L; };   // per-image ascending active-channel lists
+// per-image ascending active-channel lists; wimg / gwimg (optional): per-image weights [N][M][L][KS2] in list order instead
+// of one shared weight tensor (factored layout convs: the channels are the objects of the image)
+struct Sparse { const int* list; const int* cnt; int L; const float* wimg; float* gwimg; };
 thread_local unsigned t_variant_stride = 0;   // >0: tap t of the k-table reads from source copy t (see reflect_variants_kernel)
 thread_local int t_fixed_kchunk = 0;        // >0: grid.z = ceil(K / chunk) with exactly this chunk (one image per z)
 
@@ -983,14 +985,16 @@ int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* b
 // runs in batched mode (tiles never straddle images).
 __global__ void build_sparse_fwd_kernel(const float* W, int M, int K, int KS2, int C1, int C2, unsigned shw, int bcast2,
                                         const int* list, const int* cnt, int L, int Kc, int Kpad, float* Wc,
-                                        KEntry* ktab, int* kcnt, int tail_valid) {
+                                        KEntry* ktab, int* kcnt, int tail_valid, const float* Wimg) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = cnt[b];
   if (i < M * Kc) {
     const int m = i / Kc, k = i - m * Kc;
     const int j = k / KS2, t = k - j * KS2;
-    Wc[((size_t)b * M + m) * Kc + k] = j < n ? W[(size_t)m * K + list[b * L + j] * KS2 + t] : 0.f;
+    float v = 0.f;
+    if (j < n) v = Wimg ? Wimg[(((size_t)b * M + m) * L + j) * KS2 + t] : W[(size_t)m * K + list[b * L + j] * KS2 + t];
+    Wc[((size_t)b * M + m) * Kc + k] = v;
   }
   if (i < Kpad) {
     const int j = i / KS2, t = i - j * KS2;
@@ -1030,7 +1034,8 @@ int run_kn_sparse(const float* W, int M, int K, const Gather& g, int NB, const f
   {
     const int work = M * Kc > Kpad ? M * Kc : Kpad;
     hipLaunchKernelGGL(build_sparse_fwd_kernel, dim3(sg_cdiv(work, 256), NB), dim3(256), 0, s, W, M, K, KS2, g.C1, g.C2,
-                       (unsigned)(g.SH * g.SW), g.bcast2, sp.list, sp.cnt, sp.L, Kc, Kpad, Wc, ktab, kcnt, nomask ? 1 : 0);
+                       (unsigned)(g.SH * g.SW), g.bcast2, sp.list, sp.cnt, sp.L, Kc, Kpad, Wc, ktab, kcnt, nomask ? 1 : 0,
+                       sp.wimg);
   }
   EpNCHW ep{out, bias, PHW, M, M, Npix, act, slope, 0, 0, 1, 0, 0, 0, 0};
   // flops actually issued: the padded compact K of every image (bench.py prices the dominant kernel with this)
@@ -1167,6 +1172,17 @@ __global__ void sparse_wgrad_reduce_kernel(const float* slabs, const int* inv, f
   }
   gw[i] = v;
 }
+// gwimg[b][m][j][t] = slab[b][m][t][j] (per-image weight gradients of a factored layout conv; zero beyond the image's list)
+__global__ void sparse_wgrad_perimage_kernel(const float* slabs, const int* cnt, float* gwimg, int M, int L, int KS2, int cpad,
+                                             int NB) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)NB * M * L * KS2) return;
+  const int t = (int)(i % KS2);
+  const int j = (int)((i / KS2) % L);
+  const size_t bm = i / ((size_t)KS2 * L);
+  const int b = (int)(bm / M);
+  gwimg[i] = j < cnt[b] ? slabs[(bm * KS2 + t) * cpad + j] : 0.f;
+}
 // gw[m][c][t] = sum_z slab[z][m][t][c]: un-permutes the tap-major slabs of the weight-gradient GEMM (the GEMM epilogue
 // writes them coalesced; scattering 4-byte stores at stride KS2*4 from there cost 8x write amplification in HBM)
 __global__ void wgrad_unpermute_reduce_kernel(const float* slabs, float* gw, int M, int C, int KS2, int cpad, int S) {
@@ -1290,6 +1306,12 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
   }
   t_fixed_kchunk = 0;
   const size_t nout = (size_t)M * C * KS2;
+  if (sp && sp->gwimg) {
+    const size_t n = (size_t)NB * M * sp->L * KS2;
+    hipLaunchKernelGGL(sparse_wgrad_perimage_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, s, (const float*)ws, sp->cnt,
+                       sp->gwimg, M, sp->L, KS2, pl.cpad, NB);
+    return 0;
+  }
   if (sp) {
     int* inv = reinterpret_cast<int*>(reinterpret_cast<float*>(ws) + (size_t)NB * mn);
     hipLaunchKernelGGL(sparse_inv_kernel, dim3(sg_cdiv(C, 256), NB), dim3(256), 0, s, sp->list, sp->cnt, sp->L, C, inv);
@@ -1486,7 +1508,7 @@ extern "C" int sg_conv2d_fwd_sparse(const sgConvDesc* d, const float* x1, const 
   const int K = (d->C1 + d->C2) * d->KS * d->KS;
   Gather g = make_gather(x1, x2, d->C1, d->C2, d->H, d->W, d->upsample, d->OH, d->OW, d->stride, d->pad, d->pad_reflect);
   g.bcast2 = d->x2_broadcast;
-  const Sparse sp{chan_list, chan_cnt, L};
+  const Sparse sp{chan_list, chan_cnt, L, nullptr, nullptr};
   int rc = -1;
   switch (d->KS) {
     case 1: rc = run_kn_sparse<1>(w, d->Cout, K, g, d->N, bias, y, act, slope, sp, ws, s); break;
@@ -1507,12 +1529,51 @@ extern "C" int sg_conv2d_wgrad_sparse(const sgConvDesc* d, const float* gy, cons
   hipStream_t s = (hipStream_t)stream;
   Gather g = make_gather(x1, x2, d->C1, d->C2, d->H, d->W, d->upsample, d->OH, d->OW, d->stride, d->pad, d->pad_reflect);
   g.bcast2 = d->x2_broadcast;
-  const Sparse sp{chan_list, chan_cnt, L};
+  const Sparse sp{chan_list, chan_cnt, L, nullptr, nullptr};
   if (int rc = run_nk_ks(d->KS, gy, d->Cout, d->Cout, g, d->N, gw, ws, ws_bytes, 0.0, s, &sp)) return rc;
   SG_LAUNCH_CHECK("sg_conv2d_wgrad_sparse");
   if (gb) return sg_channel_sum(gy, gb, d->N, d->Cout, d->OH * d->OW, ws, ws_bytes, stream);
   return 0;
 }
+// ---- per-image weights (factored layout convs) ---------------------------------------------------------------
+extern "C" int sg_conv2d_fwd_perimage(const sgConvDesc* d, const float* x1, const float* x2, const float* wimg,
+                                      const float* bias, const int32_t* chan_list, const int32_t* chan_cnt, int L, float* y,
+                                      int act, float slope, void* ws, size_t ws_bytes, sgStream stream) {
+  if (check_desc(d, "sg_conv2d_fwd_perimage") || check_sparse(d, chan_list, chan_cnt, L, "sg_conv2d_fwd_perimage")) return -1;
+  SG_ARG_CHECK(x1 && wimg && y && ws, "sg_conv2d_fwd_perimage: null pointer");
+  SG_ARG_CHECK(d->C2 == 0 || x2, "sg_conv2d_fwd_perimage: C2>0 but x2 null");
+  SG_ARG_CHECK(ws_bytes >= sg_conv2d_sparse_ws_bytes(d, L, 0), "sg_conv2d_fwd_perimage: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int K = (d->C1 + d->C2) * d->KS * d->KS;
+  Gather g = make_gather(x1, x2, d->C1, d->C2, d->H, d->W, d->upsample, d->OH, d->OW, d->stride, d->pad, d->pad_reflect);
+  g.bcast2 = d->x2_broadcast;
+  const Sparse sp{chan_list, chan_cnt, L, wimg, nullptr};
+  int rc = -1;
+  switch (d->KS) {
+    case 1: rc = run_kn_sparse<1>(nullptr, d->Cout, K, g, d->N, bias, y, act, slope, sp, ws, s); break;
+    case 3: rc = run_kn_sparse<3>(nullptr, d->Cout, K, g, d->N, bias, y, act, slope, sp, ws, s); break;
+    case 4: rc = run_kn_sparse<4>(nullptr, d->Cout, K, g, d->N, bias, y, act, slope, sp, ws, s); break;
+    case 7: rc = run_kn_sparse<7>(nullptr, d->Cout, K, g, d->N, bias, y, act, slope, sp, ws, s); break;
+  }
+  SG_LAUNCH_CHECK("sg_conv2d_fwd_perimage");
+  return rc;
+}
+extern "C" int sg_conv2d_wgrad_perimage(const sgConvDesc* d, const float* gy, const float* x1, const float* x2,
+                                        const int32_t* chan_list, const int32_t* chan_cnt, int L, float* gwimg, void* ws,
+                                        size_t ws_bytes, sgStream stream) {
+  if (check_desc(d, "sg_conv2d_wgrad_perimage") || check_sparse(d, chan_list, chan_cnt, L, "sg_conv2d_wgrad_perimage")) return -1;
+  SG_ARG_CHECK(gy && x1 && gwimg && ws, "sg_conv2d_wgrad_perimage: null pointer");
+  SG_ARG_CHECK(d->C2 == 0 || x2, "sg_conv2d_wgrad_perimage: C2>0 but x2 null");
+  SG_ARG_CHECK(ws_bytes >= sg_conv2d_sparse_ws_bytes(d, L, 2), "sg_conv2d_wgrad_perimage: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  Gather g = make_gather(x1, x2, d->C1, d->C2, d->H, d->W, d->upsample, d->OH, d->OW, d->stride, d->pad, d->pad_reflect);
+  g.bcast2 = d->x2_broadcast;
+  const Sparse sp{chan_list, chan_cnt, L, nullptr, gwimg};
+  if (int rc = run_nk_ks(d->KS, gy, d->Cout, d->Cout, g, d->N, nullptr, ws, ws_bytes, 0.0, s, &sp)) return rc;
+  SG_LAUNCH_CHECK("sg_conv2d_wgrad_perimage");
+  return 0;
+}
+
 extern "C" int sg_convT2d_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y,
                               void* ws, size_t ws_bytes, sgStream stream) {
   if (check_desc(d, "sg_convT2d_fwd")) return -1;

@@ -118,6 +118,20 @@ class Model(nn.Module):
         for lay in (gt_layout, pred_layout, wrong_layout):
             lay._sg_sparse = sparse
             lay._sg_sparse_cat = {3: sparse_img}
+        if ops.FACTORED_LAYOUT:
+            # factored form of the two layouts that feed convolutions: planes S_o + per-object vectors (ops.FactoredLayout)
+            counts = [0] * N
+            plane = []
+            for i in o2i_h:
+                plane.append(counts[i])
+                counts[i] += 1
+            pidx = torch.tensor(plane, dtype=torch.int64).to(dev, non_blocking=True)
+            Z = ops.layout_planes(boxes_gt, masks_gt, ops.segment_offsets(obj_to_img, N), pidx, N, max(counts), H, W)
+            R = self.rep_size
+            gt_layout._sg_factored = ops.FactoredLayout(Z, objs, scene_layout_vecs[:, self.num_objs:], self.num_objs,
+                                                        obj_to_img, pidx, counts)
+            wrong_layout._sg_factored = ops.FactoredLayout(Z, objs, wrong_layout_vecs[:, self.num_objs:].detach(),
+                                                           self.num_objs, obj_to_img, pidx, counts)
         imgs_pred = self.layout_to_image(gt_layout)
         return imgs_pred, boxes_pred, masks_pred, gt_layout, pred_layout, wrong_layout
 

@@ -221,6 +221,8 @@ class Conv2dFn(Function):
 
 # Winograd F(2x2,3x3) for the ResnetBlock convs (SG_WINOGRAD=0 keeps them on the direct implicit-GEMM kernels)
 WINOGRAD = os.environ.get('SG_WINOGRAD', '1') != '0'
+# convs over a masks_to_layout() layout computed from its factored form (SG_FACTORED_LAYOUT=0: channel-sparse path instead)
+FACTORED_LAYOUT = os.environ.get('SG_FACTORED_LAYOUT', '1') != '0'
 
 _SKIP_PARAM_GRADS = set()
 
@@ -242,7 +244,7 @@ def _wants_grad(t):
     return t is not None and t.data_ptr() not in _SKIP_PARAM_GRADS
 
 
-_HINTS = ('_sg_sparse', '_sg_sparse_cat', '_sg_grad_from')
+_HINTS = ('_sg_sparse', '_sg_sparse_cat', '_sg_grad_from', '_sg_factored')
 
 
 def carry_hints(src, dst, grad_from=False):
@@ -255,7 +257,10 @@ def carry_hints(src, dst, grad_from=False):
 
 
 def detach_keep(t):
-    return carry_hints(t, t.detach(), grad_from=True)
+    d = carry_hints(t, t.detach(), grad_from=True)
+    if hasattr(d, '_sg_factored'):
+        d._sg_factored = d._sg_factored.detached()       # no gradient reaches the appearance vectors through it either
+    return d
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, upsample=1, act=ACT_NONE, slope=0.0, x2=None):
@@ -263,6 +268,9 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, upsample=1, act
     only computed for channels >= c (the rest is returned as zeros).  ``x._sg_sparse = (chan_list, chan_cnt)`` (set by the
     model next to the layout) promises that, per image, every channel outside the list is all-zero: forward and weight
     gradient then only visit the listed channels (sg_conv2d_*_sparse)."""
+    f = getattr(x, '_sg_factored', None) if FACTORED_LAYOUT else None
+    if f is not None and upsample == 1 and (x2 is None or (x2.dim() == 4 and not reflect)):
+        return factored_layout_conv(f, weight, bias, stride, pad, reflect, act, slope, x2)
     grad_from = int(getattr(x, '_sg_grad_from', 0))
     if not (0 < grad_from < x.size(1)):
         grad_from = 0
@@ -811,6 +819,146 @@ def masks_to_layout_test(vecs, boxes, masks, seg_off, N, H, W, avg):
     _call('sg_masks_to_layout_test_fwd', _p(vecs), _p(boxes), _p(masks), 1 if masks.dtype == torch.int64 else 0, _p(seg_off),
           _p(out), _p(ws), wsb, N, O, D, masks.size(1), H, W, 1 if avg else 0, _stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------
+# factored layout convolutions
+# ------------------------------------------------------------------------------------------
+def layout_planes(boxes, masks, seg_off, plane_idx, N, J, H, W):
+    """Z [N, J, H, W]: the sampled mask S_o of the j-th object of every image (the spatial factor of masks_to_layout) =
+    masks_to_layout with the vectors one_hot(plane index of o): the same fused kernel, D = J channels."""
+    with torch.no_grad():
+        sel = one_hot(plane_idx, J)
+        return MasksToLayoutFn.apply(sel, boxes.detach(), masks.detach(), seg_off, N, H, W, False, 0, J)
+
+
+class FactoredLayout(object):
+    """layout = sum_o vecs[o] (x) S_o with vecs[o] = [one_hot(class_o) | repr_o] (model.py:165-168, layout.py:85-86), kept in
+    factored form: Z [N, J, H, W] (planes S_o per image), the class ids, the appearance vectors and where object o sits
+    (image, plane).  A conv over the layout is then a conv over <= J planes with per-image weights
+    W_eff[o] = W[:, class_o] + sum_d repr[o, d] W[:, num_objs + d] -- 204 -> <= 9 "channels"."""
+
+    def __init__(self, Z, objs, repr_vecs, num_objs, img_idx, plane_idx, counts_host):
+        self.Z, self.objs, self.repr, self.num_objs = Z, objs, repr_vecs, int(num_objs)
+        self.img_idx, self.plane_idx = img_idx, plane_idx          # int64 [O] on the device
+        self.counts_host = list(counts_host)                       # objects per image (host ints)
+        self._lists = {}
+
+    def detached(self):
+        f = FactoredLayout(self.Z, self.objs, self.repr.detach(), self.num_objs, self.img_idx, self.plane_idx,
+                           self.counts_host)
+        f._lists = self._lists
+        return f
+
+    def with_planes(self, Z):
+        f = FactoredLayout(Z, self.objs, self.repr, self.num_objs, self.img_idx, self.plane_idx, self.counts_host)
+        f._lists = self._lists
+        return f
+
+    def lists(self, extra):
+        """(chan_list [N, L], chan_cnt [N], extra_pos [N, extra]) for the gather: the image's planes, then ``extra``
+        channels of a concatenated second source (they sit at channel ids J.. and list positions cnt[n]..)"""
+        key = int(extra)
+        if key not in self._lists:
+            import numpy as np
+            N, J = self.Z.size(0), self.Z.size(1)
+            L = max(self.counts_host) + key
+            cl = np.zeros((N, L), dtype=np.int32)
+            cc = np.zeros((N,), dtype=np.int32)
+            ep = np.zeros((N, max(key, 1)), dtype=np.int64)
+            for n, c in enumerate(self.counts_host):
+                ch = list(range(c)) + [J + i for i in range(key)]
+                cl[n, :len(ch)] = ch
+                cl[n, len(ch):] = ch[0]
+                cc[n] = len(ch)
+                ep[n, :key] = [c + i for i in range(key)]
+            dev = self.Z.device
+            self._lists[key] = (torch.from_numpy(cl).to(dev), torch.from_numpy(cc).to(dev), torch.from_numpy(ep).to(dev), L)
+        return self._lists[key]
+
+
+class PerImageConvFn(Function):
+    """conv over planes with per-image weights wimg [N, Cout, L, KS, KS] (sg_conv2d_fwd_perimage / _wgrad_perimage).
+    The planes are constants (sampled masks); a channel-concatenated second source ``x2`` (the image next to the layout in
+    the image discriminator) gets its data gradient from the shared weights ``w_full`` [Cout, Cfull + C2, KS, KS]."""
+
+    @staticmethod
+    def forward(ctx, Z, x2, wimg, bias, clist, ccnt, w_full, cfull, stride, pad, reflect, act, slope):
+        Z = _f32(Z, 'planes')
+        x2 = None if x2 is None else _f32(x2, 'conv input 2')
+        wimg = _f32(wimg, 'per-image weights')
+        N, J, H, W = Z.shape
+        C2 = 0 if x2 is None else x2.size(1)
+        Cout, L, KS = wimg.size(1), wimg.size(2), wimg.size(3)
+        OH, OW = conv_out_size(H, KS, stride, pad, 1), conv_out_size(W, KS, stride, pad, 1)
+        d = _conv_desc(N, J, C2, H, W, Cout, KS, stride, pad, reflect, 1, OH, OW, 0, 0)
+        y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=Z.device)
+        wsb = _L().sg_conv2d_sparse_ws_bytes(ctypes.byref(d), L, 0)
+        _call('sg_conv2d_fwd_perimage', ctypes.byref(d), _p(Z), _p(x2), _p(wimg), _p(bias), _p(clist), _p(ccnt), L, _p(y),
+              act, slope, _p(workspace(wsb, Z.device)), wsb, _stream())
+        ctx.desc, ctx.L = d, L
+        ctx.cfg = (act, slope, bias is not None, int(cfull), stride, pad, reflect)
+        ctx.save_for_backward(Z, x2, clist, ccnt, w_full, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        Z, x2, clist, ccnt, w_full, y = ctx.saved_tensors
+        d, L = ctx.desc, ctx.L
+        act, slope, has_bias, cfull, stride, pad, reflect = ctx.cfg
+        gy = _f32(gy)
+        s, dev = _stream(), gy.device
+        if act != ACT_NONE:
+            g2 = torch.empty_like(gy)
+            _call('sg_act_bwd', _p(y), _p(gy), _p(g2), gy.numel(), act, slope, s)
+            gy = g2
+        gx2 = gwimg = gb = None
+        if ctx.needs_input_grad[2]:
+            gwimg = torch.empty(d.N, d.Cout, L, d.KS, d.KS, dtype=torch.float32, device=dev)
+            wsb = _L().sg_conv2d_sparse_ws_bytes(ctypes.byref(d), L, 2)
+            _call('sg_conv2d_wgrad_perimage', ctypes.byref(d), _p(gy), _p(Z), _p(x2), _p(clist), _p(ccnt), L, _p(gwimg),
+                  _p(workspace(wsb, dev)), wsb, s)
+        if has_bias and ctx.needs_input_grad[3]:
+            gb = torch.empty(d.Cout, dtype=torch.float32, device=dev)
+            wsb = _L().sg_channel_sum_ws_bytes(d.Cout)
+            _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(workspace(wsb, dev)), wsb, s)
+        if x2 is not None and ctx.needs_input_grad[1]:
+            # same conv seen with its full channel layout [layout channels | x2]: only the x2 slice is differentiated
+            df = _conv_desc(d.N, cfull, d.C2, d.H, d.W, d.Cout, d.KS, stride, pad, reflect, 1, d.OH, d.OW, 0, 0)
+            wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(df), 1)
+            if reflect:
+                raise NotImplementedError('factored layout conv: x2 gradient with reflection padding')
+            gx2 = torch.empty(d.N, d.C2, d.H, d.W, dtype=torch.float32, device=dev)
+            _call('sg_conv2d_dgrad', ctypes.byref(df), _p(gy), _p(_f32(w_full)), _p(gx2), cfull, cfull + d.C2,
+                  _p(workspace(wsb, dev)), wsb, s)
+        return None, gx2, gwimg, gb, None, None, None, None, None, None, None, None, None
+
+
+def factored_layout_conv(f, weight, bias, stride, pad, reflect, act, slope, x2):
+    """conv2d([layout | x2], weight) computed from the factored layout ``f`` (see FactoredLayout)."""
+    M, Ctot, KS, _ = weight.shape
+    KS2 = KS * KS
+    R = f.repr.size(1)
+    cfull = f.num_objs + R
+    C2 = 0 if x2 is None else x2.size(1)
+    assert Ctot == cfull + C2, 'weight has %d input channels, layout %d + second source %d' % (Ctot, cfull, C2)
+    N = f.Z.size(0)
+    clist, ccnt, extra_pos, L = f.lists(C2)
+    # per-object filters  W_eff[o] = W[:, class_o] + sum_d repr[o, d] W[:, num_objs + d]      -> [O, M * KS2]
+    table = weight[:, :f.num_objs].permute(1, 0, 2, 3).reshape(f.num_objs, M * KS2).contiguous()
+    w_rep = weight[:, f.num_objs:cfull].permute(0, 2, 3, 1).reshape(M * KS2, R)
+    w_eff = embedding(table, f.objs) + linear(f.repr.contiguous(), w_rep.contiguous())
+    rows, cols, vals = f.img_idx, f.plane_idx, w_eff.view(-1, M, KS2)
+    if C2:
+        w_x2 = weight[:, cfull:].permute(1, 0, 2, 3).reshape(1, C2, M, KS2).expand(N, C2, M, KS2)
+        rows = torch.cat([rows, torch.arange(N, device=rows.device).repeat_interleave(C2)])
+        cols = torch.cat([cols, extra_pos[:, :C2].reshape(-1)])
+        vals = torch.cat([vals, w_x2.reshape(N * C2, M, KS2)])
+    wimg = torch.zeros(N, L, M, KS2, dtype=torch.float32, device=weight.device).index_put((rows, cols), vals)
+    wimg = wimg.permute(0, 2, 1, 3).reshape(N, M, L, KS, KS).contiguous()
+    return PerImageConvFn.apply(f.Z, x2, wimg, bias, clist, ccnt, weight.detach(), cfull, stride, pad, reflect, act,
+                                float(slope))
+
 
 
 class CropBBoxFn(Function):

@@ -172,6 +172,42 @@ def test_conv2d_channel_sparse(hip, N, C, dense, H, Cout, KS, stride, pad, refle
     close(bg.grad, br.grad, 5e-5, 'gb')
 
 
+@pytest.mark.parametrize('KS,stride,pad,reflect,C2,H', [(7, 1, 3, True, 0, 32), (4, 2, 2, False, 3, 32), (3, 1, 1, False, 0, 16),
+                                                       (4, 2, 2, False, 3, 17), (7, 1, 3, True, 0, 64)])
+def test_factored_layout_conv_matches_dense(hip, KS, stride, pad, reflect, C2, H):
+    """conv over a masks_to_layout() layout computed from its factored form (planes S_o + per-object filters) == the dense
+    conv over the materialised layout: outputs, weight / bias / appearance-vector / second-source gradients."""
+    from scene_generation_amd.layout import masks_to_layout
+    num_objs, R, Cout = 14, 6, (64 if H == 64 else 16)
+    b = make_batch(N=4, min_objs=2, max_objs=6, size=H, mask_size=8, num_objs=num_objs, seed=21)
+    O_ = b.objs.numel()
+    objs, o2i = b.objs.to(DEV), b.obj_to_img.to(DEV)
+    rep0 = det((O_, R), 91).abs()
+    w0, b0 = det((Cout, num_objs + R + C2, KS, KS), 92, 0.2), det((Cout,), 93, 0.2)
+    x20 = det((4, C2, H, H), 94) if C2 else None
+    outs = []
+    for factored in (False, True):
+        rep = rep0.to(DEV).requires_grad_()
+        w, bias = w0.to(DEV).requires_grad_(), b0.to(DEV).requires_grad_()
+        x2 = x20.to(DEV).requires_grad_() if C2 else None
+        vecs = hip.concat_cols(hip.one_hot(objs, num_objs), rep)
+        layout = masks_to_layout(vecs, b.boxes.to(DEV), b.masks.to(DEV), o2i, H, num_images=4, validate=False)
+        if factored:
+            counts, plane = [0] * 4, []
+            for i in b.obj_to_img.tolist():
+                plane.append(counts[i]); counts[i] += 1
+            pidx = torch.tensor(plane, device=DEV)
+            Z = hip.layout_planes(b.boxes.to(DEV), b.masks.to(DEV), hip.segment_offsets(o2i, 4), pidx, 4, max(counts), H, H)
+            layout._sg_factored = hip.FactoredLayout(Z, objs, vecs[:, num_objs:], num_objs, o2i, pidx, counts)
+        y = hip.conv2d(layout, w, bias, stride=stride, pad=pad, reflect=reflect, act=2, slope=0.2, x2=x2)
+        (y * det(tuple(y.shape), 95).to(DEV)).sum().backward()
+        outs.append((y.detach(), w.grad, bias.grad, rep.grad, None if x2 is None else x2.grad))
+    names = ['y', 'gw', 'gb', 'g_repr', 'g_x2']
+    for nme, a, r in zip(names, outs[1], outs[0]):
+        if r is not None:
+            close(a, r.cpu(), 1e-4, nme)
+
+
 def test_conv2d_broadcast_second_source(hip):
     """mask-D: one-hot class map broadcast over the grid == expand()+cat() of discriminators.py:107-110."""
     N, C1, C2, H = 6, 16, 12, 8
