@@ -380,7 +380,8 @@ __device__ __forceinline__ int axis_offset(int a, int k, int L, int reflect, int
 template <int BN, int KS, bool TWO, bool MASK = true>
 struct LoadGatherNK {
   Gather g; int Ncols;
-  const int* chan_list; const int* chan_cnt; int L;     // optional per-image active-channel lists (image = blockIdx.z)
+  const int* chan_list; const int* chan_cnt; int L;     // optional per-image active-channel lists
+  int zdiv;                                             // image = blockIdx.z / zdiv (k-chunks per image), 0 == 1
   static constexpr int KS2 = KS * KS;
   // per k-tile LDS table (separable): rowoff[KS][16] (= ih*SW or -1), coloff[KS][16] (= iw or -1), one all -1 row,
   // img1[16], img2[16]
@@ -397,8 +398,9 @@ struct LoadGatherNK {
   __device__ __forceinline__ void init(int n0, int tid, int* lds, int kbeg, int kend) {
     kl_ = tid & 15; nr_ = tid >> 4; tid_ = tid; lds_ = lds; kbeg_ = kbeg; kend_ = kend;
     const unsigned shw = (unsigned)(g.SH * g.SW);
-    const int* list = chan_list ? chan_list + (size_t)blockIdx.z * L : nullptr;
-    const int ncols = chan_list ? chan_cnt[blockIdx.z] * KS2 : Ncols;
+    const int zimg = zdiv > 1 ? blockIdx.z / zdiv : blockIdx.z;
+    const int* list = chan_list ? chan_list + (size_t)zimg * L : nullptr;
+    const int ncols = chan_list ? chan_cnt[zimg] * KS2 : Ncols;
     secmask_ = 0;
 #pragma unroll
     for (int j = 0; j < COLS; ++j) {
@@ -642,7 +644,12 @@ struct EpWgrad {     // tap-major virtual column n = t*cpad + cj  ->  slab[z][m]
 // ------------------------------------------------------------------------------------------------
 // Batched mode (channel-sparse first layers): the N axis is split into `nbatch` images of `cols_per_batch` columns,
 // tiles never straddle images, and each image has its own compact A operand, k-table and K extent.
-struct BatchInfo { int cols_per_batch; int nbatch; const int* kcnt; int a_stride; int b_stride; };
+struct BatchInfo {
+  int cols_per_batch; int nbatch; const int* kcnt; int a_stride; int b_stride;
+  // K = (image, pixel) GEMMs split so that no k-chunk straddles an image: grid.z = image * ksplit + q, chunk q of
+  // image i covers pixels [i*kimg + q*kcs, min((i+1)*kimg, ... + kcs))  (ksplit == 0: plain blockIdx.z * kchunk)
+  int kimg, ksplit, kcs;
+};
 template <class CFG, class AL, class BL, class EP>
 __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int kchunk, BatchInfo bi) {
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, LDA = CFG::LDA, LDB = CFG::LDB;
@@ -665,8 +672,13 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   }
   const int m0 = (bid / tiles_n) * BM;
   int n0 = (bid % tiles_n) * BN;
-  const int kbeg = blockIdx.z * kchunk;
+  int kbeg = blockIdx.z * kchunk;
   int kend = min(K, kbeg + kchunk);
+  if (bi.ksplit > 0) {
+    const int img = blockIdx.z / bi.ksplit, q = blockIdx.z - img * bi.ksplit;
+    kbeg = img * bi.kimg + q * bi.kcs;
+    kend = min((img + 1) * bi.kimg, kbeg + bi.kcs);
+  }
   if (bi.cols_per_batch > 0) {
     const int tn = bid % tiles_n, batch = tn / tiles_pb;
     n0 = batch * bi.cols_per_batch + (tn - batch * tiles_pb) * BN;
@@ -779,11 +791,12 @@ inline int pick_tile(int M, int N) {
 }
 
 // thread-local launch modifiers (set by the sparse entry points around a regular dispatch)
-thread_local BatchInfo t_batch = {0, 0, nullptr, 0, 0};
+thread_local BatchInfo t_batch = {0, 0, nullptr, 0, 0, 0, 0, 0};
 // per-image ascending active-channel lists; wimg / gwimg (optional): per-image weights [N][M][L][KS2] in list order instead
 // of one shared weight tensor (factored layout convs: the channels are the objects of the image)
 struct Sparse { const int* list; const int* cnt; int L; const float* wimg; float* gwimg; };
 thread_local unsigned t_variant_stride = 0;   // >0: tap t of the k-table reads from source copy t (see reflect_variants_kernel)
+thread_local int t_grid_z = 0;                // >0: explicit grid.z (per-image k-chunks, see BatchInfo::ksplit)
 thread_local int t_fixed_kchunk = 0;        // >0: grid.z = ceil(K / chunk) with exactly this chunk (one image per z)
 
 template <class CFG, class AL, class BL, class EP>
@@ -793,7 +806,7 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
   int kchunk = K;
   if (splits > 1) kchunk = sg_cdiv(sg_cdiv(K, splits), CFG::BKT) * CFG::BKT;
   if (t_fixed_kchunk > 0) kchunk = t_fixed_kchunk;
-  dim3 grid(tiles, 1, (splits > 1 || t_fixed_kchunk > 0) ? sg_cdiv(K, kchunk) : 1);
+  dim3 grid(tiles, 1, t_grid_z > 0 ? t_grid_z : ((splits > 1 || t_fixed_kchunk > 0) ? sg_cdiv(K, kchunk) : 1));
   hipLaunchKernelGGL((igemm_kernel<CFG, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, N, K, kchunk, t_batch);
   return 0;
 }
@@ -1172,6 +1185,15 @@ __global__ void sparse_wgrad_reduce_kernel(const float* slabs, const int* inv, f
   }
   gw[i] = v;
 }
+// out[b][i] = sum_q ws[(b*S + q)][i]: k-chunks of one image (fixed order)
+__global__ void slab_group_reduce_kernel(const float* ws, float* out, size_t n, int S, int NB) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * NB) return;
+  const size_t b = i / n, r = i - b * n;
+  float v = 0.f;
+  for (int q = 0; q < S; ++q) v += ws[(b * S + q) * n + r];
+  out[i] = v;
+}
 // gwimg[b][m][j][t] = slab[b][m][t][j] (per-image weight gradients of a factored layout conv; zero beyond the image's list)
 __global__ void sparse_wgrad_perimage_kernel(const float* slabs, const int* cnt, float* gwimg, int M, int L, int KS2, int cpad,
                                              int NB) {
@@ -1227,14 +1249,15 @@ inline NkPlan nk_plan(int M, int C, int KS2, int Kpix, bool two) {
 // general (c, tap)-ordered loader: only for few-channel inputs (RGB crops / images)
 template <int KS>
 void launch_nk_general(int tile, const float* A, int M, int Mtot, int PQ, const Gather& g, int Ncols, const EpRowMajor& ep,
-                       int Kpix, int splits, hipStream_t s) {
+                       int Kpix, int splits, hipStream_t s, const Sparse* sp = nullptr, int zdiv = 1) {
   const FastDiv dPQ((unsigned)PQ);
+  const int* sl = sp ? sp->list : nullptr; const int* sc = sp ? sp->cnt : nullptr; const int L = sp ? sp->L : 0;
   if (tile == 2)
-    launch_cfg<Cfg32>(LoadPixK<32>{A, M, Mtot, PQ, dPQ}, LoadGatherNK<128, KS, false>{g, Ncols, nullptr, nullptr, 0}, ep, M,
-                      Ncols, Kpix, splits, s);
+    launch_cfg<Cfg32>(LoadPixK<32>{A, M, Mtot, PQ, dPQ}, LoadGatherNK<128, KS, false>{g, Ncols, sl, sc, L, zdiv}, ep, M, Ncols,
+                      Kpix, splits, s);
   else
-    launch_cfg<Cfg64>(LoadPixK<64>{A, M, Mtot, PQ, dPQ}, LoadGatherNK<64, KS, false>{g, Ncols, nullptr, nullptr, 0}, ep, M,
-                      Ncols, Kpix, splits, s);
+    launch_cfg<Cfg64>(LoadPixK<64>{A, M, Mtot, PQ, dPQ}, LoadGatherNK<64, KS, false>{g, Ncols, sl, sc, L, zdiv}, ep, M, Ncols,
+                      Kpix, splits, s);
 }
 
 template <class CFG, int BMv, int BNv>
@@ -1269,6 +1292,39 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
   const int Ccols = sp ? sp->L : C;
   const int Ncols = Ccols * KS2;
   NkPlan pl = nk_plan(M, Ccols, KS2, Kpix, g.C2 > 0);
+  if (sp && sp->gwimg && g.C2 == 0 && sg_cdiv(Ccols, 64) * 64 >= 3 * Ccols) {
+    // a handful of channels per image (factored layout convs): the tap-major layout would pad every tap to a 64-column
+    // tile; use the (channel, tap)-ordered gather instead, L*KS2 columns, k-chunks inside each image for occupancy
+    const int tile = M <= 32 ? 2 : 1;
+    const long tiles = (long)sg_cdiv(M, tile == 2 ? 32 : 64) * sg_cdiv(Ncols, tile == 2 ? 128 : 64) * NB;
+    int S = (int)((1024 + tiles - 1) / tiles);
+    if (S > 128 / Ccols) S = 128 / Ccols;           // slabs fit the workspace sized for the tap-major path
+    if (S > PQ / 256) S = PQ / 256;
+    if (S < 1) S = 1;
+    const int kcs = sg_cdiv(sg_cdiv(PQ, S), BK) * BK;
+    S = sg_cdiv(PQ, kcs);
+    const size_t mnc = (size_t)M * Ncols;
+    SG_ARG_CHECK(ws && ws_bytes >= mnc * sizeof(float) * (size_t)S * NB, "wgrad: workspace too small");
+    float* dstp = S > 1 ? reinterpret_cast<float*>(ws) : sp->gwimg;
+    const EpRowMajor ep{dstp, nullptr, M, Ncols, Ncols, SG_ACT_NONE, 0.f, mnc};
+    t_batch = BatchInfo{0, 0, nullptr, 0, 0, PQ, S, kcs};
+    t_grid_z = NB * S;
+    {
+      SgProfScope prof(sg_igemm_kind(2, KS, tile), s, 2.0 * M * (double)Ncols * Kpix, 0);
+      switch (KS) {
+        case 1: launch_nk_general<1>(tile, A, M, Mtot, PQ, g, Ncols, ep, Kpix, 1, s, sp, S); break;
+        case 3: launch_nk_general<3>(tile, A, M, Mtot, PQ, g, Ncols, ep, Kpix, 1, s, sp, S); break;
+        case 4: launch_nk_general<4>(tile, A, M, Mtot, PQ, g, Ncols, ep, Kpix, 1, s, sp, S); break;
+        case 7: launch_nk_general<7>(tile, A, M, Mtot, PQ, g, Ncols, ep, Kpix, 1, s, sp, S); break;
+      }
+    }
+    t_batch = BatchInfo{0, 0, nullptr, 0, 0, 0, 0, 0};
+    t_grid_z = 0;
+    if (S > 1)
+      hipLaunchKernelGGL(slab_group_reduce_kernel, dim3(sg_cdiv(mnc * NB, 256)), dim3(256), 0, s, (const float*)ws, sp->gwimg,
+                         mnc, S, NB);
+    return 0;
+  }
   if (sp) pl.tap = true;
   if (sp && pl.cpad == 0) pl.cpad = sg_cdiv(Ccols, pl.tile == 1 ? 64 : 128) * (pl.tile == 1 ? 64 : 128);
   int splits = sp ? NB : pl.splits;

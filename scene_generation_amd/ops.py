@@ -879,33 +879,32 @@ class FactoredLayout(object):
 
 class PerImageConvFn(Function):
     """conv over planes with per-image weights wimg [N, Cout, L, KS, KS] (sg_conv2d_fwd_perimage / _wgrad_perimage).
-    The planes are constants (sampled masks); a channel-concatenated second source ``x2`` (the image next to the layout in
-    the image discriminator) gets its data gradient from the shared weights ``w_full`` [Cout, Cfull + C2, KS, KS]."""
+    ``planes`` = the layout's mask planes, followed by the channels of a concatenated second source ``x2`` when there
+    is one (the image next to the layout in the image discriminator).  The mask planes are constants; ``x2`` gets its data
+    gradient from the shared weights ``w_full`` [Cout, cfull + C2, KS, KS] (it does not depend on the per-image part)."""
 
     @staticmethod
-    def forward(ctx, Z, x2, wimg, bias, clist, ccnt, w_full, cfull, stride, pad, reflect, act, slope):
-        Z = _f32(Z, 'planes')
-        x2 = None if x2 is None else _f32(x2, 'conv input 2')
+    def forward(ctx, planes, x2, wimg, bias, clist, ccnt, w_full, cfull, stride, pad, reflect, act, slope):
+        planes = _f32(planes, 'planes')
         wimg = _f32(wimg, 'per-image weights')
-        N, J, H, W = Z.shape
-        C2 = 0 if x2 is None else x2.size(1)
+        N, J, H, W = planes.shape
         Cout, L, KS = wimg.size(1), wimg.size(2), wimg.size(3)
         OH, OW = conv_out_size(H, KS, stride, pad, 1), conv_out_size(W, KS, stride, pad, 1)
-        d = _conv_desc(N, J, C2, H, W, Cout, KS, stride, pad, reflect, 1, OH, OW, 0, 0)
-        y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=Z.device)
+        d = _conv_desc(N, J, 0, H, W, Cout, KS, stride, pad, reflect, 1, OH, OW, 0, 0)
+        y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=planes.device)
         wsb = _L().sg_conv2d_sparse_ws_bytes(ctypes.byref(d), L, 0)
-        _call('sg_conv2d_fwd_perimage', ctypes.byref(d), _p(Z), _p(x2), _p(wimg), _p(bias), _p(clist), _p(ccnt), L, _p(y),
-              act, slope, _p(workspace(wsb, Z.device)), wsb, _stream())
+        _call('sg_conv2d_fwd_perimage', ctypes.byref(d), _p(planes), None, _p(wimg), _p(bias), _p(clist), _p(ccnt), L, _p(y),
+              act, slope, _p(workspace(wsb, planes.device)), wsb, _stream())
         ctx.desc, ctx.L = d, L
-        ctx.cfg = (act, slope, bias is not None, int(cfull), stride, pad, reflect)
-        ctx.save_for_backward(Z, x2, clist, ccnt, w_full, y if act != ACT_NONE else None)
+        ctx.cfg = (act, slope, bias is not None, int(cfull), 0 if x2 is None else x2.size(1), stride, pad, reflect)
+        ctx.save_for_backward(planes, clist, ccnt, w_full, y if act != ACT_NONE else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        Z, x2, clist, ccnt, w_full, y = ctx.saved_tensors
+        planes, clist, ccnt, w_full, y = ctx.saved_tensors
         d, L = ctx.desc, ctx.L
-        act, slope, has_bias, cfull, stride, pad, reflect = ctx.cfg
+        act, slope, has_bias, cfull, C2, stride, pad, reflect = ctx.cfg
         gy = _f32(gy)
         s, dev = _stream(), gy.device
         if act != ACT_NONE:
@@ -913,23 +912,26 @@ class PerImageConvFn(Function):
             _call('sg_act_bwd', _p(y), _p(gy), _p(g2), gy.numel(), act, slope, s)
             gy = g2
         gx2 = gwimg = gb = None
-        if ctx.needs_input_grad[2]:
+        # skip_param_grads (the discriminators inside the generator step): the per-image weights only carry parameter
+        # gradients when the appearance vectors are detached, which is the case for every discriminator input
+        want_w = _wants_grad(w_full)
+        if ctx.needs_input_grad[2] and want_w:
             gwimg = torch.empty(d.N, d.Cout, L, d.KS, d.KS, dtype=torch.float32, device=dev)
             wsb = _L().sg_conv2d_sparse_ws_bytes(ctypes.byref(d), L, 2)
-            _call('sg_conv2d_wgrad_perimage', ctypes.byref(d), _p(gy), _p(Z), _p(x2), _p(clist), _p(ccnt), L, _p(gwimg),
+            _call('sg_conv2d_wgrad_perimage', ctypes.byref(d), _p(gy), _p(planes), None, _p(clist), _p(ccnt), L, _p(gwimg),
                   _p(workspace(wsb, dev)), wsb, s)
-        if has_bias and ctx.needs_input_grad[3]:
+        if has_bias and ctx.needs_input_grad[3] and want_w:
             gb = torch.empty(d.Cout, dtype=torch.float32, device=dev)
             wsb = _L().sg_channel_sum_ws_bytes(d.Cout)
             _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(workspace(wsb, dev)), wsb, s)
-        if x2 is not None and ctx.needs_input_grad[1]:
+        if C2 and ctx.needs_input_grad[1]:
             # same conv seen with its full channel layout [layout channels | x2]: only the x2 slice is differentiated
-            df = _conv_desc(d.N, cfull, d.C2, d.H, d.W, d.Cout, d.KS, stride, pad, reflect, 1, d.OH, d.OW, 0, 0)
-            wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(df), 1)
             if reflect:
                 raise NotImplementedError('factored layout conv: x2 gradient with reflection padding')
-            gx2 = torch.empty(d.N, d.C2, d.H, d.W, dtype=torch.float32, device=dev)
-            _call('sg_conv2d_dgrad', ctypes.byref(df), _p(gy), _p(_f32(w_full)), _p(gx2), cfull, cfull + d.C2,
+            df = _conv_desc(d.N, cfull, C2, d.H, d.W, d.Cout, d.KS, stride, pad, reflect, 1, d.OH, d.OW, 0, 0)
+            wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(df), 1)
+            gx2 = torch.empty(d.N, C2, d.H, d.W, dtype=torch.float32, device=dev)
+            _call('sg_conv2d_dgrad', ctypes.byref(df), _p(gy), _p(_f32(w_full)), _p(gx2), cfull, cfull + C2,
                   _p(workspace(wsb, dev)), wsb, s)
         return None, gx2, gwimg, gb, None, None, None, None, None, None, None, None, None
 
@@ -956,9 +958,9 @@ def factored_layout_conv(f, weight, bias, stride, pad, reflect, act, slope, x2):
         vals = torch.cat([vals, w_x2.reshape(N * C2, M, KS2)])
     wimg = torch.zeros(N, L, M, KS2, dtype=torch.float32, device=weight.device).index_put((rows, cols), vals)
     wimg = wimg.permute(0, 2, 1, 3).reshape(N, M, L, KS, KS).contiguous()
-    return PerImageConvFn.apply(f.Z, x2, wimg, bias, clist, ccnt, weight.detach(), cfull, stride, pad, reflect, act,
+    planes = f.Z if x2 is None else torch.cat([f.Z, x2.detach()], 1)
+    return PerImageConvFn.apply(planes, x2, wimg, bias, clist, ccnt, weight.detach(), cfull, stride, pad, reflect, act,
                                 float(slope))
-
 
 
 class CropBBoxFn(Function):
