@@ -107,17 +107,18 @@ class Model(nn.Module):
                                       test_mode=False, grad_from_channel=self.num_objs, **kw)
         wrong_layout = masks_to_layout(wrong_layout_vecs, boxes_gt, masks_gt, obj_to_img, H, W, test_mode=False,
                                        grad_from_channel=self.num_objs, **kw)
-        # per image only the one-hot planes of its own classes + the representation block are non-zero: the
-        # generator's first conv (204 -> 64 channels, 7x7, full resolution) skips the rest
         dev = gt_layout.device
-        sparse = tuple(torch.from_numpy(a).to(dev, non_blocking=True)
-                       for a in active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size))
-        # same lists + the 3 image channels the image discriminator concatenates behind the layout
-        sparse_img = tuple(torch.from_numpy(a).to(dev, non_blocking=True)
-                           for a in active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size, extra=3))
-        for lay in (gt_layout, pred_layout, wrong_layout):
-            lay._sg_sparse = sparse
-            lay._sg_sparse_cat = {3: sparse_img}
+        if not ops.FACTORED_LAYOUT:
+            # per image only the one-hot planes of its own classes + the representation block are non-zero: the
+            # generator's first conv (204 -> 64 channels, 7x7, full resolution) skips the rest
+            sparse = tuple(torch.from_numpy(a).to(dev, non_blocking=True)
+                           for a in active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size))
+            # same lists + the 3 image channels the image discriminator concatenates behind the layout
+            sparse_img = tuple(torch.from_numpy(a).to(dev, non_blocking=True)
+                               for a in active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size, extra=3))
+            for lay in (gt_layout, pred_layout, wrong_layout):
+                lay._sg_sparse = sparse
+                lay._sg_sparse_cat = {3: sparse_img}
         if ops.FACTORED_LAYOUT:
             # factored form of the two layouts that feed convolutions: planes S_o + per-object vectors (ops.FactoredLayout)
             counts = [0] * N
@@ -132,6 +133,7 @@ class Model(nn.Module):
                                                         obj_to_img, pidx, counts)
             wrong_layout._sg_factored = ops.FactoredLayout(Z, objs, wrong_layout_vecs[:, self.num_objs:].detach(),
                                                            self.num_objs, obj_to_img, pidx, counts)
+            wrong_layout._sg_factored._lists = gt_layout._sg_factored._lists          # same objects: share the list cache
         imgs_pred = self.layout_to_image(gt_layout)
         return imgs_pred, boxes_pred, masks_pred, gt_layout, pred_layout, wrong_layout
 

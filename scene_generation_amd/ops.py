@@ -24,8 +24,18 @@ def _L():
     return _hip.lib()
 
 
+# raw handle of the current stream without building a torch.cuda.Stream object (this runs once per kernel launch)
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def _stream_handle():
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(_stream_handle())
 
 
 def _p(t):
@@ -55,7 +65,7 @@ def _i64(t, name='index'):
 
 def workspace(nbytes, device):
     """Per-device scratch, grown on demand.  Safe to share: every consumer is ordered on the current stream."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    key = (device.index, _stream_handle())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -63,8 +73,14 @@ def workspace(nbytes, device):
     return buf
 
 
+_fn_cache = {}
+
+
 def _call(name, *args):
-    rc = getattr(_L(), name)(*args)
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(_L(), name)
+    rc = fn(*args)
     if rc != 0:
         raise RuntimeError('%s failed (rc=%d): %s' % (name, rc, _hip.last_error()))
 
