@@ -844,3 +844,55 @@ def test_layout_full_size_properties(hip):
     ones[last] = 1.0
     lim = masks_to_layout(ones, b.boxes, b.masks, b.obj_to_img, 128, **kw)
     close(lim[:, :, 4:-4, 4:-4], torch.ones_like(lim[:, :, 4:-4, 4:-4]), 1e-6, 'image node')
+
+
+@pytest.mark.parametrize('name,N', [('c4', 2), ('c5', 4)])
+def test_step_runs_at_config4_and_config5_shapes(hip, name, N):
+    """BASELINE configs[3] (256x256, <=16 objects) and configs[4] (32 objects / 96 triples per image) per-GPU shapes at
+    full widths: two G+D steps finish with finite losses (Winograd at 16x16 planes, two column blocks in the RGB head,
+    33 object planes in the factored layout convs, the dense-graph scatter)."""
+    from scene_generation_amd.trainer import Trainer
+    from scene_generation_amd.synthetic import make_config_batch
+    b = make_config_batch(name, seed=3, N=N)
+    S = b.imgs.size(-1)
+    args = parser.parse_args(['--image_size', '%d,%d' % (S, S), '--batch_size', str(N), '--vgg_features_weight', '0',
+                              '--output_dir', '/tmp/o'])
+    torch.manual_seed(0)
+    tr = Trainer(args, make_vocab())
+    random.seed(0)
+    for it in range(2):
+        tr.step(batch_to(b, DEV), use_gt=(it == 0))
+    for L in (tr.generator_losses, tr.d_img_losses, tr.d_obj_losses, tr.d_mask_losses):
+        for k, v in L.items():
+            assert v == v and abs(v) < 1e6, (name, k, v)
+
+
+def test_fast_paths_agree_with_plain_paths(hip):
+    """Winograd / factored layout convs / shared D forwards are exact re-formulations: one generator forward + the losses
+    of a full step with every switch off equal the default path to fp32 rounding."""
+    from scene_generation_amd import ops
+    from scene_generation_amd.trainer import Trainer
+    args = parser.parse_args(['--image_size', '64,64', '--batch_size', '4', '--vgg_features_weight', '0', '--output_dir', '/tmp/o'])
+    b = batch_to(make_batch(N=4, min_objs=3, max_objs=6, size=64, seed=9), DEV)
+    res = []
+    saved = (ops.WINOGRAD, ops.FACTORED_LAYOUT)
+    try:
+        for fast in (True, False):
+            ops.WINOGRAD = ops.FACTORED_LAYOUT = fast
+            torch.manual_seed(0)
+            tr = Trainer(args, make_vocab())
+            for m in (tr.model, tr.netD, tr.obj_discriminator, tr.mask_discriminator):
+                fill_deterministic(m)
+            tr.share_d_forward = fast
+            tr.model.noise_override = det((1, 64), 131).to(DEV)
+            random.seed(3)
+            out = tr.step(b, use_gt=True)
+            losses = {}
+            for L in (tr.generator_losses, tr.d_img_losses, tr.d_obj_losses, tr.d_mask_losses):
+                losses.update(dict(L.items()))
+            res.append((out[0].detach().cpu(), losses))
+    finally:
+        ops.WINOGRAD, ops.FACTORED_LAYOUT = saved
+    close(res[0][0], res[1][0], 2e-4, 'imgs_pred fast vs plain')
+    for k, v in res[1][1].items():
+        assert abs(res[0][1][k] - v) <= 2e-3 * max(1.0, abs(v)), (k, res[0][1][k], v)
