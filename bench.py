@@ -107,6 +107,8 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    issue = [0.0]
+
     def timed(n_steps, first):
         torch.cuda.synchronize()
         if world > 1:
@@ -115,6 +117,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(n_steps):
             one_step(first + i)
+        issue[0] = time.perf_counter() - t0          # host done issuing; the GPU may still be working
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -129,6 +132,7 @@ def main():
     # headline pass: exactly K steps, no per-launch instrumentation (the step issues ~2300 kernels and is within a few
     # percent of being launch-bound: two hipEventRecord per kernel cost ~6 % of the step)
     dt = timed(a.steps, a.warmup)
+    host_issue = issue[0]
     # roofline pass: the SAME K steps again with a HIP event pair around every kernel launch on the launch stream
     dt_prof = None
     if not a.no_prof:
@@ -149,6 +153,8 @@ def main():
                                'widths, VGG loss off' % (S, S, B, ' + RCCL grad all-reduce' if world > 1 else ''),
                    'global_batch': B * world, 'image_size': S, 'parallelism': 'dp%d' % world,
                    'share_d_forward': not a.no_share_d_forward},
+        # wall time the host needed to ISSUE the K steps (no sync): close to ms_per_step => launch-bound
+        'host_issue_ms_per_step': 1e3 * host_issue / a.steps,
     }
     if rank == 0:
         if not a.no_prof:
