@@ -15,7 +15,7 @@ from .generators import mask_net, AppearanceEncoder, define_G
 from .graph import GraphTripleConv, GraphTripleConvNet
 from .layers import build_mlp, Embedding, Linear
 from .layout import masks_to_layout
-from .utils import VectorPool, active_layout_channels
+from .utils import VectorPool, active_layout_channels, to_device_async
 
 
 class Model(nn.Module):
@@ -97,7 +97,7 @@ class Model(nn.Module):
             pred_layout = masks_to_layout(scene_layout_vecs, boxes, masks, obj_to_img, H, W, test_mode=True,
                                           num_images=N, validate=False)
             pred_layout._sg_sparse = tuple(
-                torch.from_numpy(a).to(pred_layout.device, non_blocking=True)
+                to_device_async(torch.from_numpy(a), pred_layout.device)
                 for a in active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size))
             return self.layout_to_image(pred_layout), boxes_pred, masks_pred, None, pred_layout, None
         gt_layout = masks_to_layout(scene_layout_vecs, boxes_gt, masks_gt, obj_to_img, H, W, test_mode=False,
@@ -111,10 +111,10 @@ class Model(nn.Module):
         if not ops.FACTORED_LAYOUT:
             # per image only the one-hot planes of its own classes + the representation block are non-zero: the
             # generator's first conv (204 -> 64 channels, 7x7, full resolution) skips the rest
-            sparse = tuple(torch.from_numpy(a).to(dev, non_blocking=True)
+            sparse = tuple(to_device_async(torch.from_numpy(a), dev)
                            for a in active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size))
             # same lists + the 3 image channels the image discriminator concatenates behind the layout
-            sparse_img = tuple(torch.from_numpy(a).to(dev, non_blocking=True)
+            sparse_img = tuple(to_device_async(torch.from_numpy(a), dev)
                                for a in active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size, extra=3))
             for lay in (gt_layout, pred_layout, wrong_layout):
                 lay._sg_sparse = sparse
@@ -126,7 +126,7 @@ class Model(nn.Module):
             for i in o2i_h:
                 plane.append(counts[i])
                 counts[i] += 1
-            pidx = torch.tensor(plane, dtype=torch.int64).to(dev, non_blocking=True)
+            pidx = to_device_async(torch.tensor(plane, dtype=torch.int64), dev)
             Z = ops.layout_planes(boxes_gt, masks_gt, ops.segment_offsets(obj_to_img, N), pidx, N, max(counts), H, W)
             R = self.rep_size
             gt_layout._sg_factored = ops.FactoredLayout(Z, objs, scene_layout_vecs[:, self.num_objs:], self.num_objs,

@@ -93,9 +93,29 @@ def conv_out_size(size, k, stride, pad, upsample=1):
     return (size * upsample + 2 * pad - k) // stride + 1
 
 
+_desc_cache = {}
+
+
 def _conv_desc(N, C1, C2, H, W, Cout, KS, stride, pad, reflect, upsample, OH, OW, out_pad=0, x2_broadcast=0):
-    return sgConvDesc(N, C1, C2, H, W, Cout, KS, stride, pad, 1 if reflect else 0, upsample, OH, OW, out_pad,
-                      x2_broadcast)
+    """sgConvDesc for these sizes (one instance per shape: the ctypes reference and every shape-only query of the library
+    -- workspace sizes, which specialised kernels apply -- are memoised on it; a training step repeats ~150 shapes)."""
+    key = (N, C1, C2, H, W, Cout, KS, stride, pad, 1 if reflect else 0, upsample, OH, OW, out_pad, x2_broadcast)
+    d = _desc_cache.get(key)
+    if d is None:
+        d = sgConvDesc(*key)
+        d._ref = ctypes.byref(d)
+        d._memo = {}
+        _desc_cache[key] = d
+    return d
+
+
+def _q(d, name, *extra):
+    """memoised shape-only query ``name(desc, *extra)`` of the library"""
+    key = (name,) + extra
+    v = d._memo.get(key)
+    if v is None:
+        v = d._memo[key] = getattr(_L(), name)(d._ref, *extra)
+    return v
 
 
 class Conv2dFn(Function):
@@ -116,26 +136,26 @@ class Conv2dFn(Function):
         bcast = 1 if (x2 is not None and x2.dim() == 2) else 0      # [N, C2] broadcast over H x W
         d = _conv_desc(N, C1, C2, H, W, Cout, KS, stride, pad, reflect, upsample, OH, OW, 0, bcast)
         y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=x1.device)
-        ctx.smallm = x2 is None and sparse is None and bool(_L().sg_conv2d_smallm_supported(ctypes.byref(d)))
-        ctx.wino = (x2 is None and sparse is None and WINOGRAD and bool(_L().sg_conv2d_wino_supported(ctypes.byref(d))))
+        ctx.smallm = x2 is None and sparse is None and bool(_q(d, 'sg_conv2d_smallm_supported'))
+        ctx.wino = (x2 is None and sparse is None and WINOGRAD and bool(_q(d, 'sg_conv2d_wino_supported')))
         if ctx.wino:                # ResnetBlock convs: Winograd F(2x2,3x3), 16 batched dense GEMMs
-            wsb = _L().sg_conv2d_wino_ws_bytes(ctypes.byref(d))
-            _call('sg_conv2d_wino_fwd', ctypes.byref(d), _p(x1), _p(weight), _p(bias), _p(y), act, slope,
+            wsb = _q(d, 'sg_conv2d_wino_ws_bytes')
+            _call('sg_conv2d_wino_fwd', d._ref, _p(x1), _p(weight), _p(bias), _p(y), act, slope,
                   _p(workspace(wsb, x1.device)), wsb, _stream())
         elif ctx.smallm:              # <= 4 output channels (the RGB head): direct vector-ALU kernel, no MFMA tile waste
-            _call('sg_conv2d_smallm_fwd', ctypes.byref(d), _p(x1), _p(weight), _p(bias), _p(y), act, slope, _stream())
+            _call('sg_conv2d_smallm_fwd', d._ref, _p(x1), _p(weight), _p(bias), _p(y), act, slope, _stream())
         elif sparse is not None:    # (chan_list [N, L] int32, chan_cnt [N] int32): see sg_conv2d_fwd_sparse
             clist, ccnt = sparse
             assert clist.dtype == torch.int32 and ccnt.dtype == torch.int32 and clist.size(0) == N == ccnt.numel()
             L = int(clist.size(1))
-            wsb = _L().sg_conv2d_sparse_ws_bytes(ctypes.byref(d), L, 0)
+            wsb = _q(d, 'sg_conv2d_sparse_ws_bytes', L, 0)
             ws = workspace(wsb, x1.device)
-            _call('sg_conv2d_fwd_sparse', ctypes.byref(d), _p(x1), _p(x2), _p(weight), _p(bias), _p(clist), _p(ccnt), L,
+            _call('sg_conv2d_fwd_sparse', d._ref, _p(x1), _p(x2), _p(weight), _p(bias), _p(clist), _p(ccnt), L,
                   _p(y), act, slope, _p(ws), wsb, _stream())
         else:
-            wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 0)
+            wsb = _q(d, 'sg_conv2d_ws_bytes', 0)
             ws = workspace(wsb, x1.device)
-            _call('sg_conv2d_fwd', ctypes.byref(d), _p(x1), _p(x2), _p(weight), _p(bias), _p(y), act, slope, _p(ws), wsb,
+            _call('sg_conv2d_fwd', d._ref, _p(x1), _p(x2), _p(weight), _p(bias), _p(y), act, slope, _p(ws), wsb,
                   _stream())
         ctx.desc = d
         ctx.sparse = sparse
@@ -160,28 +180,28 @@ class Conv2dFn(Function):
         gx1 = gx2 = gw = gb = None
         dev = gy.device
         if need_x1 or need_x2:
-            wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 1)
+            wsb = _q(d, 'sg_conv2d_ws_bytes', 1)
             ws = workspace(wsb, dev)
             fold = d.pad_reflect or d.upsample == 2
             GH = d.H * d.upsample + (2 * d.pad if d.pad_reflect else 0)
             GW = d.W * d.upsample + (2 * d.pad if d.pad_reflect else 0)
 
-            folded = x2 is None and _L().sg_conv2d_dgrad_folded_supported(ctypes.byref(d))
+            folded = x2 is None and _q(d, 'sg_conv2d_dgrad_folded_supported')
 
             def dgrad(c0, c1):
                 if ctx.wino and c0 == 0 and c1 == d.C1:     # Winograd on the padded gradient grid + reflection fold
                     out = torch.empty(d.N, d.C1, d.H, d.W, dtype=torch.float32, device=dev)
-                    fb = _L().sg_conv2d_wino_ws_bytes(ctypes.byref(d))
-                    _call('sg_conv2d_wino_dgrad', ctypes.byref(d), _p(gy), _p(weight), _p(out), _p(workspace(fb, dev)), fb, s)
+                    fb = _q(d, 'sg_conv2d_wino_ws_bytes')
+                    _call('sg_conv2d_wino_dgrad', d._ref, _p(gy), _p(weight), _p(out), _p(workspace(fb, dev)), fb, s)
                     return out
                 if folded:       # ReflectionPad(1)+3x3: gradient straight on the H x W grid (no padded grid, no fold pass)
                     out = torch.empty(d.N, c1 - c0, d.H, d.W, dtype=torch.float32, device=dev)
-                    fb = _L().sg_conv2d_dgrad_folded_ws_bytes(ctypes.byref(d))
-                    _call('sg_conv2d_dgrad_folded', ctypes.byref(d), _p(gy), _p(weight), _p(out), c0, c1,
+                    fb = _q(d, 'sg_conv2d_dgrad_folded_ws_bytes')
+                    _call('sg_conv2d_dgrad_folded', d._ref, _p(gy), _p(weight), _p(out), c0, c1,
                           _p(workspace(fb, dev)), fb, s)
                     return out
                 g = torch.empty(d.N, c1 - c0, GH, GW, dtype=torch.float32, device=dev)
-                _call('sg_conv2d_dgrad', ctypes.byref(d), _p(gy), _p(weight), _p(g), c0, c1, _p(ws), wsb, s)
+                _call('sg_conv2d_dgrad', d._ref, _p(gy), _p(weight), _p(g), c0, c1, _p(ws), wsb, s)
                 if fold:
                     out = torch.empty(d.N, c1 - c0, d.H, d.W, dtype=torch.float32, device=dev)
                     _call('sg_pad_upsample_bwd', _p(g), _p(out), d.N * (c1 - c0), d.H, d.W,
@@ -205,28 +225,28 @@ class Conv2dFn(Function):
                 gw = torch.empty_like(weight)
                 gb = torch.empty(d.Cout, dtype=torch.float32, device=dev) if need_b else None
                 if ctx.wino:
-                    wsb = max(_L().sg_conv2d_wino_ws_bytes(ctypes.byref(d)), _L().sg_channel_sum_ws_bytes(d.Cout))
+                    wsb = max(_q(d, 'sg_conv2d_wino_ws_bytes'), _L().sg_channel_sum_ws_bytes(d.Cout))
                     ws = workspace(wsb, dev)
-                    _call('sg_conv2d_wino_wgrad', ctypes.byref(d), _p(gy), _p(x1), _p(gw), _p(ws), wsb, s)
+                    _call('sg_conv2d_wino_wgrad', d._ref, _p(gy), _p(x1), _p(gw), _p(ws), wsb, s)
                     if gb is not None:
                         _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb, s)
                 elif ctx.smallm:
-                    wsb = max(_L().sg_conv2d_smallm_ws_bytes(ctypes.byref(d)), _L().sg_channel_sum_ws_bytes(d.Cout))
+                    wsb = max(_q(d, 'sg_conv2d_smallm_ws_bytes'), _L().sg_channel_sum_ws_bytes(d.Cout))
                     ws = workspace(wsb, dev)
-                    _call('sg_conv2d_smallm_wgrad', ctypes.byref(d), _p(gy), _p(x1), _p(gw), _p(ws), wsb, s)
+                    _call('sg_conv2d_smallm_wgrad', d._ref, _p(gy), _p(x1), _p(gw), _p(ws), wsb, s)
                     if gb is not None:
                         _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb, s)
                 elif ctx.sparse is not None:
                     clist, ccnt = ctx.sparse
                     L = int(clist.size(1))
-                    wsb = _L().sg_conv2d_sparse_ws_bytes(ctypes.byref(d), L, 2)
+                    wsb = _q(d, 'sg_conv2d_sparse_ws_bytes', L, 2)
                     ws = workspace(wsb, dev)
-                    _call('sg_conv2d_wgrad_sparse', ctypes.byref(d), _p(gy), _p(x1), _p(x2), _p(clist), _p(ccnt), L,
+                    _call('sg_conv2d_wgrad_sparse', d._ref, _p(gy), _p(x1), _p(x2), _p(clist), _p(ccnt), L,
                           _p(gw), _p(gb), _p(ws), wsb, s)
                 else:
-                    wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 2)
+                    wsb = _q(d, 'sg_conv2d_ws_bytes', 2)
                     ws = workspace(wsb, dev)
-                    _call('sg_conv2d_wgrad', ctypes.byref(d), _p(gy), _p(x1), _p(x2), _p(gw), _p(gb), _p(ws), wsb, s)
+                    _call('sg_conv2d_wgrad', d._ref, _p(gy), _p(x1), _p(x2), _p(gw), _p(gb), _p(ws), wsb, s)
             else:
                 gb = torch.empty(d.Cout, dtype=torch.float32, device=dev)
                 wsb = _L().sg_channel_sum_ws_bytes(d.Cout)
@@ -313,9 +333,9 @@ class ConvTranspose2dFn(Function):
         OW = (W - 1) * stride - 2 * pad + KS + out_pad
         d = _conv_desc(N, Cin, 0, H, W, Cout, KS, stride, pad, False, 1, OH, OW, out_pad)
         y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=x.device)
-        wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 0)
+        wsb = _q(d, 'sg_conv2d_ws_bytes', 0)
         ws = workspace(wsb, x.device)
-        _call('sg_convT2d_fwd', ctypes.byref(d), _p(x), _p(weight), _p(bias), _p(y), _p(ws), wsb, _stream())
+        _call('sg_convT2d_fwd', d._ref, _p(x), _p(weight), _p(bias), _p(y), _p(ws), wsb, _stream())
         ctx.desc = d
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight)
@@ -330,16 +350,16 @@ class ConvTranspose2dFn(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 1)
+            wsb = _q(d, 'sg_conv2d_ws_bytes', 1)
             ws = workspace(wsb, gy.device)
-            _call('sg_convT2d_dgrad', ctypes.byref(d), _p(gy), _p(weight), _p(gx), _p(ws), wsb, s)
+            _call('sg_convT2d_dgrad', d._ref, _p(gy), _p(weight), _p(gx), _p(ws), wsb, s)
         need_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(d), 2)
+            wsb = _q(d, 'sg_conv2d_ws_bytes', 2)
             ws = workspace(wsb, gy.device)
             gw = torch.empty_like(weight)
             gb = torch.empty(d.Cout, dtype=torch.float32, device=gy.device) if need_b else None
-            _call('sg_convT2d_wgrad', ctypes.byref(d), _p(gy), _p(x), _p(gw), _p(gb), _p(ws), wsb, s)
+            _call('sg_convT2d_wgrad', d._ref, _p(gy), _p(x), _p(gw), _p(gb), _p(ws), wsb, s)
         elif need_b:
             gb = torch.empty(d.Cout, dtype=torch.float32, device=gy.device)
             wsb = _L().sg_channel_sum_ws_bytes(d.Cout)
@@ -889,7 +909,9 @@ class FactoredLayout(object):
                 cc[n] = len(ch)
                 ep[n, :key] = [c + i for i in range(key)]
             dev = self.Z.device
-            self._lists[key] = (torch.from_numpy(cl).to(dev), torch.from_numpy(cc).to(dev), torch.from_numpy(ep).to(dev), L)
+            from .utils import to_device_async
+            self._lists[key] = (to_device_async(torch.from_numpy(cl), dev), to_device_async(torch.from_numpy(cc), dev),
+                                to_device_async(torch.from_numpy(ep), dev), L)
         return self._lists[key]
 
 
@@ -908,8 +930,8 @@ class PerImageConvFn(Function):
         OH, OW = conv_out_size(H, KS, stride, pad, 1), conv_out_size(W, KS, stride, pad, 1)
         d = _conv_desc(N, J, 0, H, W, Cout, KS, stride, pad, reflect, 1, OH, OW, 0, 0)
         y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=planes.device)
-        wsb = _L().sg_conv2d_sparse_ws_bytes(ctypes.byref(d), L, 0)
-        _call('sg_conv2d_fwd_perimage', ctypes.byref(d), _p(planes), None, _p(wimg), _p(bias), _p(clist), _p(ccnt), L, _p(y),
+        wsb = _q(d, 'sg_conv2d_sparse_ws_bytes', L, 0)
+        _call('sg_conv2d_fwd_perimage', d._ref, _p(planes), None, _p(wimg), _p(bias), _p(clist), _p(ccnt), L, _p(y),
               act, slope, _p(workspace(wsb, planes.device)), wsb, _stream())
         ctx.desc, ctx.L = d, L
         ctx.cfg = (act, slope, bias is not None, int(cfull), 0 if x2 is None else x2.size(1), stride, pad, reflect)
@@ -933,8 +955,8 @@ class PerImageConvFn(Function):
         want_w = _wants_grad(w_full)
         if ctx.needs_input_grad[2] and want_w:
             gwimg = torch.empty(d.N, d.Cout, L, d.KS, d.KS, dtype=torch.float32, device=dev)
-            wsb = _L().sg_conv2d_sparse_ws_bytes(ctypes.byref(d), L, 2)
-            _call('sg_conv2d_wgrad_perimage', ctypes.byref(d), _p(gy), _p(planes), None, _p(clist), _p(ccnt), L, _p(gwimg),
+            wsb = _q(d, 'sg_conv2d_sparse_ws_bytes', L, 2)
+            _call('sg_conv2d_wgrad_perimage', d._ref, _p(gy), _p(planes), None, _p(clist), _p(ccnt), L, _p(gwimg),
                   _p(workspace(wsb, dev)), wsb, s)
         if has_bias and ctx.needs_input_grad[3] and want_w:
             gb = torch.empty(d.Cout, dtype=torch.float32, device=dev)
@@ -945,9 +967,9 @@ class PerImageConvFn(Function):
             if reflect:
                 raise NotImplementedError('factored layout conv: x2 gradient with reflection padding')
             df = _conv_desc(d.N, cfull, C2, d.H, d.W, d.Cout, d.KS, stride, pad, reflect, 1, d.OH, d.OW, 0, 0)
-            wsb = _L().sg_conv2d_ws_bytes(ctypes.byref(df), 1)
+            wsb = _q(df, 'sg_conv2d_ws_bytes', 1)
             gx2 = torch.empty(d.N, C2, d.H, d.W, dtype=torch.float32, device=dev)
-            _call('sg_conv2d_dgrad', ctypes.byref(df), _p(gy), _p(_f32(w_full)), _p(gx2), cfull, cfull + C2,
+            _call('sg_conv2d_dgrad', df._ref, _p(gy), _p(_f32(w_full)), _p(gx2), cfull, cfull + C2,
                   _p(workspace(wsb, dev)), wsb, s)
         return None, gx2, gwimg, gb, None, None, None, None, None, None, None, None, None
 

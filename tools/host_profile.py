@@ -1,0 +1,24 @@
+"""cProfile of the Python host side of the training step (which host functions dominate the issue time)"""
+import cProfile, os, pstats, random, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from scene_generation_amd.args import parser
+from scene_generation_amd.synthetic import make_batch, make_vocab, batch_to
+from scene_generation_amd.trainer import Trainer
+args = parser.parse_args(['--image_size', '128,128', '--batch_size', '32', '--vgg_features_weight', '0', '--output_dir', '/tmp/o'])
+torch.manual_seed(0)
+tr = Trainer(args, make_vocab(), device='cuda')
+b = batch_to(make_batch(N=32, min_objs=3, max_objs=8, size=128, seed=1), 'cuda')
+tr.model.objs_host, tr.model.obj_to_img_host = b.objs.tolist(), b.obj_to_img.tolist()
+tr.model.layout_objects_hint = 9
+random.seed(0)
+for i in range(3):
+    tr.step(b, use_gt=bool(i % 2))
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for i in range(3):
+    tr.step(b, use_gt=bool(i % 2))
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats('tottime').print_stats(28)
