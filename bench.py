@@ -64,6 +64,8 @@ def cpu_baseline(image_size, n_images):
 
 def main():
     a = parse()
+    # the host driver only supports dmabuf IPC: RCCL / cross-process tensor sharing fails without it (set before HIP starts)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
