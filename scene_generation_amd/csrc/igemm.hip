@@ -1356,7 +1356,7 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
         case 3: launch_nk_general<3>(pl.tile, A, M, Mtot, PQ, g, Ncols, ep, Kpix, splits, s); break;
         case 4: launch_nk_general<4>(pl.tile, A, M, Mtot, PQ, g, Ncols, ep, Kpix, splits, s); break;
         case 7: launch_nk_general<7>(pl.tile, A, M, Mtot, PQ, g, Ncols, ep, Kpix, splits, s); break;
-        default: return -1;
+        default: t_fixed_kchunk = 0; return -1;
       }
     }
   }
