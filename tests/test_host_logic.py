@@ -153,3 +153,39 @@ def test_active_layout_channels():
     assert cl[2, :5].tolist() == [5, 172, 173, 174, 175]
     with pytest.raises(ValueError):
         active_layout_channels([172], [0], 1, 172, 4)
+
+
+def test_factored_layout_lists_host_logic():
+    """index plumbing of the factored layout convs: per-image plane lists, with the channels of a concatenated second
+    source sitting at channel ids J.. and at list positions cnt[n].. (ops.FactoredLayout.lists)"""
+    from scene_generation_amd.ops import FactoredLayout
+    Z = torch.zeros(3, 4, 2, 2)                      # N=3 images, J=4 planes
+    f = FactoredLayout(Z, torch.tensor([1, 2, 3, 4, 5, 6, 7]), torch.zeros(7, 2), 10,
+                       torch.tensor([0, 0, 1, 1, 1, 1, 2]), torch.tensor([0, 1, 0, 1, 2, 3, 0]), [2, 4, 1])
+    cl, cc, ep, L = f.lists(0)
+    assert L == 4 and cc.tolist() == [2, 4, 1]
+    assert cl[0, :2].tolist() == [0, 1] and cl[1].tolist() == [0, 1, 2, 3] and cl[2, :1].tolist() == [0]
+    cl, cc, ep, L = f.lists(3)
+    assert L == 7 and cc.tolist() == [5, 7, 4]
+    assert cl[0, :5].tolist() == [0, 1, 4, 5, 6] and cl[2, :4].tolist() == [0, 4, 5, 6]
+    assert ep.tolist() == [[2, 3, 4], [4, 5, 6], [1, 2, 3]]
+    assert f.lists(3) is f.lists(3)                  # cached per layout
+    g = f.detached()
+    assert g.lists(3) is f.lists(3) and not g.repr.requires_grad
+
+
+def test_weighted_sum_and_lazy_loss_manager():
+    from scene_generation_amd.utils import weighted_sum
+    a, b, c = torch.tensor(1.5, requires_grad=True), torch.tensor(-2.0, requires_grad=True), torch.tensor(0.25)
+    s = weighted_sum([a, b, c], [2.0, 0.5, 4.0])
+    assert abs(float(s) - (3.0 - 1.0 + 1.0)) < 1e-6
+    s.backward()
+    assert float(a.grad) == 2.0 and float(b.grad) == 0.5
+    L = LossManager()
+    L.add_loss(torch.tensor(2.0), 'x', 3.0)
+    L.add_loss(torch.tensor(1.0), 'logged_only', 5.0, use_loss=False)
+    L.add_loss(torch.tensor(4.0), 'y')
+    assert abs(float(L.total_loss) - 10.0) < 1e-6
+    assert dict(L.items()) == {'x': 6.0, 'logged_only': 5.0, 'y': 4.0}
+    L.add_loss(torch.tensor(1.0), 'z', 2.0)          # adding after a read invalidates the cached sum
+    assert abs(float(L.total_loss) - 12.0) < 1e-6
