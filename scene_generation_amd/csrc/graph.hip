@@ -112,16 +112,34 @@ __global__ void embedding_fwd_kernel(const float* __restrict__ table, const int6
   for (int c = threadIdx.x; c < dim; c += blockDim.x) out[(size_t)i * dim + c] = src[c];
 }
 
-// one block per table row; rows of g accumulated in ascending i (== CPU index_add order)
+// one block per table row; rows of g accumulated in ascending i (== CPU index_add order).  The matching rows are listed
+// once (thread 0, ascending) so the column loop only touches them: the scan over all n indices per column made this the
+// slowest small kernel of the factored layout convs (dim = Cout*KS*KS = 3136).
 __global__ void embedding_bwd_kernel(const float* __restrict__ g, const int64_t* __restrict__ idx,
                                      float* __restrict__ gt, int n, int dim) {
+  constexpr int CAP = 1024;
+  __shared__ int hits[CAP];
+  __shared__ int nhit;
   const int row = blockIdx.x;
-  for (int c = threadIdx.x; c < dim; c += blockDim.x) {
-    float acc = 0.f;
-    for (int i = 0; i < n; ++i)
-      if (idx[i] == row) acc += g[(size_t)i * dim + c];
-    gt[(size_t)row * dim + c] = acc;
+  for (int base = 0; base < n; base += CAP) {            // chunks of CAP indices (one chunk in practice)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int c = 0;
+      const int end = base + CAP < n ? base + CAP : n;
+      for (int i = base; i < end; ++i)
+        if (idx[i] == row) hits[c++] = i;
+      nhit = c;
+    }
+    __syncthreads();
+    const int c = nhit;
+    for (int col = threadIdx.x; col < dim; col += blockDim.x) {
+      float acc = base == 0 ? 0.f : gt[(size_t)row * dim + col];
+      for (int h = 0; h < c; ++h) acc += g[(size_t)hits[h] * dim + col];
+      gt[(size_t)row * dim + col] = acc;
+    }
   }
+  if (n == 0)
+    for (int col = threadIdx.x; col < dim; col += blockDim.x) gt[(size_t)row * dim + col] = 0.f;
 }
 
 __global__ void copy_cols_kernel(const float* __restrict__ src, int src_ld, int src_off, float* __restrict__ dst,

@@ -164,10 +164,15 @@ class MultiscaleDiscriminator(nn.Module):
             model = [getattr(self, 'scale' + str(num_D - 1 - i) + '_layer' + str(j)) for j in range(self.n_layers + 2)]
             result.append(self.singleD_forward(model, a, b))
             if i != (num_D - 1):
-                a_lo = ops.carry_hints(a, self.downsample(a))   # pooling keeps all-zero layout channels all-zero
-                f = getattr(a, '_sg_factored', None)
-                if f is not None:                               # pooling is linear: pool the planes of the factored form
-                    a_lo._sg_factored = f.with_planes(self.downsample(f.Z))
+                f = getattr(a, '_sg_factored', None) if ops.FACTORED_LAYOUT else None
+                if f is not None and b is not None:
+                    # pooling is linear: pool the planes of the factored form.  The first conv then never reads the dense
+                    # pooled layout, so it is not computed (placeholder with the right shape carries the hints)
+                    planes = self.downsample(f.Z)
+                    a_lo = a.new_empty((a.size(0), a.size(1)) + tuple(planes.shape[2:]))
+                    a_lo._sg_factored = f.with_planes(planes)
+                else:
+                    a_lo = ops.carry_hints(a, self.downsample(a))   # pooling keeps all-zero layout channels all-zero
                 a = a_lo
                 b = self.downsample(b) if b is not None else None
         return result
