@@ -741,7 +741,7 @@ def _compare_grads(snaps, tag):
     Single operators agree to ~1e-5 (tests above).  Through the 40-layer generator the forward activations differ
     by ~2e-5 (MFMA accumulates each K=2304..9216 dot product as ONE sequential fp32 fma chain, oneDNN on the CPU
     sums in blocks), so a few dozen of the ~1e6 ReLU / LeakyReLU units whose pre-activation is within 2e-5 of zero take
-    the other branch and individual gradient entries move at the 1e-3..1e-2 level (measured with tools/debug_grads.py:
+    the other branch and individual gradient entries move at the 1e-3..1e-2 level (measured with tests/debug_grads.py:
     d loss / d imgs_pred agrees to 1e-7, d loss / d layout after the generator backward to 4e-3 of its max).
     Checks that are robust to that: (1) flat gradient of every optimiser: cosine > 0.9995 (observed 0.9999 +- 1e-4
     depending on which units flip: any change of a summation order anywhere in the step moves it); (2) every tensor with a
