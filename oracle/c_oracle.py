@@ -50,6 +50,17 @@ def masks_to_layout(vecs, boxes, masks, obj_to_img, H, W=None, pooling='sum'):
     return torch.from_numpy(out)
 
 
+def masks_to_layout_test(vecs, boxes, masks, obj_to_img, H, W=None, pooling='sum'):
+    """test-mode compositing (layout.py:87-92,157-169)"""
+    W = H if W is None else W
+    v, b, m, o2i = _f(vecs), _f(boxes), _f(masks.float()), _i(obj_to_img)
+    O, D = v.shape
+    N = int(o2i.max()) + 1
+    out = np.empty((N, D, H, W), dtype=np.float32)
+    lib().ora_masks_to_layout_test(_p(v), _p(b), _p(m), _p(o2i), O, D, m.shape[1], N, H, W, int(pooling == 'avg'), _p(out))
+    return torch.from_numpy(out)
+
+
 def crop_bbox_batch(feats, boxes, idx, HH, WW=None):
     WW = HH if WW is None else WW
     f, b, i = _f(feats), _f(boxes), _i(idx)

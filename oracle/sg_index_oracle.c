@@ -6,6 +6,7 @@
  *
  *   ora_pool_triples    graph.py:94-116   scatter_add s-pass THEN o-pass, t ascending; clamp(min=1); true division
  *   ora_masks_to_layout layout.py:64-93,96-128,131-155   (factored form)
+ *   ora_masks_to_layout_test layout.py:87-92,157-169    test-mode compositing (ascending-mass order, first hit wins)
  *   ora_crop_bbox       bilinear.py:67-130,246-275       
  * grid_sample semantics = torch >= 1.3 default: bilinear, zeros padding, align_corners=False.
  */
@@ -99,6 +100,69 @@ void ora_masks_to_layout(const float* vecs, const float* boxes, const float* mas
       for (size_t p = 0; p < (size_t)D * H * W; ++p) out[(size_t)n * D * H * W + p] /= (float)count[n];
   }
   free(S); free(count); free(seen);
+}
+
+/* bilinear-sampled mask of object o at every pixel (the factor S_o of the layout) */
+static void sample_plane(const float* boxes, const float* masks, int o, int M, int H, int W, float* S) {
+  const float x0 = boxes[o * 4 + 0], y0 = boxes[o * 4 + 1], x1 = boxes[o * 4 + 2], y1 = boxes[o * 4 + 3];
+  const float* mk = masks + (size_t)o * M * M;
+  for (int h = 0; h < H; ++h) {
+    const tap_t ty = make_tap(((lin01(h, H) - y0) / (y1 - y0)) * 2.0f - 1.0f, M);
+    for (int w = 0; w < W; ++w) {
+      const tap_t tx = make_tap(((lin01(w, W) - x0) / (x1 - x0)) * 2.0f - 1.0f, M);
+      float v = mk[ty.i0 * M + tx.i0] * (ty.w0 * tx.w0);
+      v += mk[ty.i0 * M + tx.i1] * (ty.w0 * tx.w1);
+      v += mk[ty.i1 * M + tx.i0] * (ty.w1 * tx.w0);
+      v += mk[ty.i1 * M + tx.i1] * (ty.w1 * tx.w1);
+      S[h * W + w] = v;
+    }
+  }
+}
+
+/* layout.py:157-169: per image the objects are visited in ascending mass = sum_{d,h,w} vecs[o,d] * S_o[h,w] (stable for
+ * ties, like numpy's insertion sort on the short lists involved); a pixel takes vecs[o] * S_o of the first visited object
+ * whose sampled mask exceeds 0.5, zero if none.  obj_to_img sorted (layout.py:153-154). */
+void ora_masks_to_layout_test(const float* vecs, const float* boxes, const float* masks, const int64_t* obj_to_img, int O,
+                              int D, int M, int N, int H, int W, int avg, float* out) {
+  const int HW = H * W;
+  float* S = (float*)malloc(sizeof(float) * (size_t)O * HW);
+  double* mass = (double*)malloc(sizeof(double) * (size_t)O);
+  int* order = (int*)malloc(sizeof(int) * (size_t)O);
+  memset(out, 0, sizeof(float) * (size_t)N * D * HW);
+  for (int o = 0; o < O; ++o) {
+    sample_plane(boxes, masks, o, M, H, W, S + (size_t)o * HW);
+    double sv = 0.0, ss = 0.0;
+    for (int d = 0; d < D; ++d) sv += (double)vecs[(size_t)o * D + d];
+    for (int p = 0; p < HW; ++p) ss += (double)S[(size_t)o * HW + p];
+    mass[o] = sv * ss;
+  }
+  int beg = 0;
+  while (beg < O) {
+    const int n = (int)obj_to_img[beg];
+    int end = beg;
+    while (end < O && obj_to_img[end] == n) ++end;
+    const int cnt = end - beg;
+    for (int j = 0; j < cnt; ++j) order[j] = beg + j;
+    for (int j = 1; j < cnt; ++j) {                  /* insertion sort: stable */
+      const int key = order[j];
+      int k = j - 1;
+      while (k >= 0 && mass[order[k]] > mass[key]) { order[k + 1] = order[k]; --k; }
+      order[k + 1] = key;
+    }
+    const float div = (avg && cnt > 1) ? (float)cnt : 1.0f;
+    for (int p = 0; p < HW; ++p) {
+      for (int j = 0; j < cnt; ++j) {
+        const int o = order[j];
+        const float s = S[(size_t)o * HW + p];
+        if (s > 0.5f) {
+          for (int d = 0; d < D; ++d) out[((size_t)n * D + d) * HW + p] = vecs[(size_t)o * D + d] * s / div;
+          break;
+        }
+      }
+    }
+    beg = end;
+  }
+  free(S); free(mass); free(order);
 }
 
 void ora_crop_bbox(const float* feats, const float* boxes, const int64_t* box_to_feat, int C, int H, int W, int B,

@@ -287,3 +287,13 @@ def test_model_inference_forward_vs_reference(golden):
         close(out[2], g[tag + '_masks_pred'], 2e-5, tag + ' masks')
         close(out[4], g[tag + '_pred_layout'], 2e-5, tag + ' layout')
         close(out[0], g[tag + '_imgs_pred'], 5e-5, tag + ' imgs')
+
+
+@pytest.mark.parametrize('case', TEST_LAYOUT_CASES)
+def test_c_oracle_layout_test_mode(golden, case):
+    """plain-C restatement of the test-mode compositing against the reference goldens"""
+    from oracle import c_oracle as CO
+    g = golden('layout_test_' + case)
+    out = CO.masks_to_layout_test(T(g['vecs']), T(g['boxes']), T(g['masks']), T(g['obj_to_img']), int(g['H']), int(g['W']),
+                                  'avg' if int(g['avg']) else 'sum')
+    close(out, g['out'], 1e-5, 'test-mode layout (C)')
