@@ -189,3 +189,46 @@ def test_weighted_sum_and_lazy_loss_manager():
     assert dict(L.items()) == {'x': 6.0, 'logged_only': 5.0, 'y': 4.0}
     L.add_loss(torch.tensor(1.0), 'z', 2.0)          # adding after a read invalidates the cached sum
     assert abs(float(L.total_loss) - 12.0) < 1e-6
+
+
+def test_checkpoint_round_trip_and_torch_adam_compatibility(tmp_path):
+    """SURVEY 8f rank 4 (host logic only): Trainer.save_checkpoint / restore_checkpoint round-trip every network and all
+    four optimisers (trainer.py:136-203 schema), and the saved optimiser state is what torch.optim.Adam -- the reference's
+    optimiser -- loads (the oracle Trainer restores it)."""
+    from scene_generation_amd.trainer import Trainer
+    argv = ['--image_size', '32,32', '--batch_size', '3', '--vgg_features_weight', '0', '--output_dir', str(tmp_path),
+            '--n_downsample_global', '2', '--gconv_hidden_dim', '64', '--gconv_num_layers', '3', '--mask_size', '8',
+            '--ndf', '8', '--ndf_mask', '8', '--crop_size', '16', '--d_obj_arch', 'C4-8-2,C4-16-2', '--pool_size', '2']
+    args = parser.parse_args(argv)
+    vocab = make_vocab(12, 4, 35)
+    tr = Trainer(args, vocab, device='cpu')
+    nets = lambda t: [t.model, t.netD, t.obj_discriminator, t.mask_discriminator]
+    opts = lambda t: [t.optimizer, t.optimizer_d_img, t.optimizer_d_obj, t.optimizer_d_mask]
+    for m in nets(tr):
+        fill_deterministic(m)
+    g = torch.Generator().manual_seed(0)
+    for o in opts(tr):                                   # pretend three Adam steps happened
+        o.exp_avg.copy_(torch.randn(o.exp_avg.shape, generator=g))
+        o.exp_avg_sq.copy_(torch.rand(o.exp_avg_sq.shape, generator=g))
+        o.steps = [3] * len(o.steps)
+    path = tr.save_checkpoint({}, 7, args, 2)
+    sd = torch.load(path, weights_only=False)
+    assert sd['counters'] == {'t': 7, 'epoch': 2}
+    tr2 = Trainer(args, vocab, device='cpu')
+    tr2.restore_checkpoint(sd)
+    for a, b in zip(nets(tr), nets(tr2)):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert all(torch.equal(sa[k], sb[k]) for k in sa)
+    for a, b in zip(opts(tr), opts(tr2)):
+        assert a.steps == b.steps
+        assert torch.equal(a.fp.packed(a.exp_avg), b.fp.packed(b.exp_avg))
+        assert torch.equal(a.fp.packed(a.exp_avg_sq), b.fp.packed(b.exp_avg_sq))
+    # the same file restores the torch-Adam based oracle (= the reference's optimiser format)
+    ref = O.Trainer(args, vocab)
+    ref.model.load_state_dict(sd['model_state'])
+    ref.optimizer.load_state_dict(sd['optim_state'])
+    p0 = next(iter(ref.model.parameters()))
+    st = ref.optimizer.state[p0]
+    assert float(st['step']) == 3.0
+    assert torch.equal(st['exp_avg'], tr.optimizer.exp_avg[:p0.numel()].view(p0.shape))
