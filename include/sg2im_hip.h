@@ -31,7 +31,11 @@ typedef void* sgStream;
 /* activation codes fused into epilogues */
 enum { SG_ACT_NONE = 0, SG_ACT_RELU = 1, SG_ACT_LEAKY = 2, SG_ACT_TANH = 3, SG_ACT_SIGMOID = 4 };
 /* scalar loss kinds (sg_loss_fwd / sg_loss_bwd) */
-enum { SG_LOSS_MSE_CONST = 0, SG_LOSS_MSE = 1, SG_LOSS_L1 = 2, SG_LOSS_BCE_LOGITS_CONST = 3 };
+enum { SG_LOSS_MSE_CONST = 0, SG_LOSS_MSE = 1, SG_LOSS_L1 = 2, SG_LOSS_BCE_LOGITS_CONST = 3,
+       SG_LOSS_MEAN = 4,               /* sum a_i                      (wgan_*_loss, losses.py:93-112) */
+       SG_LOSS_MSE_SIGMOID_CONST = 5,  /* (sigmoid(a_i) - target)^2    (lsgan_*_loss, losses.py:115-132) */
+       SG_LOSS_BCE_PROB_CONST = 6 };   /* nn.BCELoss vs a constant     (GANLoss(use_lsgan=False), losses.py:147) */
+#define SG_WSUM_MAX 32
 
 int sg_version(void);
 const char* sg_last_error_string(void);
@@ -191,6 +195,10 @@ int sg_batchnorm_bwd(const float* x, const float* gy, const float* gamma, const 
                      int act, float slope, void* ws, size_t ws_bytes, sgStream stream);
 int sg_avgpool3s2_fwd(const float* x, float* y, int NC, int H, int W, int OH, int OW, sgStream stream);
 int sg_avgpool3s2_bwd(const float* gy, float* gx, int NC, int H, int W, int OH, int OW, sgStream stream);
+/* nn.MaxPool2d(2, 2) of the VGG19 feature extractor behind VGGLoss (losses.py:179-224; torchvision vgg19.features[4,9,18,27]):
+ * y [NC, H/2, W/2]; _bwd routes gy to the first maximum of each window (recomputed from x), zero elsewhere */
+int sg_maxpool2_fwd(const float* x, float* y, int NC, int H, int W, sgStream stream);
+int sg_maxpool2_bwd(const float* x, const float* gy, float* gx, int NC, int H, int W, sgStream stream);
 int sg_gap_fwd(const float* x, float* y, int NC, int HW, sgStream stream);
 int sg_gap_bwd(const float* gy, float* gx, int NC, int HW, sgStream stream);
 int sg_upsample2_fwd(const float* x, float* y, int NC, int H, int W, sgStream stream);   /* nearest x2 */
@@ -249,6 +257,14 @@ int sg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
                  float eps, float bias_corr1, float bias_corr2_sqrt, sgStream stream);
 int sg_fill(float* p, float value, int64_t n, sgStream stream);
 int sg_scale(float* p, float alpha, int64_t n, sgStream stream);
+/* y += alpha * x : a second gradient contribution to a parameter slice of the flat gradient buffer (the first one is
+ * written in place by the weight-gradient kernels; replaces autograd's AccumulateGrad add, trainer.py:262,278,299,324) */
+int sg_axpy(float* y, const float* x, float alpha, int64_t n, sgStream stream);
+/* total_loss = sum_i weight_i * loss_i over <= SG_WSUM_MAX device scalars (LossManager.add_loss, utils.py:50-57, and the
+ * scale sums of GANLoss / calculate_features_loss, losses.py:166-172, trainer.py:331-340); terms_host = HOST array of
+ * DEVICE pointers, weights_host = HOST array.  _bwd: gterms[i] = weights[i] * gout[0] */
+int sg_weighted_sum_fwd(const void* const* terms_host, const float* weights_host, int n, float* out, sgStream stream);
+int sg_weighted_sum_bwd(const float* weights_host, int n, const float* gout, float* gterms, sgStream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Opt-in per-kernel timing with HIP events on the launch stream (bench.py roofline leg).

@@ -552,24 +552,54 @@ def gan_d_loss(scores_real, scores_fake):
     return bce_loss(r, torch.ones_like(r)) + bce_loss(f, torch.zeros_like(f))
 
 
+def wgan_g_loss(scores_fake):
+    """losses.py:93-101."""
+    return -scores_fake.mean()
+
+
+def wgan_d_loss(scores_real, scores_fake):
+    """losses.py:104-112."""
+    return scores_fake.mean() - scores_real.mean()
+
+
+def lsgan_g_loss(scores_fake):
+    """losses.py:115-119: MSE of sigmoid(scores) against 1."""
+    s = scores_fake.reshape(-1)
+    return F.mse_loss(s.sigmoid(), torch.ones_like(s))
+
+
+def lsgan_d_loss(scores_real, scores_fake):
+    """losses.py:122-132."""
+    assert scores_real.size() == scores_fake.size()
+    r, f = scores_real.reshape(-1), scores_fake.reshape(-1)
+    return F.mse_loss(r.sigmoid(), torch.ones_like(r)) + F.mse_loss(f.sigmoid(), torch.zeros_like(f))
+
+
 def get_gan_losses(gan_type):
-    """losses.py:8-23 ('gan' is the only type the default flags select, args.py:95)."""
+    """losses.py:8-23 ('gan' is the type the default flags select, args.py:95)."""
     if gan_type == 'gan':
         return gan_g_loss, gan_d_loss
+    if gan_type == 'wgan':
+        return wgan_g_loss, wgan_d_loss
+    if gan_type == 'lsgan':
+        return lsgan_g_loss, lsgan_d_loss
     raise ValueError('Unrecognized GAN type "%s"' % gan_type)
 
 
 class GANLoss(nn.Module):
-    """losses.py:135-175: LSGAN = MSE against a constant 1/0 target, SUMMED over scales (:166-172)."""
+    """losses.py:135-175: MSE (LSGAN, default) or nn.BCELoss against a constant 1/0 target, SUMMED over scales
+    (:166-172)."""
 
     def __init__(self, use_lsgan=True, target_real_label=1.0, target_fake_label=0.0, tensor=None):
         super().__init__()
-        assert use_lsgan
+        self.use_lsgan = use_lsgan
         self.real_label, self.fake_label = target_real_label, target_fake_label
 
     def _one(self, pred, target_is_real):
         t = self.real_label if target_is_real else self.fake_label
-        return F.mse_loss(pred, torch.full_like(pred, t))
+        if self.use_lsgan:
+            return F.mse_loss(pred, torch.full_like(pred, t))
+        return F.binary_cross_entropy(pred, torch.full_like(pred, t))
 
     def __call__(self, preds, target_is_real):
         if isinstance(preds[0], list):
@@ -589,6 +619,66 @@ def features_loss(pred_fake, pred_real):
         for j in range(len(pred_fake[i]) - 1):
             total = total + w * F.l1_loss(pred_fake[i][j], pred_real[i][j].detach())
     return total
+
+
+# VGG feature matching (losses.py:179-224).  The reference slices torchvision's vgg19(pretrained=True).features; torchvision
+# (and its ImageNet weights) are absent here, so the ARCHITECTURE below restates torchvision's published configuration 'E'
+# (conv3x3 pad 1 + ReLU(inplace), MaxPool2d(2, 2); features indices 0..29) and the weights are whatever the caller loads.
+# tools/make_golden.py runs the reference's own Vgg19 / VGGLoss classes on a torchvision shim with this configuration,
+# which pins the reference-side part (slice boundaries, L1 weights, detach) -- the ImageNet weights stay unpinned.
+VGG19_CFG = (64, 64, 'M', 128, 128, 'M', 256, 256, 256, 256, 'M', 512, 512, 512, 512, 'M', 512, 512, 512, 512, 'M')
+
+
+def vgg19_features():
+    layers, cin = [], 3
+    for v in VGG19_CFG:
+        if v == 'M':
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    return nn.Sequential(*layers)
+
+
+class Vgg19(nn.Module):
+    """losses.py:179-209."""
+
+    def __init__(self, requires_grad=False):
+        super().__init__()
+        feats = vgg19_features()
+        bounds = [(0, 2), (2, 7), (7, 12), (12, 21), (21, 30)]
+        for k, (lo, hi) in enumerate(bounds):
+            seq = nn.Sequential()
+            for x in range(lo, hi):
+                seq.add_module(str(x), feats[x])
+            setattr(self, 'slice%d' % (k + 1), seq)
+        if not requires_grad:
+            for p in self.parameters():
+                p.requires_grad = False
+
+    def forward(self, X):
+        h1 = self.slice1(X)
+        h2 = self.slice2(h1)
+        h3 = self.slice3(h2)
+        h4 = self.slice4(h3)
+        h5 = self.slice5(h4)
+        return [h1, h2, h3, h4, h5]
+
+
+class VGGLoss(nn.Module):
+    """losses.py:212-224."""
+
+    def __init__(self):
+        super().__init__()
+        self.vgg = Vgg19()
+        self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+
+    def forward(self, x, y):
+        x_vgg, y_vgg = self.vgg(x), self.vgg(y)
+        loss = 0
+        for i in range(len(x_vgg)):
+            loss = loss + self.weights[i] * F.l1_loss(x_vgg[i], y_vgg[i].detach())
+        return loss
 
 
 # ------------------------------------------------------------------------------------------
@@ -738,7 +828,8 @@ class Model(nn.Module):
 # ------------------------------------------------------------------------------------------
 
 class Trainer:
-    """trainer.py:15-134,205-340 without logging/checkpoint glue; VGG loss off."""
+    """trainer.py:15-134,205-340 without logging/checkpoint glue.  ``criterionVGG`` (trainer.py:57) is built when
+    ``--vgg_features_weight > 0``; its weights are the caller's business (see Vgg19 above)."""
 
     def __init__(self, args, vocab, model_extra=None):
         self.args, self.vocab = args, vocab
@@ -753,7 +844,7 @@ class Trainer:
                   mask_noise_dim=args.mask_noise_dim, pool_size=args.pool_size, rep_size=args.rep_size)
         mk.update(model_extra or {})
         self.model = Model(**mk)
-        assert args.vgg_features_weight == 0, 'VGG loss needs pretrained weights (SURVEY a23)'
+        self.criterionVGG = VGGLoss() if args.vgg_features_weight > 0 else None
         self.criterionGAN = GANLoss(use_lsgan=not args.no_lsgan)
         adam = lambda m, lr: torch.optim.Adam(m.parameters(), lr=lr, betas=(args.beta1, 0.999))
         self.optimizer = adam(self.model, args.learning_rate)
@@ -780,6 +871,8 @@ class Trainer:
             if a.l1_pixel_loss_weight > 0:
                 L.add_loss(F.l1_loss(imgs_pred, imgs), 'L1_pixel_loss', a.l1_pixel_loss_weight)
             L.add_loss(F.mse_loss(boxes_pred, boxes), 'bbox_pred', a.bbox_pred_loss_weight)
+        if self.criterionVGG is not None:                                        # trainer.py:218-221
+            L.add_loss(self.criterionVGG(imgs_pred, imgs), 'g_vgg', a.vgg_features_weight)
         scores_fake, ac_loss, _ = self.obj_discriminator(imgs_pred, objs, boxes, obj_to_img)
         L.add_loss(ac_loss, 'ac_loss', a.ac_loss_weight)
         L.add_loss(self.gan_g_loss(scores_fake), 'g_gan_obj_loss', a.d_obj_weight)

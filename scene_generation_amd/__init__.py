@@ -14,9 +14,33 @@ _SUBMODULES = ('args', 'utils', 'layers', 'graph', 'layout', 'bilinear', 'genera
                'model', 'trainer', 'optim', 'parallel', 'synthetic', 'ops')
 
 
-def install_as(name='scene_generation'):
-    """Register this package (and its submodules) in sys.modules under ``name`` -- the drop-in switch."""
+def _find_host_package(name):
+    """directory of a DIFFERENT package called ``name`` on sys.path / the working directory (the checkout whose train.py is
+    being run): everything this package does not provide -- data/, metrics, vis -- keeps coming from there"""
+    import os
+    own = os.path.realpath(os.path.dirname(os.path.abspath(__file__)))
+    for base in [os.getcwd()] + list(sys.path):
+        d = os.path.join(base or '.', name)
+        if os.path.isfile(os.path.join(d, '__init__.py')) and os.path.realpath(d) != own:
+            return os.path.abspath(d)
+    return None
+
+
+def install_as(name='scene_generation', host_package_dir=None):
+    """The drop-in switch: register this package in sys.modules under ``name`` so that
+    ``from scene_generation.trainer import Trainer`` etc. resolve to the MI355X implementation.
+
+    Only the hot-path modules are replaced (args, utils, layers, graph, layout, bilinear, generators, discriminators,
+    losses, model, trainer).  Everything else the reference's scripts import from the package -- ``scene_generation.data.*``,
+    ``scene_generation.metrics``, ``scene_generation.vis`` (train.py:10-12) -- is out of this package's scope and keeps
+    resolving to the host checkout: its package directory (found on sys.path / the working directory, or given as
+    ``host_package_dir``) is appended to the package search path."""
     pkg = sys.modules[__name__]
+    host = host_package_dir if host_package_dir is not None else _find_host_package(name)
+    if host and host not in pkg.__path__:
+        pkg.__path__.append(host)
+    for key in [k for k in sys.modules if k == name or k.startswith(name + '.')]:
+        del sys.modules[key]                      # a previously imported reference package must not shadow the overlay
     sys.modules[name] = pkg
     for sub in _SUBMODULES:
         sys.modules['%s.%s' % (name, sub)] = importlib.import_module('%s.%s' % (__name__, sub))

@@ -13,6 +13,10 @@ __device__ __forceinline__ float loss_term(int kind, float a, float b, float t) 
     case SG_LOSS_MSE_CONST: { const float d = a - t; return d * d; }
     case SG_LOSS_MSE: { const float d = a - b; return d * d; }
     case SG_LOSS_L1: return fabsf(a - b);
+    case SG_LOSS_MEAN: return a;                                            // wgan losses (losses.py:93-112)
+    case SG_LOSS_MSE_SIGMOID_CONST: { const float d = 1.f / (1.f + expf(-a)) - t; return d * d; }   // losses.py:115-132
+    case SG_LOSS_BCE_PROB_CONST:      // nn.BCELoss on probabilities (losses.py:147), logs clamped at -100 like torch
+      return -(t * fmaxf(logf(a), -100.f) + (1.f - t) * fmaxf(logf(1.f - a), -100.f));
     default: return fmaxf(a, 0.f) - a * t + logf(1.f + expf(-fabsf(a)));   // losses.py:42-44
   }
 }
@@ -22,6 +26,12 @@ __device__ __forceinline__ float loss_grad(int kind, float a, float b, float t) 
     case SG_LOSS_MSE_CONST: return 2.f * (a - t);
     case SG_LOSS_MSE: return 2.f * (a - b);
     case SG_LOSS_L1: { const float d = a - b; return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+    case SG_LOSS_MEAN: return 1.f;
+    case SG_LOSS_MSE_SIGMOID_CONST: { const float sg = 1.f / (1.f + expf(-a)); return 2.f * (sg - t) * sg * (1.f - sg); }
+    case SG_LOSS_BCE_PROB_CONST: {
+      const float g1 = logf(a) > -100.f ? 1.f / a : 0.f, g0 = logf(1.f - a) > -100.f ? 1.f / (1.f - a) : 0.f;
+      return -(t * g1 - (1.f - t) * g0);
+    }
     default: {
       // d/da [max(a,0) - a t + log(1+exp(-|a|))]
       const float e = expf(-fabsf(a));
@@ -113,13 +123,40 @@ __global__ void scale_kernel(float* __restrict__ p, float a, size_t n) {
   if (i < n) p[i] *= a;
 }
 
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += a * x[i];
+}
+__global__ void axpy4_kernel(float4* __restrict__ y, const float4* __restrict__ x, float a, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 u = y[i];
+  const float4 v = x[i];
+  u.x += a * v.x; u.y += a * v.y; u.z += a * v.z; u.w += a * v.w;
+  y[i] = u;
+}
+
+// total = sum_i w[i] * *term[i] in index order (one thread: <= 32 terms), and its dual g[i] = w[i] * gout
+struct WsumArgs { const float* term[SG_WSUM_MAX]; float w[SG_WSUM_MAX]; int n; };
+__global__ void wsum_fwd_kernel(WsumArgs a, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < a.n; ++i) s += a.w[i] * a.term[i][0];
+    out[0] = s;
+  }
+}
+__global__ void wsum_bwd_kernel(WsumArgs a, const float* __restrict__ gout, float* __restrict__ g) {
+  const int i = threadIdx.x;
+  if (i < a.n) g[i] = a.w[i] * gout[0];
+}
+
 }  // namespace
 
 extern "C" size_t sg_loss_ws_bytes(int64_t n) { (void)n; return LOSS_BLOCKS * sizeof(float); }
 
 extern "C" int sg_loss_fwd(int kind, const float* a, const float* b, float target, int64_t n, float scale, float* out,
                            int accumulate, void* ws, size_t ws_bytes, sgStream stream) {
-  SG_ARG_CHECK(a && out && ws && n > 0 && kind >= 0 && kind <= 3, "sg_loss_fwd: bad arguments");
+  SG_ARG_CHECK(a && out && ws && n > 0 && kind >= 0 && kind <= SG_LOSS_BCE_PROB_CONST, "sg_loss_fwd: bad arguments");
   SG_ARG_CHECK((kind != SG_LOSS_MSE && kind != SG_LOSS_L1) || b, "sg_loss_fwd: pair loss needs b");
   SG_ARG_CHECK(ws_bytes >= LOSS_BLOCKS * sizeof(float), "sg_loss_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
@@ -133,7 +170,7 @@ extern "C" int sg_loss_fwd(int kind, const float* a, const float* b, float targe
 
 extern "C" int sg_loss_bwd(int kind, const float* a, const float* b, float target, int64_t n, float scale, const float* gout,
                            float* ga, sgStream stream) {
-  SG_ARG_CHECK(a && gout && ga && n > 0 && kind >= 0 && kind <= 3, "sg_loss_bwd: bad arguments");
+  SG_ARG_CHECK(a && gout && ga && n > 0 && kind >= 0 && kind <= SG_LOSS_BCE_PROB_CONST, "sg_loss_bwd: bad arguments");
   hipLaunchKernelGGL(loss_bwd_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, kind, a, b, target, (size_t)n,
                      scale, gout, ga);
   SG_LAUNCH_CHECK("sg_loss_bwd");
@@ -183,5 +220,39 @@ extern "C" int sg_scale(float* p, float alpha, int64_t n, sgStream stream) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(scale_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, alpha, (size_t)n);
   SG_LAUNCH_CHECK("sg_scale");
+  return 0;
+}
+
+extern "C" int sg_axpy(float* y, const float* x, float alpha, int64_t n, sgStream stream) {
+  SG_ARG_CHECK(y && x && n >= 0, "sg_axpy: bad arguments");
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (n % 4 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x)) & 15) == 0)
+    hipLaunchKernelGGL(axpy4_kernel, dim3(sg_cdiv(n / 4, 256)), dim3(256), 0, s, (float4*)y, (const float4*)x, alpha, (size_t)(n / 4));
+  else
+    hipLaunchKernelGGL(axpy_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, s, y, x, alpha, (size_t)n);
+  SG_LAUNCH_CHECK("sg_axpy");
+  return 0;
+}
+
+extern "C" int sg_weighted_sum_fwd(const void* const* terms_host, const float* weights_host, int n, float* out,
+                                   sgStream stream) {
+  SG_ARG_CHECK(terms_host && weights_host && out && n > 0 && n <= SG_WSUM_MAX, "sg_weighted_sum_fwd: bad arguments (n=%d)", n);
+  WsumArgs a;
+  a.n = n;
+  for (int i = 0; i < n; ++i) { a.term[i] = (const float*)terms_host[i]; a.w[i] = weights_host[i]; }
+  for (int i = n; i < SG_WSUM_MAX; ++i) { a.term[i] = nullptr; a.w[i] = 0.f; }
+  hipLaunchKernelGGL(wsum_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, out);
+  SG_LAUNCH_CHECK("sg_weighted_sum_fwd");
+  return 0;
+}
+
+extern "C" int sg_weighted_sum_bwd(const float* weights_host, int n, const float* gout, float* gterms, sgStream stream) {
+  SG_ARG_CHECK(weights_host && gout && gterms && n > 0 && n <= SG_WSUM_MAX, "sg_weighted_sum_bwd: bad arguments (n=%d)", n);
+  WsumArgs a;
+  a.n = n;
+  for (int i = 0; i < SG_WSUM_MAX; ++i) { a.term[i] = nullptr; a.w[i] = i < n ? weights_host[i] : 0.f; }
+  hipLaunchKernelGGL(wsum_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, gout, gterms);
+  SG_LAUNCH_CHECK("sg_weighted_sum_bwd");
   return 0;
 }

@@ -347,6 +347,61 @@ __global__ void avgpool3s2_bwd_kernel(const float* __restrict__ gy, float* __res
   gx[i] = s;
 }
 
+// nn.MaxPool2d(kernel_size=2, stride=2) of VGG19 (losses.py:183-198 slices torchvision's vgg19.features): floor mode, first
+// maximum of the window wins (row-major scan with a strict '>' like ATen), NaN propagates.  One thread per output pixel;
+// even widths read / write float2 rows.
+__device__ __forceinline__ int maxpool_argmax(float a, float b, float c, float d) {
+  int k = 0; float m = a;
+  if (b > m || b != b) { m = b; k = 1; }
+  if (c > m || c != c) { m = c; k = 2; }
+  if (d > m || d != d) { m = d; k = 3; }
+  return k;
+}
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int NC, int H, int W, int OH, int OW) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)NC * OH * OW) return;
+  const int ow = i % OW;
+  const int oh = (i / OW) % OH;
+  const size_t nc = i / ((size_t)OW * OH);
+  const float* p = x + (nc * H + 2 * oh) * W + 2 * ow;
+  float a, b, c, d;
+  if ((W & 1) == 0) {
+    const float2 r0 = *reinterpret_cast<const float2*>(p), r1 = *reinterpret_cast<const float2*>(p + W);
+    a = r0.x; b = r0.y; c = r1.x; d = r1.y;
+  } else {
+    a = p[0]; b = p[1]; c = p[W]; d = p[W + 1];
+  }
+  const int k = maxpool_argmax(a, b, c, d);
+  y[i] = k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d));
+}
+// gx = gy routed to the window's arg-max (recomputed from x); rows / columns no window covers (odd sizes) get zero
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx, int NC,
+                                    int H, int W, int OH, int OW) {
+  const int CW = (W + 1) / 2, CH = (H + 1) / 2;            // cells incl. the uncovered tail
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)NC * CH * CW) return;
+  const int cw = i % CW;
+  const int ch = (i / CW) % CH;
+  const size_t nc = i / ((size_t)CW * CH);
+  const size_t base = (nc * H + 2 * ch) * W + 2 * cw;
+  if (ch >= OH || cw >= OW) {                              // tail cell: up to 2x2 inputs outside every window
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b)
+        if (2 * ch + a < H && 2 * cw + b < W) gx[base + a * W + b] = 0.f;
+    return;
+  }
+  const float* p = x + base;
+  const float g = gy[(nc * OH + ch) * OW + cw];
+  const int k = maxpool_argmax(p[0], p[1], p[W], p[W + 1]);
+  if ((W & 1) == 0) {
+    *reinterpret_cast<float2*>(gx + base) = make_float2(k == 0 ? g : 0.f, k == 1 ? g : 0.f);
+    *reinterpret_cast<float2*>(gx + base + W) = make_float2(k == 2 ? g : 0.f, k == 3 ? g : 0.f);
+  } else {
+    gx[base] = k == 0 ? g : 0.f; gx[base + 1] = k == 1 ? g : 0.f;
+    gx[base + W] = k == 2 ? g : 0.f; gx[base + W + 1] = k == 3 ? g : 0.f;
+  }
+}
+
 __global__ void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int NC, int HW) {
   const int plane = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (plane >= NC) return;
@@ -562,6 +617,24 @@ extern "C" int sg_avgpool3s2_bwd(const float* gy, float* gx, int NC, int H, int 
   SG_ARG_CHECK(gy && gx, "sg_avgpool3s2_bwd: bad arguments");
   hipLaunchKernelGGL(avgpool3s2_bwd_kernel, grid1d((size_t)NC * H * W), dim3(256), 0, (hipStream_t)stream, gy, gx, NC, H, W, OH, OW);
   SG_LAUNCH_CHECK("sg_avgpool3s2_bwd");
+  return 0;
+}
+
+extern "C" int sg_maxpool2_fwd(const float* x, float* y, int NC, int H, int W, sgStream stream) {
+  SG_ARG_CHECK(x && y && NC > 0 && H >= 2 && W >= 2, "sg_maxpool2_fwd: bad arguments");
+  const int OH = H / 2, OW = W / 2;
+  SG_ARG_CHECK((double)NC * H * W < 2147483647.0 * 2, "sg_maxpool2_fwd: tensor too large");
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, grid1d((size_t)NC * OH * OW), dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, OH, OW);
+  SG_LAUNCH_CHECK("sg_maxpool2_fwd");
+  return 0;
+}
+
+extern "C" int sg_maxpool2_bwd(const float* x, const float* gy, float* gx, int NC, int H, int W, sgStream stream) {
+  SG_ARG_CHECK(x && gy && gx && NC > 0 && H >= 2 && W >= 2, "sg_maxpool2_bwd: bad arguments");
+  const int OH = H / 2, OW = W / 2;
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, grid1d((size_t)NC * ((H + 1) / 2) * ((W + 1) / 2)), dim3(256), 0, (hipStream_t)stream,
+                     x, gy, gx, NC, H, W, OH, OW);
+  SG_LAUNCH_CHECK("sg_maxpool2_bwd");
   return 0;
 }
 

@@ -164,15 +164,15 @@ class MultiscaleDiscriminator(nn.Module):
             model = [getattr(self, 'scale' + str(num_D - 1 - i) + '_layer' + str(j)) for j in range(self.n_layers + 2)]
             result.append(self.singleD_forward(model, a, b))
             if i != (num_D - 1):
-                f = getattr(a, '_sg_factored', None) if ops.FACTORED_LAYOUT else None
+                f = ops.hint(a, 'factored') if ops.FACTORED_LAYOUT else None
                 if f is not None and b is not None:
                     # pooling is linear: pool the planes of the factored form.  The first conv then never reads the dense
-                    # pooled layout, so it is not computed (placeholder with the right shape carries the hints)
+                    # pooled layout, so it is not computed: a storage-less placeholder of the right shape carries the hint
                     planes = self.downsample(f.Z)
-                    a_lo = a.new_empty((a.size(0), a.size(1)) + tuple(planes.shape[2:]))
-                    a_lo._sg_factored = f.with_planes(planes)
+                    a_lo = a.new_empty((1,)).expand((a.size(0), a.size(1)) + tuple(planes.shape[2:]))
+                    ops.set_hints(a_lo, factored=(f if a.requires_grad else f.detached()).with_planes(planes))
                 else:
-                    a_lo = ops.carry_hints(a, self.downsample(a))   # pooling keeps all-zero layout channels all-zero
+                    a_lo = ops.carry_hints(a, self.downsample(ops.ensure_dense(a)))   # pooling keeps zero channels zero
                 a = a_lo
                 b = self.downsample(b) if b is not None else None
         return result

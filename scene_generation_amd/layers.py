@@ -130,11 +130,15 @@ class Interpolate(nn.Module):
     def __init__(self, size=None, scale_factor=None, mode='nearest', align_corners=None):
         super().__init__()
         self.size, self.scale_factor, self.mode, self.align_corners = size, scale_factor, mode, align_corners
-        if not (size is None and scale_factor == 2 and mode == 'nearest'):
-            raise NotImplementedError('Interpolate: only nearest x2 has a HIP kernel')
+        self.hot = size is None and scale_factor == 2 and mode == 'nearest'
 
     def forward(self, x):
-        return ops.upsample2(x)
+        if self.hot:
+            return ops.upsample2(x)
+        # other modes only occur off the training path (scripts/inception_score.py:29 resizes to 299x299 bilinear for the
+        # evaluation network): plain torch on the device
+        return torch.nn.functional.interpolate(x, size=self.size, scale_factor=self.scale_factor, mode=self.mode,
+                                               align_corners=self.align_corners)
 
 
 class GlobalAvgPool(nn.Module):
@@ -147,6 +151,18 @@ class AvgPool3s2(nn.Module):
 
     def forward(self, x):
         return ops.avgpool3s2(x)
+
+
+class MaxPool2d(nn.Module):
+    """nn.MaxPool2d(kernel_size=2, stride=2) -- the only pooling the path uses (VGG19 of VGGLoss; build_cnn 'P2')."""
+
+    def __init__(self, kernel_size=2, stride=2):
+        super().__init__()
+        if int(kernel_size) != 2 or int(stride) != 2:
+            raise NotImplementedError('MaxPool2d: only kernel 2 / stride 2 has a HIP kernel')
+
+    def forward(self, x):
+        return ops.maxpool2(x)
 
 
 class Flatten(nn.Module):
@@ -170,7 +186,7 @@ class FusedSequential(nn.Sequential):
                 act, slope, used = _peek_act(mods, i + 2)
                 x = nxt(x, reflect_pad=m.padding, act=act, slope=slope)
                 i += 2 + used
-            elif isinstance(m, Interpolate) and isinstance(nxt, Conv2d):
+            elif isinstance(m, Interpolate) and m.hot and isinstance(nxt, Conv2d):
                 act, slope, used = _peek_act(mods, i + 2)
                 x = nxt(x, upsample=2, act=act, slope=slope)
                 i += 2 + used
@@ -238,8 +254,9 @@ def _get_padding(K, mode):
 
 def build_cnn(arch, normalization='batch', activation='relu', padding='same', pooling='max', init='default'):
     """Architecture-string CNN builder (layers.py:128-212) for the layer kinds the training path uses:
-    IX (input channels), CK-X[-S] (conv), UX (nearest upsample).  R/P/FC specs belong to model variants the
-    training path never builds and raise."""
+    IX (input channels), CK-X[-S] (conv), UX (nearest upsample), P2 (max pooling), FC-X-Y.  'R' (the reference's
+    ResidualBlock, which runs its body twice, layers.py:115-116) belongs to model variants the training path never builds
+    and raises."""
     if isinstance(arch, str):
         arch = arch.split(',')
     cur_C = 3
@@ -247,8 +264,9 @@ def build_cnn(arch, normalization='batch', activation='relu', padding='same', po
         cur_C = int(arch[0][1:])
         arch = arch[1:]
     first_conv = True
+    flat = False
     layers = []
-    for s in arch:
+    for i, s in enumerate(arch):
         if s[0] == 'C':
             if not first_conv:
                 layers.append(get_normalization_2d(cur_C, normalization))
@@ -261,6 +279,19 @@ def build_cnn(arch, normalization='batch', activation='relu', padding='same', po
             cur_C = next_C
         elif s[0] == 'U':
             layers.append(Interpolate(scale_factor=int(s[1:]), mode='nearest'))
+        elif s[0] == 'P':                                   # layers.py:181-189: 'P2' = 2x2 pooling, stride 2
+            if int(s[1:]) != 2 or pooling != 'max':
+                raise NotImplementedError('build_cnn pooling "%s" (%s): only max-pool 2 has a HIP kernel' % (s, pooling))
+            layers.append(MaxPool2d(2, 2))
+        elif s[:2] == 'FC':                                 # layers.py:190-199: flatten + Linear (+ activation unless last)
+            _, Din, Dout = s.split('-')
+            if not flat:
+                layers.append(Flatten())
+            flat = True
+            layers.append(Linear(int(Din), int(Dout)))
+            if i + 1 < len(arch):
+                layers.append(get_activation(activation))
+            cur_C = int(Dout)
         else:
             raise NotImplementedError('build_cnn layer "%s" is not on the MI355X training path' % s)
     layers = [l for l in layers if l is not None]

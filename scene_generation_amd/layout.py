@@ -48,7 +48,7 @@ def masks_to_layout(vecs, boxes, masks, obj_to_img, H, W=None, pooling='sum', te
                                     int(max_per_image))
     if grad_from_channel > 0:
         # backward only reads d out[:, grad_from_channel:]; consumers (the generator's first conv) may skip the rest
-        out._sg_grad_from = int(grad_from_channel)
+        ops.set_hints(out, grad_from=int(grad_from_channel))
     return out
 
 

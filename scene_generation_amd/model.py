@@ -71,10 +71,12 @@ class Model(nn.Module):
         self.layout_objects_hint = 0        # objects/image the layout kernel provisions LDS for (0 = default 12)
         self.objs_host = None               # optional host copies of ``objs`` / ``obj_to_img`` (lists): skip the one
         self.obj_to_img_host = None         # D2H copy per forward that VectorPool and the sparse first conv need
+        self.lazy_layouts = False           # defer the dense layout kernels until a dense read (see forward)
         self.rep_size = rep_size
 
     def forward(self, gt_imgs, objs, triples, obj_to_img, boxes_gt=None, masks_gt=None, attributes=None,
                 test_mode=False, use_gt_box=False, features=None):
+        ops.clear_hints()                        # layout hints of the previous iteration (and the tensors they pin)
         O = objs.size(0)
         objs_h, o2i_h = self.objs_host, self.obj_to_img_host
         if objs_h is None or o2i_h is None:      # one sync (the reference's pool does objs.tolist(), utils.py:104)
@@ -96,17 +98,25 @@ class Model(nn.Module):
             masks = masks_gt if masks_gt is not None else masks_pred
             pred_layout = masks_to_layout(scene_layout_vecs, boxes, masks, obj_to_img, H, W, test_mode=True,
                                           num_images=N, validate=False)
-            pred_layout._sg_sparse = tuple(
+            ops.set_hints(pred_layout, sparse=tuple(
                 to_device_async(torch.from_numpy(a), pred_layout.device)
-                for a in active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size))
+                for a in active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size)))
             return self.layout_to_image(pred_layout), boxes_pred, masks_pred, None, pred_layout, None
-        gt_layout = masks_to_layout(scene_layout_vecs, boxes_gt, masks_gt, obj_to_img, H, W, test_mode=False,
-                                    grad_from_channel=self.num_objs, **kw)
-        # pred_layout feeds no loss (train.py:203,219); back-propagating through its masks raises loudly
-        pred_layout = masks_to_layout(scene_layout_vecs, boxes_gt, masks_pred, obj_to_img, H, W,
-                                      test_mode=False, grad_from_channel=self.num_objs, **kw)
-        wrong_layout = masks_to_layout(wrong_layout_vecs, boxes_gt, masks_gt, obj_to_img, H, W, test_mode=False,
+        lazy = self.lazy_layouts and ops.FACTORED_LAYOUT
+        seg = ops.segment_offsets(obj_to_img, N)
+        if lazy:
+            # nothing on the training step reads the dense layouts (the convs over them run on the factored form): their
+            # kernels are deferred until a dense read (ops.ensure_dense; Trainer.step does it for the outputs it returns)
+            def layout_of(vecs, masks):
+                return ops.masks_to_layout_deferred(vecs, boxes_gt, masks, seg, N, H, W, False, self.layout_objects_hint)
+        else:
+            def layout_of(vecs, masks):
+                return masks_to_layout(vecs, boxes_gt, masks, obj_to_img, H, W, test_mode=False,
                                        grad_from_channel=self.num_objs, **kw)
+        gt_layout = layout_of(scene_layout_vecs, masks_gt)
+        # pred_layout feeds no loss (train.py:203,219); back-propagating through its masks raises loudly
+        pred_layout = layout_of(scene_layout_vecs, masks_pred)
+        wrong_layout = layout_of(wrong_layout_vecs, masks_gt)
         dev = gt_layout.device
         if not ops.FACTORED_LAYOUT:
             # per image only the one-hot planes of its own classes + the representation block are non-zero: the
@@ -117,8 +127,7 @@ class Model(nn.Module):
             sparse_img = tuple(to_device_async(torch.from_numpy(a), dev)
                                for a in active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size, extra=3))
             for lay in (gt_layout, pred_layout, wrong_layout):
-                lay._sg_sparse = sparse
-                lay._sg_sparse_cat = {3: sparse_img}
+                ops.set_hints(lay, sparse=sparse, sparse_cat={3: sparse_img})
         if ops.FACTORED_LAYOUT:
             # factored form of the two layouts that feed convolutions: planes S_o + per-object vectors (ops.FactoredLayout)
             counts = [0] * N
@@ -127,13 +136,13 @@ class Model(nn.Module):
                 plane.append(counts[i])
                 counts[i] += 1
             pidx = to_device_async(torch.tensor(plane, dtype=torch.int64), dev)
-            Z = ops.layout_planes(boxes_gt, masks_gt, ops.segment_offsets(obj_to_img, N), pidx, N, max(counts), H, W)
-            R = self.rep_size
-            gt_layout._sg_factored = ops.FactoredLayout(Z, objs, scene_layout_vecs[:, self.num_objs:], self.num_objs,
-                                                        obj_to_img, pidx, counts)
-            wrong_layout._sg_factored = ops.FactoredLayout(Z, objs, wrong_layout_vecs[:, self.num_objs:].detach(),
-                                                           self.num_objs, obj_to_img, pidx, counts)
-            wrong_layout._sg_factored._lists = gt_layout._sg_factored._lists          # same objects: share the list cache
+            Z = ops.layout_planes(boxes_gt, masks_gt, seg, pidx, N, max(counts), H, W)
+            f_gt = ops.FactoredLayout(Z, objs, scene_layout_vecs[:, self.num_objs:], self.num_objs, obj_to_img, pidx, counts)
+            f_wrong = ops.FactoredLayout(Z, objs, wrong_layout_vecs[:, self.num_objs:].detach(), self.num_objs, obj_to_img,
+                                         pidx, counts)
+            f_wrong._lists = f_gt._lists          # same objects: share the list cache
+            ops.set_hints(gt_layout, factored=f_gt, keep_grad=lazy)
+            ops.set_hints(wrong_layout, factored=f_wrong)
         imgs_pred = self.layout_to_image(gt_layout)
         return imgs_pred, boxes_pred, masks_pred, gt_layout, pred_layout, wrong_layout
 

@@ -15,7 +15,8 @@ from . import _hip
 from ._hip import sgConvDesc
 
 ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
-LOSS_MSE_CONST, LOSS_MSE, LOSS_L1, LOSS_BCE_CONST = 0, 1, 2, 3
+LOSS_MSE_CONST, LOSS_MSE, LOSS_L1, LOSS_BCE_CONST, LOSS_MEAN, LOSS_MSE_SIGMOID_CONST, LOSS_BCE_PROB_CONST = range(7)
+WSUM_MAX = 32
 
 _ws_cache = {}
 
@@ -83,6 +84,68 @@ def _call(name, *args):
     rc = fn(*args)
     if rc != 0:
         raise RuntimeError('%s failed (rc=%d): %s' % (name, rc, _hip.last_error()))
+
+
+# =============================================================================================
+# parameter-gradient sinks
+# =============================================================================================
+# A parameter owned by a FusedAdam lives in a flat buffer and so does its gradient (optim.FlatParams).  Returning a
+# gradient tensor from backward makes autograd ADD it into that slice with one ATen launch per parameter per backward
+# (~300 launches and 3 passes over the 765 MB generator gradient per step).  Instead the weight-gradient kernels write
+# straight into the slice: the first contribution after zero_grad() overwrites (the slice is zero), later ones go through a
+# temporary + sg_axpy.  backward then returns None for that input and notifies the optimiser (touched flag, DP reducer).
+_SINKS = {}
+
+
+class ParamSink(object):
+    __slots__ = ('opt', 'i', 'view', 'ptr')
+
+    def __init__(self, opt, i):
+        import weakref
+        self.opt, self.i = weakref.ref(opt), i
+        self.view = opt.fp.grad_view(i)
+        self.ptr = opt.fp.params[i].data_ptr()
+
+
+def register_param_sinks(opt):
+    for i, p in enumerate(opt.fp.params):
+        _SINKS[p.data_ptr()] = ParamSink(opt, i)
+
+
+def _sink_of(param):
+    if not _SINKS or param is None:
+        return None
+    sk = _SINKS.get(param.data_ptr())
+    if sk is None:
+        return None
+    opt = sk.opt()
+    if opt is None or opt.fp.params[sk.i].data_ptr() != sk.ptr or tuple(sk.view.shape) != tuple(param.shape):
+        del _SINKS[param.data_ptr()]           # the optimiser is gone (its flat buffer may have been re-used)
+        return None
+    return sk
+
+
+class GradOut(object):
+    """where the gradient of ``param`` goes: ``buf`` is what the kernel writes; ``finish()`` is what backward returns"""
+    __slots__ = ('sink', 'buf', 'mode')
+
+    def __init__(self, param):
+        sk = self.sink = _sink_of(param)
+        if sk is None:
+            self.buf, self.mode = torch.empty_like(param), 2
+        elif not sk.opt()._touched[sk.i]:
+            self.buf, self.mode = sk.view, 0               # first contribution since zero_grad(): write in place
+        else:
+            self.buf, self.mode = torch.empty_like(param), 1
+
+    def finish(self):
+        if self.mode == 2:
+            return self.buf
+        sk = self.sink
+        if self.mode == 1:
+            _call('sg_axpy', _p(sk.view), _p(self.buf), 1.0, self.buf.numel(), _stream())
+        sk.opt()._on_grad(sk.i)
+        return None
 
 
 # =============================================================================================
@@ -159,12 +222,16 @@ class Conv2dFn(Function):
                   _stream())
         ctx.desc = d
         ctx.sparse = sparse
+        ctx.bias_ref = bias          # only its identity is used (gradient sink / skip list), never its values
+        ctx.set_materialize_grads(False)
         ctx.cfg = (act, slope, bias is not None, int(grad_from))
         ctx.save_for_backward(x1, x2, weight, y if act != ACT_NONE else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:
+            return (None,) * 12
         x1, x2, weight, y = ctx.saved_tensors
         d = ctx.desc
         act, slope, has_bias, grad_from = ctx.cfg
@@ -176,7 +243,7 @@ class Conv2dFn(Function):
             gy = g2
         need_x1, need_x2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and x2 is not None
         need_w = ctx.needs_input_grad[2] and _wants_grad(weight)
-        need_b = has_bias and ctx.needs_input_grad[3] and need_w
+        need_b = has_bias and ctx.needs_input_grad[3] and _wants_grad(ctx.bias_ref)
         gx1 = gx2 = gw = gb = None
         dev = gy.device
         if need_x1 or need_x2:
@@ -221,9 +288,11 @@ class Conv2dFn(Function):
                     _call('sg_gap_fwd', _p(gx2), _p(red), d.N * d.C2, d.H * d.W, s)
                     gx2 = scale_(red, float(d.H * d.W))
         if need_w or need_b:
+            ow = GradOut(weight) if need_w else None
+            ob = GradOut(ctx.bias_ref) if need_b else None
             if need_w:
-                gw = torch.empty_like(weight)
-                gb = torch.empty(d.Cout, dtype=torch.float32, device=dev) if need_b else None
+                gw = ow.buf
+                gb = ob.buf if need_b else None
                 if ctx.wino:
                     wsb = max(_q(d, 'sg_conv2d_wino_ws_bytes'), _L().sg_channel_sum_ws_bytes(d.Cout))
                     ws = workspace(wsb, dev)
@@ -248,10 +317,12 @@ class Conv2dFn(Function):
                     ws = workspace(wsb, dev)
                     _call('sg_conv2d_wgrad', d._ref, _p(gy), _p(x1), _p(x2), _p(gw), _p(gb), _p(ws), wsb, s)
             else:
-                gb = torch.empty(d.Cout, dtype=torch.float32, device=dev)
+                gb = ob.buf
                 wsb = _L().sg_channel_sum_ws_bytes(d.Cout)
                 ws = workspace(wsb, dev)
                 _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb, s)
+            gw = ow.finish() if need_w else None
+            gb = ob.finish() if need_b else None
         return gx1, gx2, gw, gb, None, None, None, None, None, None, None, None
 
 
@@ -280,40 +351,87 @@ def _wants_grad(t):
     return t is not None and t.data_ptr() not in _SKIP_PARAM_GRADS
 
 
-_HINTS = ('_sg_sparse', '_sg_sparse_cat', '_sg_grad_from', '_sg_factored')
+# ---- layout hints -------------------------------------------------------------------------------------
+# What the model knows about a masks_to_layout() result -- which channels can be non-zero per image ('sparse',
+# 'sparse_cat'), that the one-hot block is a constant of the graph ('grad_from'), its factored form ('factored'), whether
+# the dense tensor has been written yet ('pending') -- lives in a side table keyed by the tensor's storage address, NOT in
+# Python attributes: the reference's training loop passes ``layout.detach()`` around (train.py:208-215) and a plain
+# ``.detach()`` keeps the storage but drops attributes.  An entry holds a strong reference to its tensor, so the address
+# cannot be recycled while the entry exists; Model.forward clears the table at the start of every iteration.
+_HINT_TABLE = {}
+_HINT_KEYS = ('sparse', 'sparse_cat', 'grad_from', 'factored', 'keep_grad', 'pending')
+
+
+def clear_hints():
+    _HINT_TABLE.clear()
+
+
+def set_hints(t, **kw):
+    e = _HINT_TABLE.get(t.data_ptr())
+    if e is None or tuple(e[0].shape) != tuple(t.shape):
+        e = _HINT_TABLE[t.data_ptr()] = (t, {})
+    e[1].update(kw)
+    return t
+
+
+def hints_of(t):
+    if not _HINT_TABLE:
+        return None
+    e = _HINT_TABLE.get(t.data_ptr())
+    if e is None or tuple(e[0].shape) != tuple(t.shape) or e[0].stride() != t.stride():
+        return None
+    return e[1]
+
+
+def hint(t, key, default=None):
+    h = hints_of(t)
+    return default if h is None else h.get(key, default)
 
 
 def carry_hints(src, dst, grad_from=False):
     """copy the layout hints (per-image active channels, constant channel block) to a tensor derived from ``src`` by an
-    op that keeps all-zero channels all-zero (detach, average pooling)"""
-    for k in _HINTS:
-        if (k != '_sg_grad_from' or grad_from) and hasattr(src, k):
-            setattr(dst, k, getattr(src, k))
+    op that keeps all-zero channels all-zero (average pooling)"""
+    h = hints_of(src)
+    if h:
+        set_hints(dst, **{k: v for k, v in h.items() if k != 'pending' and (k != 'grad_from' or grad_from)})
     return dst
 
 
 def detach_keep(t):
-    d = carry_hints(t, t.detach(), grad_from=True)
-    if hasattr(d, '_sg_factored'):
-        d._sg_factored = d._sg_factored.detached()       # no gradient reaches the appearance vectors through it either
-    return d
+    """``t.detach()``: the hints follow the storage (kept for callers of the round-1 API)"""
+    return t.detach()
+
+
+def ensure_dense(t):
+    """run the deferred masks_to_layout launch of a lazily built layout (Model.lazy_layouts) before a dense read"""
+    h = hints_of(t)
+    if h and h.get('pending') is not None:
+        fill = h.pop('pending')
+        fill()
+    return t
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, upsample=1, act=ACT_NONE, slope=0.0, x2=None):
-    """``x._sg_grad_from = c`` (set by masks_to_layout) promises that nobody needs d/dx[:, :c]: the data gradient is then
-    only computed for channels >= c (the rest is returned as zeros).  ``x._sg_sparse = (chan_list, chan_cnt)`` (set by the
-    model next to the layout) promises that, per image, every channel outside the list is all-zero: forward and weight
-    gradient then only visit the listed channels (sg_conv2d_*_sparse)."""
-    f = getattr(x, '_sg_factored', None) if FACTORED_LAYOUT else None
+    """Layout hints (see the table above): 'grad_from' = c promises that nobody needs d/dx[:, :c] (the data gradient is
+    then only computed for channels >= c, the rest is returned as zeros); 'sparse' = (chan_list, chan_cnt) promises that,
+    per image, every channel outside the list is all-zero (forward and weight gradient then only visit the listed
+    channels, sg_conv2d_*_sparse); 'factored' = the layout as planes x per-object vectors (factored_layout_conv)."""
+    h = hints_of(x)
+    if h is None:
+        return Conv2dFn.apply(x, x2, weight, bias, stride, pad, reflect, upsample, act, float(slope), 0, None)
+    f = h.get('factored') if FACTORED_LAYOUT else None
     if f is not None and upsample == 1 and (x2 is None or (x2.dim() == 4 and not reflect)):
+        if not (x.requires_grad or h.get('keep_grad')):     # a detached layout: no gradient reaches the appearance
+            f = f.detached()                                # vectors through its factored form either
         return factored_layout_conv(f, weight, bias, stride, pad, reflect, act, slope, x2)
-    grad_from = int(getattr(x, '_sg_grad_from', 0))
+    ensure_dense(x)
+    grad_from = int(h.get('grad_from', 0)) if x.requires_grad else 0
     if not (0 < grad_from < x.size(1)):
         grad_from = 0
     if x2 is None:
-        sparse = getattr(x, '_sg_sparse', None)
+        sparse = h.get('sparse')
     else:          # channel-concatenated second source (the image next to the layout): lists that include its channels
-        sparse = getattr(x, '_sg_sparse_cat', {}).get(x2.size(1)) if x2.dim() == 4 else None
+        sparse = h.get('sparse_cat', {}).get(x2.size(1)) if x2.dim() == 4 else None
     if sparse is not None and not (2 * sparse[0].size(1) <= x.size(1)):
         sparse = None                      # not sparse enough to pay for the per-image weight compaction
     return Conv2dFn.apply(x, x2, weight, bias, stride, pad, reflect, upsample, act, float(slope), grad_from, sparse)
@@ -337,12 +455,15 @@ class ConvTranspose2dFn(Function):
         ws = workspace(wsb, x.device)
         _call('sg_convT2d_fwd', d._ref, _p(x), _p(weight), _p(bias), _p(y), _p(ws), wsb, _stream())
         ctx.desc = d
-        ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, weight)
         return y
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:
+            return (None,) * 6
         x, weight = ctx.saved_tensors
         d = ctx.desc
         gy = _f32(gy)
@@ -353,18 +474,20 @@ class ConvTranspose2dFn(Function):
             wsb = _q(d, 'sg_conv2d_ws_bytes', 1)
             ws = workspace(wsb, gy.device)
             _call('sg_convT2d_dgrad', d._ref, _p(gy), _p(weight), _p(gx), _p(ws), wsb, s)
-        need_b = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
+        need_w = ctx.needs_input_grad[1] and _wants_grad(weight)
+        need_b = ctx.bias_ref is not None and ctx.needs_input_grad[2] and _wants_grad(ctx.bias_ref)
+        ow = GradOut(weight) if need_w else None
+        ob = GradOut(ctx.bias_ref) if need_b else None
+        if need_w:
             wsb = _q(d, 'sg_conv2d_ws_bytes', 2)
             ws = workspace(wsb, gy.device)
-            gw = torch.empty_like(weight)
-            gb = torch.empty(d.Cout, dtype=torch.float32, device=gy.device) if need_b else None
-            _call('sg_convT2d_wgrad', d._ref, _p(gy), _p(x), _p(gw), _p(gb), _p(ws), wsb, s)
+            _call('sg_convT2d_wgrad', d._ref, _p(gy), _p(x), _p(ow.buf), _p(ob.buf) if need_b else None, _p(ws), wsb, s)
         elif need_b:
-            gb = torch.empty(d.Cout, dtype=torch.float32, device=gy.device)
             wsb = _L().sg_channel_sum_ws_bytes(d.Cout)
             ws = workspace(wsb, gy.device)
-            _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb, s)
+            _call('sg_channel_sum', _p(gy), _p(ob.buf), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb, s)
+        gw = ow.finish() if need_w else None
+        gb = ob.finish() if need_b else None
         return gx, gw, gb, None, None, None
 
 
@@ -390,11 +513,15 @@ class LinearFn(Function):
         if rows > 0:
             _call('sg_linear_fwd', _p(x), _p(weight), _p(bias), _p(y), rows, in_f, out_f, act, slope, _stream())
         ctx.cfg = (act, slope, bias is not None)
+        ctx.bias_ref = bias
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:
+            return (None,) * 5
         x, weight, y = ctx.saved_tensors
         act, slope, has_bias = ctx.cfg
         gy = _f32(gy)
@@ -412,14 +539,16 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             _call('sg_linear_bwd_data', _p(gy), _p(weight), _p(gx), rows, in_f, out_f, s)
-        need_b = has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
-            gw = torch.empty_like(weight)
-            gb = torch.empty(out_f, dtype=torch.float32, device=x.device) if need_b else None
-            _call('sg_linear_bwd_weight', _p(gy), _p(x), _p(gw), _p(gb), rows, in_f, out_f, s)
+        need_w = ctx.needs_input_grad[1] and _wants_grad(weight)
+        need_b = has_bias and ctx.needs_input_grad[2] and _wants_grad(ctx.bias_ref)
+        ow = GradOut(weight) if need_w else None
+        ob = GradOut(ctx.bias_ref) if need_b else None
+        if need_w:
+            _call('sg_linear_bwd_weight', _p(gy), _p(x), _p(ow.buf), _p(ob.buf) if need_b else None, rows, in_f, out_f, s)
         elif need_b:
-            gb = torch.empty(out_f, dtype=torch.float32, device=x.device)
-            _call('sg_channel_sum', _p(gy), _p(gb), rows, out_f, 1, None, 0, s)
+            _call('sg_channel_sum', _p(gy), _p(ob.buf), rows, out_f, 1, None, 0, s)
+        gw = ow.finish() if need_w else None
+        gb = ob.finish() if need_b else None
         return gx, gw, gb, None, None
 
 
@@ -503,21 +632,30 @@ class BatchNormFn(Function):
         _call('sg_batchnorm_fwd', _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(rmean), _p(rvar), _p(nbt),
               N, C, HW, eps, momentum, 1 if training else 0, act, slope, _p(workspace(wsb, x.device)), wsb, _stream())
         ctx.cfg = (N, C, HW, act, slope, 1 if training else 0)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(x, gamma, beta, mean, rstd)
         return y
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:
+            return (None,) * 11
         x, gamma, beta, mean, rstd = ctx.saved_tensors
         N, C, HW, act, slope, training = ctx.cfg
         gy = _f32(gy)
         gx = torch.empty_like(x)
-        gg = torch.empty(C, dtype=torch.float32, device=x.device) if gamma is not None else None
-        gb = torch.empty(C, dtype=torch.float32, device=x.device) if beta is not None else None
+        # the kernel produces both affine gradients in one pass; skipped parameters get scratch outputs that are dropped
+        want_g = gamma is not None and ctx.needs_input_grad[1] and _wants_grad(gamma)
+        want_b = beta is not None and ctx.needs_input_grad[2] and _wants_grad(beta)
+        og = GradOut(gamma) if want_g else None
+        ob = GradOut(beta) if want_b else None
+        gg = og.buf if want_g else (torch.empty(C, dtype=torch.float32, device=x.device) if gamma is not None else None)
+        gb = ob.buf if want_b else (torch.empty(C, dtype=torch.float32, device=x.device) if beta is not None else None)
         wsb = _L().sg_batchnorm_ws_bytes(N, C, HW)
         _call('sg_batchnorm_bwd', _p(x), _p(gy), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(gx), _p(gg), _p(gb), N, C, HW,
               training, act, slope, _p(workspace(wsb, x.device)), wsb, _stream())
-        return gx, gg, gb, None, None, None, None, None, None, None, None
+        return (gx, og.finish() if want_g else None, ob.finish() if want_b else None, None, None, None, None, None, None,
+                None, None)
 
 
 def batch_norm(x, gamma, beta, rmean, rvar, nbt, training, momentum=0.1, eps=1e-5, act=ACT_NONE, slope=0.0):
@@ -548,6 +686,32 @@ class AvgPool3s2Fn(Function):
 
 def avgpool3s2(x):
     return AvgPool3s2Fn.apply(x)
+
+
+class MaxPool2Fn(Function):
+    """nn.MaxPool2d(2, 2) (VGG19 feature extractor of VGGLoss, losses.py:183-198)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32(x)
+        N, C, H, W = x.shape
+        y = torch.empty(N, C, H // 2, W // 2, dtype=torch.float32, device=x.device)
+        _call('sg_maxpool2_fwd', _p(x), _p(y), N * C, H, W, _stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, = ctx.saved_tensors
+        gy = _f32(gy)
+        N, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        _call('sg_maxpool2_bwd', _p(x), _p(gy), _p(gx), N * C, H, W, _stream())
+        return gx
+
+
+def maxpool2(x):
+    return MaxPool2Fn.apply(x)
 
 
 class GapFn(Function):
@@ -710,16 +874,19 @@ class EmbeddingFn(Function):
         out = torch.empty(idx.numel(), table.size(1), dtype=torch.float32, device=table.device)
         _call('sg_embedding_fwd', _p(table), _p(idx), _p(out), idx.numel(), table.size(1), _stream())
         ctx.rows = table.size(0)
-        ctx.save_for_backward(idx)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(idx, table)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        idx, = ctx.saved_tensors
+        idx, table = ctx.saved_tensors
+        if g is None or not (ctx.needs_input_grad[0] and _wants_grad(table)):
+            return None, None
         g = _f32(g)
-        gt = torch.empty(ctx.rows, g.size(1), dtype=torch.float32, device=g.device)
-        _call('sg_embedding_bwd', _p(g), _p(idx), _p(gt), idx.numel(), ctx.rows, g.size(1), _stream())
-        return gt, None
+        ot = GradOut(table)
+        _call('sg_embedding_bwd', _p(g), _p(idx), _p(ot.buf), idx.numel(), ctx.rows, g.size(1), _stream())
+        return ot.finish(), None
 
 
 def embedding(table, idx):
@@ -838,6 +1005,25 @@ class MasksToLayoutFn(Function):
         return gv, None, None, None, None, None, None, None, None, None
 
 
+def masks_to_layout_deferred(vecs, boxes, masks, seg_off, N, H, W, avg, max_per_image):
+    """An (N, D, H, W) layout whose sg_masks_to_layout_fwd launch is DEFERRED until somebody reads it densely
+    (ensure_dense): with the factored layout convs nothing on the training step does -- the three dense 428 MB layouts of
+    model.py:119-121 are outputs for logging only (train.py:201-203,219).  No autograd history: gradients reach the
+    appearance vectors through the factored form."""
+    vecs, boxes = _f32(vecs.detach(), 'vecs'), _f32(boxes.detach(), 'boxes')
+    masks = _dev(masks.detach(), 'masks')
+    if masks.dtype not in (torch.int64, torch.float32):
+        raise TypeError('masks must be int64 or float32')
+    masks = masks if masks.is_contiguous() else masks.contiguous()
+    O, D = vecs.shape
+    out = torch.empty(N, D, H, W, dtype=torch.float32, device=vecs.device)
+
+    def fill():
+        _call('sg_masks_to_layout_fwd', _p(vecs), _p(boxes), _p(masks), 1 if masks.dtype == torch.int64 else 0, _p(seg_off),
+              _p(out), N, O, D, masks.size(1), H, W, 1 if avg else 0, max_per_image, _stream())
+    return set_hints(out, pending=fill)
+
+
 def masks_to_layout_test(vecs, boxes, masks, seg_off, N, H, W, avg):
     """test-mode compositing (layout.py:87-92,157-169); inference only, returns a tensor without history."""
     if torch.is_grad_enabled() and (vecs.requires_grad or masks.requires_grad or boxes.requires_grad):
@@ -881,6 +1067,8 @@ class FactoredLayout(object):
         self._lists = {}
 
     def detached(self):
+        if not self.repr.requires_grad:
+            return self
         f = FactoredLayout(self.Z, self.objs, self.repr.detach(), self.num_objs, self.img_idx, self.plane_idx,
                            self.counts_host)
         f._lists = self._lists
@@ -934,12 +1122,16 @@ class PerImageConvFn(Function):
         _call('sg_conv2d_fwd_perimage', d._ref, _p(planes), None, _p(wimg), _p(bias), _p(clist), _p(ccnt), L, _p(y),
               act, slope, _p(workspace(wsb, planes.device)), wsb, _stream())
         ctx.desc, ctx.L = d, L
+        ctx.bias_ref = bias
+        ctx.set_materialize_grads(False)
         ctx.cfg = (act, slope, bias is not None, int(cfull), 0 if x2 is None else x2.size(1), stride, pad, reflect)
         ctx.save_for_backward(planes, clist, ccnt, w_full, y if act != ACT_NONE else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:
+            return (None,) * 13
         planes, clist, ccnt, w_full, y = ctx.saved_tensors
         d, L = ctx.desc, ctx.L
         act, slope, has_bias, cfull, C2, stride, pad, reflect = ctx.cfg
@@ -958,10 +1150,11 @@ class PerImageConvFn(Function):
             wsb = _q(d, 'sg_conv2d_sparse_ws_bytes', L, 2)
             _call('sg_conv2d_wgrad_perimage', d._ref, _p(gy), _p(planes), None, _p(clist), _p(ccnt), L, _p(gwimg),
                   _p(workspace(wsb, dev)), wsb, s)
-        if has_bias and ctx.needs_input_grad[3] and want_w:
-            gb = torch.empty(d.Cout, dtype=torch.float32, device=dev)
+        if has_bias and ctx.needs_input_grad[3] and _wants_grad(ctx.bias_ref):
+            ob = GradOut(ctx.bias_ref)
             wsb = _L().sg_channel_sum_ws_bytes(d.Cout)
-            _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(workspace(wsb, dev)), wsb, s)
+            _call('sg_channel_sum', _p(gy), _p(ob.buf), d.N, d.Cout, d.OH * d.OW, _p(workspace(wsb, dev)), wsb, s)
+            gb = ob.finish()
         if C2 and ctx.needs_input_grad[1]:
             # same conv seen with its full channel layout [layout channels | x2]: only the x2 slice is differentiated
             if reflect:
@@ -984,6 +1177,11 @@ def factored_layout_conv(f, weight, bias, stride, pad, reflect, act, slope, x2):
     assert Ctot == cfull + C2, 'weight has %d input channels, layout %d + second source %d' % (Ctot, cfull, C2)
     N = f.Z.size(0)
     clist, ccnt, extra_pos, L = f.lists(C2)
+    w_full = weight
+    if not _wants_grad(weight):
+        # a discriminator inside the generator step (skip_param_grads): no gradient may reach the parameter through the
+        # per-image filters either -- otherwise its AccumulateGrad (and the DP reducer hook) fires with a zero gradient
+        weight = weight.detach()
     # per-object filters  W_eff[o] = W[:, class_o] + sum_d repr[o, d] W[:, num_objs + d]      -> [O, M * KS2]
     table = weight[:, :f.num_objs].permute(1, 0, 2, 3).reshape(f.num_objs, M * KS2).contiguous()
     w_rep = weight[:, f.num_objs:cfull].permute(0, 2, 3, 1).reshape(M * KS2, R)
@@ -997,7 +1195,7 @@ def factored_layout_conv(f, weight, bias, stride, pad, reflect, act, slope, x2):
     wimg = torch.zeros(N, L, M, KS2, dtype=torch.float32, device=weight.device).index_put((rows, cols), vals)
     wimg = wimg.permute(0, 2, 1, 3).reshape(N, M, L, KS, KS).contiguous()
     planes = f.Z if x2 is None else torch.cat([f.Z, x2.detach()], 1)
-    return PerImageConvFn.apply(planes, x2, wimg, bias, clist, ccnt, weight.detach(), cfull, stride, pad, reflect, act,
+    return PerImageConvFn.apply(planes, x2, wimg, bias, clist, ccnt, w_full.detach(), cfull, stride, pad, reflect, act,
                                 float(slope))
 
 
@@ -1080,6 +1278,54 @@ def l1(a, b):
 def bce_logits_const(x, target):
     """bce_loss(x, full_like(x, target)) (losses.py:26-44)."""
     return ScalarLossFn.apply(x, None, LOSS_BCE_CONST, float(target), 1.0 / x.numel())
+
+
+def mean(x):
+    """x.mean() as a 0-dim device tensor (wgan losses, losses.py:93-112)"""
+    return ScalarLossFn.apply(x, None, LOSS_MEAN, 0.0, 1.0 / x.numel())
+
+
+def mse_sigmoid_const(x, target):
+    """F.mse_loss(x.sigmoid(), full_like(x, target)) (lsgan losses, losses.py:115-132)"""
+    return ScalarLossFn.apply(x, None, LOSS_MSE_SIGMOID_CONST, float(target), 1.0 / x.numel())
+
+
+def bce_prob_const(x, target):
+    """nn.BCELoss()(x, full_like(x, target)) on probabilities (GANLoss(use_lsgan=False), losses.py:147)"""
+    return ScalarLossFn.apply(x, None, LOSS_BCE_PROB_CONST, float(target), 1.0 / x.numel())
+
+
+class WeightedSumFn(Function):
+    """sum_i w_i * t_i over 0-dim device tensors as ONE launch (and one for the backward): LossManager's running
+    ``total_loss += loss * weight`` (utils.py:50-57) and the per-scale sums of GANLoss / calculate_features_loss."""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        n = len(terms)
+        terms = [_f32(t, 'loss term') for t in terms]
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in terms])
+        w = (ctypes.c_float * n)(*weights)
+        out = torch.empty(1, dtype=torch.float32, device=terms[0].device)
+        _call('sg_weighted_sum_fwd', ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(w, ctypes.c_void_p), n, _p(out), _stream())
+        ctx.w, ctx.n = w, n
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        gout = _f32(gout.reshape(1))
+        g = torch.empty(ctx.n, dtype=torch.float32, device=gout.device)
+        _call('sg_weighted_sum_bwd', ctypes.cast(ctx.w, ctypes.c_void_p), ctx.n, _p(gout), _p(g), _stream())
+        return (None,) + tuple(g[i] if ctx.needs_input_grad[1 + i] else None for i in range(ctx.n))
+
+
+def weighted_sum(tensors, weights):
+    """sum_i weights[i] * tensors[i] for 0-dim device tensors (chunks of <= 32 terms per launch)"""
+    tensors = [t.reshape(()) for t in tensors]
+    weights = [float(w) for w in weights]
+    while len(tensors) > WSUM_MAX:
+        head = WeightedSumFn.apply(tuple(weights[:WSUM_MAX]), *tensors[:WSUM_MAX])
+        tensors, weights = [head] + tensors[WSUM_MAX:], [1.0] + weights[WSUM_MAX:]
+    return WeightedSumFn.apply(tuple(weights), *tensors)
 
 
 class CrossEntropyFn(Function):

@@ -61,7 +61,7 @@ class FusedAdam:
     (trainer.py:210-216).  "Received a gradient" is tracked with post-accumulate-grad hooks; step() launches the fused
     kernel once per maximal run of adjacent active parameters that share a step count (normally one launch)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, direct_grads=True):
         self.fp = FlatParams(params)
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.exp_avg = torch.zeros_like(self.fp.flat)
@@ -70,13 +70,24 @@ class FusedAdam:
         self.steps = [0] * n
         self._touched = [False] * n
         self.pre_step_hooks = []          # e.g. GradReducer.wait
+        self.zero_grad_hooks = []         # e.g. GradReducer.begin_step
+        self.grad_listeners = []          # callables(i): parameter i just received (a contribution to) its gradient
         for i, p in enumerate(self.fp.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
+        if direct_grads and self.fp.flat.is_cuda:
+            # backward kernels write parameter gradients straight into the flat buffer (ops.ParamSink) instead of
+            # returning a tensor that autograd then adds into it with one ATen launch per parameter
+            ops.register_param_sinks(self)
 
     def _make_hook(self, i):
         def hook(param):
-            self._touched[i] = True
+            self._on_grad(i)
         return hook
+
+    def _on_grad(self, i):
+        self._touched[i] = True
+        for f in self.grad_listeners:
+            f(i)
 
     @property
     def step_count(self):
@@ -91,6 +102,8 @@ class FusedAdam:
         ops.fill_(self.fp.grad, 0.0)
         self.fp.attach_grads()
         self._touched = [False] * len(self.fp.params)
+        for h in self.zero_grad_hooks:
+            h()
 
     def mark_all_touched(self):
         """for callers that write gradients directly into the flat buffer (tests, custom reducers)"""

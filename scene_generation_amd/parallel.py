@@ -4,8 +4,10 @@ xGMI on ROCm), gradients averaged with bucketed all-reduces over slices of each 
 
 The batched scene graph is block-diagonal (node ids are offset per image, coco.py:527-529), so the minibatch shards
 by image with no data-path exchange (synthetic.shard_batch); the only collective is the gradient mean.  What is
-NOT exchanged -- BatchNorm batch statistics, VectorPool contents, the noise row / use_gt coin -- is per rank, i.e.
-the semantics are "the reference run independently on each shard, gradients averaged" (SURVEY 8e).
+NOT exchanged -- BatchNorm batch statistics, VectorPool contents, the noise row -- is per rank, i.e. the semantics
+are "the reference run independently on each shard, gradients averaged" (SURVEY 8e).  The use_gt coin (train.py:195)
+decides which parameters receive gradients, so it is drawn once per step on rank 0 and broadcast (Trainer.draw_use_gt);
+as a second line of defence the reducer ORs the optimisers' "received a gradient" flags across ranks.
 
 xGMI note: collectives are per-link bound (7 links x ~153 GB/s), so buckets are LARGE (default 64 MB): a few big
 reduce-scatter/all-gather rings amortise the per-collective latency; the 764.7 MB generator gradient is ~12 buckets.
@@ -36,16 +38,25 @@ class GradReducer:
     """Mean all-reduce of one FlatParams gradient buffer, bucketed + overlapped with backward.
 
     Buckets are contiguous slices of the flat gradient in REVERSE parameter order (gradients become ready roughly
-    last-layer-first).  A post-accumulate-grad hook per parameter counts readiness; when a bucket is complete its
-    async all-reduce is issued immediately.  ``wait()`` (called before optimizer.step) flushes stragglers --
-    parameters that received no gradient this step still hold zeros, which is what the all-reduce must see.
+    last-layer-first).  The reducer is ARMED by the owning optimiser's ``zero_grad()`` (``begin_step``) and disarmed by
+    ``wait()``: gradient hooks that fire outside that window -- e.g. a discriminator parameter touched by the
+    generator's backward -- are ignored, and a parameter counts once per step no matter how often its hook fires
+    (per-parameter ready flags, not a counter).  When the last parameter of a bucket has reported, the bucket's async
+    all-reduce is issued immediately; ``wait()`` (called before optimizer.step) launches the remaining buckets IN
+    BUCKET ORDER (identical on every rank, whatever subset of parameters each rank touched), waits, and scales by
+    1/world.  Parameters that received no gradient this step still hold zeros, which is what the all-reduce must see.
+
+    ``touched`` (optional, a callable returning / accepting the optimiser's per-parameter "received a gradient" flags):
+    after the reduce, the flags are OR-ed across ranks so that every rank updates the same set of parameters (Adam
+    skips gradient-less parameters; ranks that disagree would silently diverge).
     """
 
-    def __init__(self, flat_params, bucket_bytes=64 << 20, group=None, overlap=True):
+    def __init__(self, flat_params, bucket_bytes=64 << 20, group=None, overlap=True, optimizer=None):
         self.fp = flat_params
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.overlap = overlap
+        self.optimizer = optimizer
         self.buckets = []            # (start, end, [param indices])
         esz = self.fp.grad.element_size()
         cur, cur_end = [], None
@@ -63,24 +74,39 @@ class GradReducer:
         for b, (_, _, idxs) in enumerate(self.buckets):
             for i in idxs:
                 self.bucket_of[i] = b
-        self._pending = [len(idxs) for _, _, idxs in self.buckets]
-        self._launched = [False] * len(self.buckets)
-        self._works = []
         self.active = True
+        self.armed = False
+        self._reset()
         if self.world > 1 and overlap:
             for i, p in enumerate(self.fp.params):
                 if p.requires_grad:
                     p.register_post_accumulate_grad_hook(self._make_hook(i))
 
+    def _reset(self):
+        self._ready = [False] * len(self.fp.params)
+        self._pending = [len(idxs) for _, _, idxs in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+
+    def begin_step(self):
+        """arm the reducer for the backward that follows (called from the owning optimiser's zero_grad())"""
+        self._reset()
+        self.armed = True
+
     def _make_hook(self, i):
         def hook(param):
-            if not self.active or not param.requires_grad:
-                return
-            b = self.bucket_of[i]
-            self._pending[b] -= 1
-            if self._pending[b] == 0 and not self._launched[b]:
-                self._launch(b)
+            self.param_ready(i)
         return hook
+
+    def param_ready(self, i):
+        """parameter ``i`` has its final gradient for this step (autograd hook, or ops.deliver_param_grad)"""
+        if not (self.active and self.armed and self.world > 1 and self.overlap) or self._ready[i]:
+            return
+        self._ready[i] = True
+        b = self.bucket_of[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and not self._launched[b]:
+            self._launch(b)
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]
@@ -88,17 +114,22 @@ class GradReducer:
         self._works.append(dist.all_reduce(self.fp.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
-        """Complete the mean all-reduce of every bucket; resets the per-step bookkeeping."""
+        """Complete the mean all-reduce of every bucket; disarms the reducer until the next begin_step()."""
         if self.world > 1 and self.active:
-            for b in range(len(self.buckets)):
+            for b in range(len(self.buckets)):          # fixed order: the same sequence of collectives on every rank
                 if not self._launched[b]:
                     self._launch(b)
             for w in self._works:
                 w.wait()
             self.fp.grad.mul_(1.0 / self.world)
-        self._works = []
-        self._pending = [len(idxs) for _, _, idxs in self.buckets]
-        self._launched = [False] * len(self.buckets)
+            opt = self.optimizer
+            if opt is not None:                          # every rank must update the same parameters
+                flags = torch.tensor([1.0 if t else 0.0 for t in opt._touched], dtype=torch.float32,
+                                     device=self.fp.grad.device)
+                dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+                opt._touched = [bool(v) for v in flags.tolist()]
+        self.armed = False
+        self._reset()
 
 
 def broadcast_params(flat_params, src=0, group=None):

@@ -19,11 +19,51 @@ import torch
 
 from . import ops
 from .discriminators import AcCropDiscriminator, define_mask_D, define_D
-from .losses import get_gan_losses, GANLoss
+from .losses import get_gan_losses, GANLoss, VGGLoss
 from .model import Model
 from .optim import FusedAdam
 from .parallel import GradReducer, broadcast_params
 from .utils import LossManager, weighted_sum
+
+
+class _NullWriter(object):
+    """stand-in for tensorboardX.SummaryWriter (trainer.py:21) when tensorboardX is not installed: logging is glue"""
+
+    def add_scalar(self, *a, **k):
+        pass
+
+    def add_image(self, *a, **k):
+        pass
+
+
+def _make_writer(args):
+    try:
+        from tensorboardX import SummaryWriter
+        return SummaryWriter(args.output_dir)
+    except Exception:
+        return _NullWriter()
+
+
+def _make_grid(imgs, pad=2):
+    """torchvision.utils.make_grid(imgs, normalize=True, scale_each=True) for the TensorBoard panels (host side)"""
+    imgs = imgs.detach().float().cpu()
+    if imgs.size(1) == 1:
+        imgs = imgs.expand(-1, 3, -1, -1)
+    lo = imgs.amin(dim=(1, 2, 3), keepdim=True)
+    hi = imgs.amax(dim=(1, 2, 3), keepdim=True)
+    imgs = (imgs - lo) / (hi - lo).clamp(min=1e-5)
+    n, c, h, w = imgs.shape
+    cols = min(8, n)
+    rows = (n + cols - 1) // cols
+    grid = torch.zeros(c, rows * (h + pad) + pad, cols * (w + pad) + pad)
+    for i in range(n):
+        r, q = divmod(i, cols)
+        grid[:, pad + r * (h + pad): pad + r * (h + pad) + h, pad + q * (w + pad): pad + q * (w + pad) + w] = imgs[i]
+    return grid
+
+
+def _has_batchnorm(module):
+    return module is not None and any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in module.modules())
 
 
 @contextlib.contextmanager
@@ -39,13 +79,16 @@ def _frozen(*modules):
 
 
 class Trainer:
-    def __init__(self, args, vocab, checkpoint=None, device='cuda', distributed=False, model_extra=None):
+    def __init__(self, args, vocab, checkpoint=None, device=None, distributed=False, model_extra=None):
         self.vocab = vocab
         self.args = args
-        self.device = device
+        # the reference moves everything to 'cuda' (trainer.py:54,77,103,130).  Without a device the object can still be
+        # CONSTRUCTED (state_dict surgery, checkpoint conversion); any forward raises: there is no CPU compute path
+        self.device = device if device is not None else ('cuda' if torch.cuda.is_available() else 'cpu')
         self.distributed = distributed
         self.num_obj = len(vocab['object_to_idx'])
-        self.writer = None
+        self.writer = _make_writer(args)                                  # trainer.py:21
+        self.colors = torch.randint(0, 256, [self.num_obj, 3]).float()    # trainer.py:22 (consumes the same RNG draws)
         checkpoint = checkpoint if checkpoint is not None else {'model_kwargs': {}, 'd_obj_kwargs': {},
                                                                'd_mask_kwargs': {}, 'd_img_kwargs': {}}
         self.gan_g_loss, self.gan_d_loss = get_gan_losses(args.gan_loss_type)
@@ -54,12 +97,22 @@ class Trainer:
         self.init_image_discriminator(args, checkpoint)
         self.init_obj_discriminator(args, checkpoint)
         self.init_mask_discriminator(args, checkpoint)
+        # Sharing the mask / image discriminator forwards between the generator step and the discriminator steps is only
+        # exact for discriminators WITHOUT BatchNorm: a BatchNorm forward updates running statistics, and the reference
+        # runs it once more per discriminator step (trainer.py:281-325)
+        self._shareable = {'mask': not _has_batchnorm(self.mask_discriminator), 'img': not _has_batchnorm(self.netD)}
+        self.share_d_forward = True
         self.reducers = []
         if distributed:
             for opt in (self.optimizer, self.optimizer_d_img, self.optimizer_d_obj, self.optimizer_d_mask):
                 if opt is not None:
                     broadcast_params(opt.fp)
-                    r = GradReducer(opt.fp)
+                    # every generator parameter is used once per step, so its gradient is final when it is delivered and
+                    # the bucket all-reduces overlap the backward; discriminator parameters collect several
+                    # contributions per step (fake / real / wrong passes) and are reduced in wait() (<= 24 MB each)
+                    r = GradReducer(opt.fp, optimizer=opt, overlap=opt is self.optimizer)
+                    opt.grad_listeners.append(r.param_ready)
+                    opt.zero_grad_hooks.append(r.begin_step)
                     opt.pre_step_hooks.append(r.wait)
                     self.reducers.append(r)
 
@@ -82,10 +135,9 @@ class Trainer:
             model_kwargs.update(self._model_extra)
             checkpoint['model_kwargs'] = model_kwargs
         self.model = Model(**model_kwargs).to(self.device)
-        if args.vgg_features_weight > 0:
-            raise NotImplementedError('VGG feature loss needs pretrained VGG19 weights (not available offline); '
-                                      'run with --vgg_features_weight 0')
         self.criterionVGG = None
+        if args.vgg_features_weight > 0:             # trainer.py:57; ImageNet weights via --vgg_weights <state_dict path>
+            self.criterionVGG = VGGLoss(weights=getattr(args, 'vgg_weights', None) or None).to(self.device)
         self.criterionGAN = GANLoss(use_lsgan=not args.no_lsgan)
         self.optimizer = self._adam(self.model, args.learning_rate)
 
@@ -132,21 +184,39 @@ class Trainer:
         self.netD.train()
         self.optimizer_d_img = self._adam(self.netD, args.learning_rate)
 
-    # ---- checkpoints (reference schema) ----
-    def restore_checkpoint(self, checkpoint):
-        self.model.load_state_dict(checkpoint['model_state'])
-        self.optimizer.load_state_dict(checkpoint['optim_state'])
+    # ---- checkpoints (reference schema: trainer.py:136-203, train.py:119-163) ----
+    def restore_checkpoint(self, checkpoint, best=False):
+        """trainer.py:136-150.  ``best=True`` loads the ``*_best_state`` entries (the ones scripts/sample_images.py
+        reads) instead of the latest ones."""
+        k = (lambda name: name.replace('_state', '_best_state')) if best else (lambda name: name)
+        self.model.load_state_dict(checkpoint[k('model_state')])
+        self.optimizer.load_state_dict(checkpoint[k('optim_state')])
         if self.obj_discriminator is not None:
-            self.obj_discriminator.load_state_dict(checkpoint['d_obj_state'])
-            self.optimizer_d_obj.load_state_dict(checkpoint['d_obj_optim_state'])
+            self.obj_discriminator.load_state_dict(checkpoint[k('d_obj_state')])
+            self.optimizer_d_obj.load_state_dict(checkpoint[k('d_obj_optim_state')])
         if self.mask_discriminator is not None:
-            self.mask_discriminator.load_state_dict(checkpoint['d_mask_state'])
-            self.optimizer_d_mask.load_state_dict(checkpoint['d_mask_optim_state'])
+            self.mask_discriminator.load_state_dict(checkpoint[k('d_mask_state')])
+            self.optimizer_d_mask.load_state_dict(checkpoint[k('d_mask_optim_state')])
         if self.netD is not None:
-            self.netD.load_state_dict(checkpoint['d_img_state'])
-            self.optimizer_d_img.load_state_dict(checkpoint['d_img_optim_state'])
+            self.netD.load_state_dict(checkpoint[k('d_img_state')])
+            self.optimizer_d_img.load_state_dict(checkpoint[k('d_img_optim_state')])
 
     def save_checkpoint(self, checkpoint, t, args, epoch, train_results=None, val_results=None):
+        """trainer.py:152-203: same keys, same "best" bookkeeping (best = highest validation inception mean)."""
+        index = int(t / args.print_every)
+        val_inception_mean = None
+        if train_results is not None:
+            t_avg_iou, t_inception_mean, t_inception_std = train_results[:3]
+            self.writer.add_scalar('checkpoint/train_iou', t_avg_iou, index)
+            self.writer.add_scalar('checkpoint/train_inception_mean', t_inception_mean, index)
+            self.writer.add_scalar('checkpoint/train_inception_std', t_inception_std, index)
+            checkpoint.setdefault('checkpoint_ts', []).append(t)
+            checkpoint.setdefault('train_inception', []).append(t_inception_mean)
+        if val_results is not None:
+            val_avg_iou, val_inception_mean, val_inception_std = val_results[:3]
+            self.writer.add_scalar('checkpoint/val_iou', val_avg_iou, index)
+            self.writer.add_scalar('checkpoint/val_inception_mean', val_inception_mean, index)
+            self.writer.add_scalar('checkpoint/val_inception_std', val_inception_std, index)
         if self.obj_discriminator is not None:
             checkpoint['d_obj_state'] = self.obj_discriminator.state_dict()
             checkpoint['d_obj_optim_state'] = self.optimizer_d_obj.state_dict()
@@ -158,6 +228,18 @@ class Trainer:
             checkpoint['d_img_optim_state'] = self.optimizer_d_img.state_dict()
         checkpoint['model_state'] = self.model.state_dict()
         checkpoint['optim_state'] = self.optimizer.state_dict()
+        if val_inception_mean is not None:
+            history = checkpoint.setdefault('val_inception', [])
+            history.append(val_inception_mean)
+            # quirk kept: the reference appends BEFORE comparing (trainer.py:168,188), so max(history) is
+            # never below the new value and only the first checkpoint ever becomes "best"
+            if len(checkpoint.setdefault('best_t', [])) == 0 or max(history) < val_inception_mean:
+                checkpoint['best_t'].append(t)
+                for name in ('d_obj', 'd_mask', 'd_img'):
+                    checkpoint[name + '_best_state'] = checkpoint.get(name + '_state')
+                    checkpoint[name + '_optim_best_state'] = checkpoint.get(name + '_optim_state')
+                checkpoint['model_best_state'] = checkpoint['model_state']
+                checkpoint['optim_best_state'] = checkpoint['optim_state']
         checkpoint.setdefault('counters', {})['t'] = t
         checkpoint['counters']['epoch'] = epoch
         path = os.path.join(args.output_dir, '%s_with_model.pt' % args.checkpoint_name)
@@ -178,12 +260,16 @@ class Trainer:
         self.generator_losses = L = LossManager()
         self._shared = shared = {}
         share = getattr(self, 'share_d_forward', True)
+        share_mask, share_img = share and self._shareable['mask'], share and self._shareable['img']
         d_shared = [p for m in (self.mask_discriminator, self.netD) if m is not None for p in m.parameters()]
         with _frozen(self.obj_discriminator), ops.skip_param_grads(d_shared):
             if use_gt:
                 if args.l1_pixel_loss_weight > 0:
                     L.add_loss(ops.l1(imgs_pred, imgs), 'L1_pixel_loss', args.l1_pixel_loss_weight)
                 L.add_loss(ops.mse(boxes_pred, boxes), 'bbox_pred', args.bbox_pred_loss_weight)
+
+            if self.criterionVGG is not None:            # trainer.py:218-221
+                L.add_loss(self.criterionVGG(imgs_pred, imgs), 'g_vgg', args.vgg_features_weight)
 
             scores_fake, ac_loss, g_fake_crops = self.obj_discriminator(imgs_pred, objs, boxes, obj_to_img)
             L.add_loss(ac_loss, 'ac_loss', args.ac_loss_weight)
@@ -192,27 +278,27 @@ class Trainer:
             if self.mask_discriminator is not None:
                 one_hot_obj = ops.one_hot(objs, self.num_obj)
                 scores_fake = self.mask_discriminator(masks_pred.unsqueeze(1), one_hot_obj)
-                if share:
+                if share_mask:
                     shared['mask_fake'] = scores_fake
                 L.add_loss(self.criterionGAN(scores_fake, True), 'g_gan_mask_obj_loss', args.d_mask_weight)
                 if args.d_mask_features_weight > 0:
-                    with (contextlib.nullcontext() if share else torch.no_grad()):
+                    with (contextlib.nullcontext() if share_mask else torch.no_grad()):
                         scores_real = self.mask_discriminator(masks.float().unsqueeze(1), one_hot_obj)
-                    if share:
+                    if share_mask:
                         shared['mask_real'] = scores_real
                     L.add_loss(self.calculate_features_loss(scores_fake, scores_real), 'g_mask_features_loss',
                                args.d_mask_features_weight)      # real features enter detached (trainer.py:339)
 
             if self.netD is not None:
-                lay = ops.detach_keep(layout)       # no gradient reaches the layout through D (trainer.py:246-248)
+                lay = layout.detach()               # no gradient reaches the layout through D (trainer.py:246-248)
                 img_pred_fake = self.netD(lay, imgs_pred)
-                if share:
+                if share_img:
                     shared['img_fake'] = img_pred_fake
                 L.add_loss(self.criterionGAN(img_pred_fake, True), 'g_gan_img_loss', args.d_img_weight)
                 if args.d_img_features_weight > 0:
-                    with (contextlib.nullcontext() if share else torch.no_grad()):
+                    with (contextlib.nullcontext() if share_img else torch.no_grad()):
                         pred_real = self.netD(lay, imgs)        # "train textures" pass
-                    if share:
+                    if share_img:
                         shared['img_real'] = pred_real
                     L.add_loss(self.calculate_features_loss(img_pred_fake, pred_real), 'g_gan_features_loss_img',
                                args.d_img_features_weight)
@@ -284,28 +370,81 @@ class Trainer:
                  for i in range(nums_d) for j in range(len(pred_fake[i]) - 1)]
         return weighted_sum(terms, [D_weights * feat_weights] * len(terms))
 
+    def draw_use_gt(self, rng=None):
+        """The use_gt coin of train.py:195.  It decides which parameters receive gradients (box_net only trains on
+        use_gt steps) and hence which Adam slots advance: under data parallelism every rank must see the same value, so
+        rank 0 draws and broadcasts."""
+        import random as _random
+        coin = (rng or _random).randint(0, 1)
+        if self.distributed and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            t = torch.tensor([coin], dtype=torch.int64, device=self.device)
+            torch.distributed.broadcast(t, src=0)
+            coin = int(t.item())
+        return coin != 0
+
     def step(self, batch, use_gt=True):
         """One full G+D iteration = train.py:190-215.  ``batch`` = the 8-tuple of coco_collate_fn on the device."""
         imgs, objs, boxes, masks, triples, obj_to_img, triple_to_img, attributes = batch
         if not use_gt:
             attributes = torch.zeros_like(attributes)
-        model_out = self.model(imgs, objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks,
-                               attributes=attributes)
+        # the dense layouts are outputs for logging only when the layout convs run on the factored form: defer their
+        # kernels (Model.lazy_layouts) and run them at the end iff the caller wants the dense tensors back
+        self.model.lazy_layouts = True
+        try:
+            model_out = self.model(imgs, objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks,
+                                   attributes=attributes)
+        finally:
+            self.model.lazy_layouts = False
         imgs_pred, boxes_pred, masks_pred, layout, layout_pred, layout_wrong = model_out
         self.train_generator(imgs, imgs_pred, masks, masks_pred, layout, objs, boxes, boxes_pred, obj_to_img, use_gt)
         self.train_mask_discriminator(masks, masks_pred.detach(), objs)
         self.train_obj_discriminator(imgs, imgs_pred.detach(), objs, boxes, boxes.detach(), obj_to_img)
-        self.train_image_discriminator(imgs, imgs_pred.detach(), ops.detach_keep(layout), ops.detach_keep(layout_wrong))
+        self.train_image_discriminator(imgs, imgs_pred.detach(), layout.detach(), layout_wrong.detach())
+        if getattr(self, 'dense_layout_outputs', True):
+            for lay in (layout, layout_pred, layout_wrong):
+                ops.ensure_dense(lay)
         return model_out
 
     def write_losses(self, checkpoint, t):
+        """trainer.py:342-369 (this is where the lazy LossManagers synchronise with the device)."""
+        index = int(t / self.args.print_every)
         print('t = %d / %d' % (t, self.args.num_iterations))
-        for tag, L in (('G', getattr(self, 'generator_losses', None)), ('D_obj', getattr(self, 'd_obj_losses', None)),
-                       ('D_mask', getattr(self, 'd_mask_losses', None)), ('D_img', getattr(self, 'd_img_losses', None))):
+        for tag, scope, key, L in (('G', 'g_loss', 'losses', getattr(self, 'generator_losses', None)),
+                                   ('D_obj', 'd_obj_loss', 'd_losses', getattr(self, 'd_obj_losses', None)),
+                                   ('D_mask', 'd_mask_loss', 'd_losses', getattr(self, 'd_mask_losses', None)),
+                                   ('D_img', 'd_img_loss', 'd_losses', getattr(self, 'd_img_losses', None))):
             if L is None:
                 continue
             for name, val in L.items():
                 print(' %s [%s]: %.4f' % (tag, name, val))
                 if checkpoint is not None:
-                    key = 'losses' if tag == 'G' else 'd_losses'
-                    checkpoint.setdefault(key, {}).setdefault(name, []).append(val)
+                    hist = checkpoint.setdefault(key, {})
+                    if name not in hist:                 # plain dict or the reference's defaultdict(list)
+                        hist[name] = []
+                    hist[name].append(val)
+                self.writer.add_scalar('%s/%s' % (scope, name), val, index)
+        if checkpoint is not None:
+            checkpoint.setdefault('losses_ts', []).append(t)
+
+    def write_images(self, t, imgs, imgs_pred, layout_one_hot, layout_pred_one_hot):
+        """trainer.py:371-397: TensorBoard panels (host-side glue, outside the hot path)."""
+        index = int(t / self.args.print_every)
+        w = self.writer
+        w.add_image('img/real', _make_grid(imgs), index)
+        if imgs_pred is not None:
+            w.add_image('img/pred', _make_grid(imgs_pred), index)
+        if self.obj_discriminator is not None and getattr(self, 'd_real_crops', None) is not None:
+            w.add_image('objs/d_real', _make_grid(self.d_real_crops), index)
+            w.add_image('objs/g_fake', _make_grid(self.d_fake_crops), index)
+        w.add_image('img/layout', _make_grid(self.one_hot_to_rgb(layout_one_hot)), index)
+        w.add_image('img/layout_pred', _make_grid(self.one_hot_to_rgb(layout_pred_one_hot)), index)
+
+    def one_hot_to_rgb(self, one_hot):
+        """trainer.py:393-397"""
+        base = one_hot
+        while base._base is not None:            # a channel slice of a lazily built layout (train.py:201-202)
+            base = base._base
+        ops.ensure_dense(base)
+        one_hot_3d = torch.einsum('abcd,be->aecd', [one_hot.detach().cpu(), self.colors])
+        one_hot_3d *= (255.0 / one_hot_3d.max())
+        return one_hot_3d

@@ -33,9 +33,6 @@ def bool_flag(s):
     raise ValueError('Invalid value "%s" for bool flag (should be 0 or 1)' % s)
 
 
-_WEIGHT_CACHE = {}
-
-
 def to_device_async(t, device):
     """Small host -> device copy that does not stall the host: a copy from PAGEABLE memory makes the host wait until the
     stream has drained (measured: ~3.5 ms each, 8 per step), a copy from pinned memory is just enqueued."""
@@ -48,13 +45,13 @@ def to_device_async(t, device):
 
 
 def weighted_sum(tensors, weights):
-    """sum_i weights[i] * tensors[i] for scalar tensors as ONE stack + dot (the reference's chain of python-level
-    ``loss = loss + w * term`` costs ~6 tiny kernels per term, forward + backward)."""
-    dev = tensors[0].device
-    key = (str(dev), tuple(float(w) for w in weights))
-    w = _WEIGHT_CACHE.get(key)
-    if w is None:
-        w = _WEIGHT_CACHE[key] = torch.tensor(key[1], dtype=torch.float32, device=dev)
+    """sum_i weights[i] * tensors[i] for scalar tensors.  On the device: ONE launch (ops.WeightedSumFn; the reference's
+    chain of python-level ``loss = loss + w * term`` costs ~6 tiny kernels per term, forward + backward).  Host tensors
+    (CPU unit tests of the host logic) take the plain torch expression."""
+    if tensors[0].is_cuda:
+        from . import ops
+        return ops.weighted_sum(tensors, weights)
+    w = torch.tensor([float(x) for x in weights], dtype=torch.float32)
     return torch.dot(torch.stack([t.reshape(()).float() for t in tensors]), w)
 
 

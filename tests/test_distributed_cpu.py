@@ -54,8 +54,18 @@ def _worker(rank, world, port, bucket_bytes, q):
     broadcast_params(fp)
     red = GradReducer(fp, bucket_bytes=bucket_bytes)
     for step in range(2):                             # two steps: bookkeeping must reset between them
+        # a backward OUTSIDE the armed window (e.g. discriminator parameters touched by the generator's backward) must
+        # neither launch collectives nor disturb the bookkeeping of the step that follows
         fp.grad.zero_()
         _loss(model, shard_batch(_batch(), rank, world)).backward()
+        assert not red._works and not any(red._ready)
+        fp.grad.zero_()
+        red.begin_step()                              # what FusedAdam.zero_grad() does through its zero_grad_hooks
+        _loss(model, shard_batch(_batch(), rank, world)).backward()
+        if bucket_bytes == 4096:
+            assert len(red._works) >= 2, 'bucket all-reduces must be launched from the hooks, during backward'
+        for i in range(len(fp.params)):
+            red.param_ready(i)                        # a second report of the same parameter is a no-op
         red.wait()
     q.put((rank, fp.packed(fp.grad).detach().numpy().copy(), fp.packed(fp.flat).detach().numpy().copy(), len(red.buckets)))   # by value
     dist.barrier()

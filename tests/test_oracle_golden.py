@@ -154,6 +154,49 @@ def test_losses_vs_reference(golden):
     close(O.gan_d_loss(T(g['sr']), T(g['sf'])), g['d_loss'], 1e-6)
 
 
+def test_loss_variants_vs_reference(golden):
+    """--gan_loss_type wgan|lsgan and GANLoss(use_lsgan=False): values and gradients (losses.py:93-132,147)."""
+    g = golden('losses_variants')
+    for name, fn, two in [('wgan_g', O.wgan_g_loss, False), ('wgan_d', O.wgan_d_loss, True),
+                          ('lsgan_g', O.lsgan_g_loss, False), ('lsgan_d', O.lsgan_d_loss, True)]:
+        sr, sf = T(g['sr']).clone().requires_grad_(), T(g['sf']).clone().requires_grad_()
+        v = fn(sr, sf) if two else fn(sf)
+        close(v, g[name], 1e-6, name)
+        v.backward()
+        close(sf.grad, g[name + '_gsf'], 1e-6, name + ' d/dfake')
+        if two:
+            close(sr.grad, g[name + '_gsr'], 1e-6, name + ' d/dreal')
+    crit = O.GANLoss(use_lsgan=False)
+    for t in (True, False):
+        p0, p1 = T(g['p0']).clone().requires_grad_(), T(g['p1']).clone().requires_grad_()
+        v = crit([[None, p0], [None, p1]], t)
+        close(v, g['bce_%d' % t], 1e-6)
+        v.backward()
+        close(p0.grad, g['bce_%d_g0' % t], 1e-6)
+        close(p1.grad, g['bce_%d_g1' % t], 1e-6)
+
+
+def test_vgg_loss_vs_reference(golden):
+    """The reference's Vgg19 / VGGLoss (losses.py:179-224) on a torchvision shim of configuration 'E': the oracle's
+    restatement reproduces keys, shapes, the five feature maps, the loss and d loss / d x."""
+    g = golden('vgg_loss')
+    crit = O.VGGLoss()
+    sd = crit.vgg.state_dict()
+    assert list(sd.keys()) == g['keys'].tolist()
+    assert [','.join(str(int(d)) for d in v.shape) for v in sd.values()] == g['shapes'].tolist()
+    fill_deterministic(crit.vgg)
+    x = T(g['x']).clone().requires_grad_()
+    feats = crit.vgg(x)
+    close(feats[0][:, :4], g['feat0'], 1e-5)
+    close(feats[4], g['feat4'], 1e-5)
+    for f, (sm, ab) in zip(feats, g['feat_stats']):
+        assert abs(f.double().abs().sum().item() - ab) <= 1e-4 * max(1.0, ab)
+    loss = crit(x, T(g['y']))
+    close(loss, g['loss'], 1e-5)
+    loss.backward()
+    close(x.grad, g['gx'], 1e-5)
+
+
 def test_state_dict_keys_match_reference(golden):
     g = golden('state_dict_keys_full')
     args = parser.parse_args(['--vgg_features_weight', '0', '--output_dir', '/tmp/o'])

@@ -428,6 +428,58 @@ def golden_testmode():
     npz('model_test_mode', seed=321, **arrs)
 
 
+def golden_vgg():
+    """losses.py:179-224: the reference's own Vgg19 / VGGLoss classes on a torchvision SHIM whose vgg19().features follows
+    torchvision's published configuration 'E' (torchvision and its ImageNet weights are absent here).  Pins the
+    reference-side arithmetic: slice boundaries, the 1/32..1 weights, L1 against the detached target features."""
+    import torchvision.models as tvm
+    from oracle.sg_oracle import vgg19_features
+
+    class _V(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.features = vgg19_features()
+    tvm.vgg19 = lambda pretrained=False, **kw: _V()
+    import importlib
+    import scene_generation.losses as RL
+    importlib.reload(RL)                       # picks up the shimmed ``models``
+    crit = RL.VGGLoss()
+    fill_deterministic(crit.vgg)
+    x = det((2, 3, 32, 32), 91).requires_grad_()
+    y = det((2, 3, 32, 32), 92)
+    loss = crit(x, y)
+    gx, = grads_of(loss, [x])
+    feats = crit.vgg(x)
+    npz('vgg_loss', x=x, y=y, loss=loss, gx=gx, keys=np.array(list(crit.vgg.state_dict().keys())),
+        shapes=np.array([','.join(str(int(d)) for d in v.shape) for v in crit.vgg.state_dict().values()]),
+        feat_stats=np.array([[float(f.double().sum()), float(f.double().abs().sum())] for f in feats]),
+        feat0=feats[0][:, :4], feat4=feats[4])
+
+
+def golden_losses2():
+    """the non-default loss variants behind the same flags: --gan_loss_type wgan|lsgan (losses.py:93-132) and
+    GANLoss(use_lsgan=False) = nn.BCELoss on the sigmoid outputs (losses.py:147)."""
+    from scene_generation.losses import GANLoss, wgan_g_loss, wgan_d_loss, lsgan_g_loss, lsgan_d_loss
+    sr, sf = det((7, 1), 168, 3.0).requires_grad_(), det((7, 1), 169, 3.0).requires_grad_()
+    arrs = dict(sr=sr, sf=sf)
+    for name, fn, args in [('wgan_g', wgan_g_loss, (sf,)), ('wgan_d', wgan_d_loss, (sr, sf)),
+                           ('lsgan_g', lsgan_g_loss, (sf,)), ('lsgan_d', lsgan_d_loss, (sr, sf))]:
+        v = fn(*args)
+        g = grads_of(v, [sr, sf])
+        arrs[name] = v
+        arrs[name + '_gsr'], arrs[name + '_gsf'] = g
+    crit = GANLoss(use_lsgan=False, tensor=torch.FloatTensor)
+    probs = [[det((2, 4, 5, 5), 160), (det((2, 1, 6, 6), 161) + 0.5).clamp(0.02, 0.98).requires_grad_()],
+             [det((2, 4, 3, 3), 162), (det((2, 1, 4, 4), 163) + 0.5).clamp(0.02, 0.98).requires_grad_()]]
+    for t in (True, False):
+        v = crit(probs, t)
+        g = grads_of(v, [probs[0][1], probs[1][1]])
+        arrs['bce_%d' % t] = v
+        arrs['bce_%d_g0' % t], arrs['bce_%d_g1' % t] = g
+    arrs['p0'], arrs['p1'] = probs[0][1], probs[1][1]
+    npz('losses_variants', **arrs)
+
+
 def golden_args():
     """flag names + defaults of the reference parser (args.py:10-109)"""
     import json
@@ -439,6 +491,6 @@ def golden_args():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     install_shims()
-    which = sys.argv[1:] or ['gconv', 'layout', 'crop', 'modules', 'losses', 'step', 'testmode', 'args']
+    which = sys.argv[1:] or ['gconv', 'layout', 'crop', 'modules', 'losses', 'losses2', 'vgg', 'step', 'testmode', 'args']
     for w in which:
         globals()['golden_' + w]()
