@@ -39,6 +39,9 @@ enum { SG_LOSS_MSE_CONST = 0, SG_LOSS_MSE = 1, SG_LOSS_L1 = 2, SG_LOSS_BCE_LOGIT
 
 int sg_version(void);
 const char* sg_last_error_string(void);
+/* device bytes held by the shape-table cache; drop it (synchronises the tables' build events) */
+size_t sg_plan_cache_bytes(void);
+int sg_plan_cache_clear(void);
 
 /* ---------------------------------------------------------------------------------------------
  * Convolution family = implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain).
@@ -102,9 +105,11 @@ int sg_conv2d_fwd_sparse(const sgConvDesc* d, const float* x1, const float* x2, 
 int sg_conv2d_wgrad_sparse(const sgConvDesc* d, const float* gy, const float* x1, const float* x2,
                            const int32_t* chan_list, const int32_t* chan_cnt, int L, float* gw, float* gb,
                            void* ws, size_t ws_bytes, sgStream stream);
-/* Winograd F(2x2, 3x3) forward / weight gradient for ReflectionPad2d(1) + 3x3 stride-1 convs whose channel counts and
-   tile count N*(H/2)*(W/2) are multiples of 128 (the ResnetBlock convs, reference layers.py:251-270): 2.25x fewer MACs;
-   fp32 throughout, results agree with sg_conv2d_fwd / sg_conv2d_wgrad to fp32 rounding (gb via sg_channel_sum). */
+/* Winograd F(2x2, 3x3) forward / data gradient / weight gradient for 3x3 stride-1 pad-1 convs (reflection padding: the
+   ResnetBlock convs, layers.py:251-270; zero padding: the VGG19 convs of VGGLoss, losses.py:183-198, and -- behind the folded
+   nearest x2 upsample -- mask_net, generators.py:20-22) with >= 128 channels on both sides, whose channel counts and tile count
+   N*(OH/2)*(OW/2) are all multiples of 128 or all multiples of 64: 2.25x fewer MACs; fp32 throughout, results agree with
+   sg_conv2d_fwd / _dgrad / _wgrad to fp32 rounding (gb via sg_channel_sum). */
 int sg_conv2d_wino_supported(const sgConvDesc* d);
 size_t sg_conv2d_wino_ws_bytes(const sgConvDesc* d);
 int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y, int act,
@@ -229,7 +234,8 @@ int sg_masks_to_layout_bwd_vecs(const float* gout, const float* boxes, const voi
                                 int M, int H, int W, int avg, int d_begin, sgStream stream);
 int sg_crop_bbox_fwd(const float* feats, const float* boxes, const int64_t* box_to_feat, float* out, int N, int C, int H,
                      int W, int B, int HH, int WW, sgStream stream);
-/* g_feats must be zero-filled by the caller; accumulated with fp32 atomics (order not deterministic) */
+/* g_feats [N, C, H, W] is written completely (no zero fill needed): a gather over the crop pixels whose bilinear
+ * footprint covers each image pixel, summed in (box, crop row, crop column) order => bit-reproducible */
 int sg_crop_bbox_bwd(const float* gout, const float* boxes, const int64_t* box_to_feat, float* g_feats, int N, int C,
                      int H, int W, int B, int HH, int WW, sgStream stream);
 /* VectorPool.query on device (utils.py:62-90): plan = int32[4][O] rows {class, src_kind, src_idx, slot}

@@ -11,7 +11,7 @@ import sys
 
 __version__ = '0.1.0'
 _SUBMODULES = ('args', 'utils', 'layers', 'graph', 'layout', 'bilinear', 'generators', 'discriminators', 'losses',
-               'model', 'trainer', 'optim', 'parallel', 'synthetic', 'ops')
+               'model', 'trainer', 'optim', 'parallel', 'synthetic', 'ops', 'pipeline')
 
 
 def _find_host_package(name):

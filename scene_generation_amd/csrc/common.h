@@ -35,7 +35,10 @@ void sg_set_error(const char* fmt, ...);
 enum {
   SG_K_IGEMM_BASE = 0, SG_K_IGEMM_COUNT = 36,
   SG_K_LINEAR = 36, SG_K_LAYOUT_FWD, SG_K_LAYOUT_BWD, SG_K_INSTNORM, SG_K_BATCHNORM, SG_K_ADAM, SG_K_SEGSUM,
-  SG_K_CROP, SG_K_OTHER, SG_K_COUNT
+  SG_K_CROP, SG_K_OTHER,
+  // the batched dense GEMMs of the Winograd convs, one kind per template instantiation (they used to be lumped into
+  // igemm_kn0_k3_t128 together with the direct 3x3 convs) and the elementwise Winograd transforms
+  SG_K_WINO_GEMM_128, SG_K_WINO_GEMM_64, SG_K_WINO_XFORM, SG_K_COUNT
 };
 static inline int sg_igemm_kind(int family, int KS, int tile) {
   const int k = KS == 1 ? 0 : (KS == 3 ? 1 : (KS == 4 ? 2 : 3));

@@ -13,6 +13,9 @@
 // Replaces the cuDNN/ATen conv + addmm kernels the reference dispatches (see include/sg2im_hip.h).
 #include "common.h"
 #include <stdlib.h>
+#include <array>
+#include <map>
+#include <mutex>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -210,6 +213,37 @@ __global__ void build_ktab_kernel(KEntry* tab, int K, int Kpad, int KS2, int C1,
     e.choff = 0u; e.tapsel = tail_valid ? 0u : (unsigned)KS2;
   }
   tab[k] = e;
+}
+
+// Shape-only index tables (k-split tables) are built once per shape and kept: the key holds everything the table
+// depends on, the table lives in device memory owned by the library (the one exception to "the caller owns every buffer":
+// sg_plan_cache_bytes / sg_plan_cache_clear in the header).  A table built on stream A is made visible to a later launch on
+// stream B with an event wait.
+struct TabEntry { void* dev; size_t bytes; hipEvent_t ready; hipStream_t stream; };
+using TabKey = std::array<long long, 12>;
+std::mutex g_tab_mu;
+std::map<TabKey, TabEntry> g_tabs;
+size_t g_tab_bytes = 0;
+
+template <class Build>
+const void* cached_table(TabKey key, size_t bytes, hipStream_t s, Build build) {
+  int dev = 0;
+  hipGetDevice(&dev);
+  key[11] = dev;
+  std::lock_guard<std::mutex> lk(g_tab_mu);
+  auto it = g_tabs.find(key);
+  if (it == g_tabs.end()) {
+    TabEntry e{nullptr, bytes, nullptr, s};
+    if (hipMalloc(&e.dev, bytes) != hipSuccess) return nullptr;
+    hipEventCreateWithFlags(&e.ready, hipEventDisableTiming);
+    build(e.dev);
+    hipEventRecord(e.ready, s);
+    g_tab_bytes += bytes;
+    it = g_tabs.emplace(key, e).first;
+  } else if (it->second.stream != s) {
+    hipStreamWaitEvent(s, it->second.ready, 0);
+  }
+  return it->second.dev;
 }
 
 template <int BN, int KS, int MODE, bool TWO, bool MASK = true>
@@ -644,12 +678,36 @@ struct EpWgrad {     // tap-major virtual column n = t*cpad + cj  ->  slab[z][m]
 // ------------------------------------------------------------------------------------------------
 // Batched mode (channel-sparse first layers): the N axis is split into `nbatch` images of `cols_per_batch` columns,
 // tiles never straddle images, and each image has its own compact A operand, k-table and K extent.
+// Parity classes of a stride-2 transposed gather run as ONE launch: class c owns the n-tiles [tile0[c], tile0[c+1]), has its
+// own compact A operand (offset aoff, row length K), k-table, K extent and pixel sub-lattice.
+struct ParityClasses {
+  int ncls; int tile0[5]; int Npix[4]; int K[4]; int PH[4], PW[4], ph0[4], pw0[4]; unsigned aoff[4];
+  const void* ktab[4];
+};
 struct BatchInfo {
   int cols_per_batch; int nbatch; const int* kcnt; int a_stride; int b_stride;
   // K = (image, pixel) GEMMs split so that no k-chunk straddles an image: grid.z = image * ksplit + q, chunk q of
   // image i covers pixels [i*kimg + q*kcs, min((i+1)*kimg, ... + kcs))  (ksplit == 0: plain blockIdx.z * kchunk)
   int kimg, ksplit, kcs;
+  // batch_major: tiles are numbered batch-major (all tiles of batch 0, then batch 1, ...), so that with the XCD remap
+  // below every XCD works on whole batches and their operands stay in ITS L2 (batched Winograd GEMMs)
+  int batch_major;
+  ParityClasses par;
 };
+// per-class hooks: loaders / epilogues that can run a parity class overload these; everything else ignores the call
+template <class L> __device__ __forceinline__ void set_class_a(L&, unsigned, int) {}
+template <class L> __device__ __forceinline__ void set_class_b(L&, const ParityClasses&, int) {}
+template <class E> __device__ __forceinline__ void set_class_ep(E&, const ParityClasses&, int) {}
+template <int BX, bool VEC, bool MASK>
+__device__ __forceinline__ void set_class_a(LoadKContig<BX, VEC, MASK>& l, unsigned off, int K) { l.base += off; l.ld = K; }
+template <int BN, int KS, int MODE, bool TWO, bool MASK>
+__device__ __forceinline__ void set_class_b(LoadGatherKN<BN, KS, MODE, TWO, MASK>& l, const ParityClasses& p, int c) {
+  l.ktab = reinterpret_cast<const KEntry*>(p.ktab[c]);
+  l.g.PH = p.PH[c]; l.g.PW = p.PW[c]; l.g.ph0 = p.ph0[c]; l.g.pw0 = p.pw0[c]; l.Npix = p.Npix[c];
+}
+__device__ __forceinline__ void set_class_ep(EpNCHW& e, const ParityClasses& p, int c) {
+  e.PHW = p.PH[c] * p.PW[c]; e.Npix = p.Npix[c]; e.PWs = p.PW[c]; e.h0 = p.ph0[c]; e.w0 = p.pw0[c];
+}
 template <class CFG, class AL, class BL, class EP>
 __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int kchunk, BatchInfo bi) {
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, LDA = CFG::LDA, LDB = CFG::LDB;
@@ -670,8 +728,21 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   }
-  const int m0 = (bid / tiles_n) * BM;
+  int m0 = (bid / tiles_n) * BM;
   int n0 = (bid % tiles_n) * BN;
+  if (bi.par.ncls > 0) {                      // one launch for the parity classes: locate this workgroup's class
+    const int tn_all = bi.par.tile0[bi.par.ncls];
+    const int tn = bid % tn_all;
+    m0 = (bid / tn_all) * BM;
+    int c = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) c += (q < bi.par.ncls && tn >= bi.par.tile0[q]) ? 1 : 0;
+    n0 = (tn - bi.par.tile0[c]) * BN;
+    K = bi.par.K[c];
+    set_class_a(al, bi.par.aoff[c], K);
+    set_class_b(bl, bi.par, c);
+    set_class_ep(ep, bi.par, c);
+  }
   int kbeg = blockIdx.z * kchunk;
   int kend = min(K, kbeg + kchunk);
   if (bi.ksplit > 0) {
@@ -680,7 +751,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     kend = min((img + 1) * bi.kimg, kbeg + bi.kcs);
   }
   if (bi.cols_per_batch > 0) {
-    const int tn = bid % tiles_n, batch = tn / tiles_pb;
+    int tn = bid % tiles_n, batch = tn / tiles_pb;
+    if (bi.batch_major) {
+      const int per_batch = (int)(gridDim.x / (unsigned)bi.nbatch);       // = tiles_m * tiles_pb
+      batch = bid / per_batch;
+      const int r = bid - batch * per_batch;
+      m0 = (r / tiles_pb) * BM;
+      tn = batch * tiles_pb + (r % tiles_pb);
+    }
     n0 = batch * bi.cols_per_batch + (tn - batch * tiles_pb) * BN;
     if (bi.kcnt) kend = min(kend, bi.kcnt[batch]);
     al.set_batch(batch, bi.a_stride, 0);
@@ -791,7 +869,7 @@ inline int pick_tile(int M, int N) {
 }
 
 // thread-local launch modifiers (set by the sparse entry points around a regular dispatch)
-thread_local BatchInfo t_batch = {0, 0, nullptr, 0, 0, 0, 0, 0};
+thread_local BatchInfo t_batch = {};
 // per-image ascending active-channel lists; wimg / gwimg (optional): per-image weights [N][M][L][KS2] in list order instead
 // of one shared weight tensor (factored layout convs: the channels are the objects of the image)
 struct Sparse { const int* list; const int* cnt; int L; const float* wimg; float* gwimg; };
@@ -803,6 +881,7 @@ template <class CFG, class AL, class BL, class EP>
 int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int splits, hipStream_t s) {
   int tiles = sg_cdiv(M, CFG::BM) * sg_cdiv(N, CFG::BN);
   if (t_batch.cols_per_batch > 0) tiles = sg_cdiv(M, CFG::BM) * t_batch.nbatch * sg_cdiv(t_batch.cols_per_batch, CFG::BN);
+  if (t_batch.par.ncls > 0) tiles = sg_cdiv(M, CFG::BM) * t_batch.par.tile0[t_batch.par.ncls];
   int kchunk = K;
   if (splits > 1) kchunk = sg_cdiv(sg_cdiv(K, splits), CFG::BKT) * CFG::BKT;
   if (t_fixed_kchunk > 0) kchunk = t_fixed_kchunk;
@@ -950,7 +1029,6 @@ template <int KS, int MODE>
 int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* bias, float* out, int Mtot, int act,
            float slope, double flops, void* ktab_ws, size_t ws_avail, hipStream_t s) {
   const int Npix = NB * g.PH * g.PW;
-  KEntry* ktab = reinterpret_cast<KEntry*>(ktab_ws);
   const bool vec = (K % 4 == 0) && aligned16(A);
   int tile = pick_tile(M, Npix);
   if (!vec && tile == 0) tile = 1;                  // the scalar-A variant is only instantiated for the small tiles
@@ -961,11 +1039,15 @@ int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* b
   float* slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(ktab_ws) + ktab_bytes(K));
   int splits = (Mtot == M) ? kn_splits(M, Npix, K) : 1;
   if (splits > 1 && ws_avail < ktab_bytes(K) + (size_t)splits * M * Npix * sizeof(float)) splits = 1;
-  {
-    const int Kpad = sg_cdiv(K, 64) * 64 + 128;      // the k-loop prefetches entries up to two tiles past the end
-    hipLaunchKernelGGL(build_ktab_kernel, dim3(sg_cdiv(Kpad, 256)), dim3(256), 0, s, ktab, K, Kpad, KS * KS, g.C1, g.C2,
-                       (unsigned)(g.SH * g.SW), g.bcast2, nomask ? 1 : 0, t_variant_stride);
-  }
+  const int Kpad = sg_cdiv(K, 64) * 64 + 128;      // the k-loop prefetches entries up to two tiles past the end
+  const unsigned shw_ = (unsigned)(g.SH * g.SW), vstride = t_variant_stride;
+  const KEntry* ktab = reinterpret_cast<const KEntry*>(cached_table(
+      TabKey{0, K, Kpad, KS * KS, g.C1, g.C2, shw_, g.bcast2, nomask ? 1 : 0, vstride, 0, 0}, (size_t)Kpad * sizeof(KEntry), s,
+      [&](void* dst) {
+        hipLaunchKernelGGL(build_ktab_kernel, dim3(sg_cdiv(Kpad, 256)), dim3(256), 0, s, reinterpret_cast<KEntry*>(dst), K, Kpad,
+                           KS * KS, g.C1, g.C2, shw_, g.bcast2, nomask ? 1 : 0, vstride);
+      }));
+  SG_ARG_CHECK(ktab != nullptr, "conv: device allocation of the k-split table failed");
   const size_t nout = (size_t)M * Npix;
   EpNCHW ep{out, bias, g.PH * g.PW, Mtot, M, Npix, act, slope, 0, 0, 1, 0, 0, 0, 0};
   if (splits > 1) ep = EpNCHW{slabs, nullptr, g.PH * g.PW, Mtot, M, Npix, SG_ACT_NONE, 0.f, nout, 0, 1, 0, 0, 0, 0};
@@ -1053,7 +1135,7 @@ int run_kn_sparse(const float* W, int M, int K, const Gather& g, int NB, const f
   EpNCHW ep{out, bias, PHW, M, M, Npix, act, slope, 0, 0, 1, 0, 0, 0, 0};
   // flops actually issued: the padded compact K of every image (bench.py prices the dominant kernel with this)
   const double flops = 2.0 * M * (double)Kc * Npix;
-  t_batch = BatchInfo{PHW, NB, kcnt, M * Kc, Kpad};
+  t_batch = BatchInfo{}; t_batch.cols_per_batch = PHW; t_batch.nbatch = NB; t_batch.kcnt = kcnt; t_batch.a_stride = M * Kc; t_batch.b_stride = Kpad;
   {
     SgProfScope prof(sg_igemm_kind(0, KS, tile), s, flops, 0);
     switch (tile) {
@@ -1062,7 +1144,7 @@ int run_kn_sparse(const float* W, int M, int K, const Gather& g, int NB, const f
       default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, 0>(Wc, Kc, M, true, g, Npix, ktab, ep, 1, nomask, s); break;
     }
   }
-  t_batch = BatchInfo{0, 0, nullptr, 0, 0};
+  t_batch = BatchInfo{};
   return 0;
 }
 
@@ -1072,15 +1154,24 @@ int run_kn_sparse(const float* W, int M, int K, const Gather& g, int NB, const f
 // pixels of that class, with a compact weight matrix / k-table that lists only the class's taps -- 4x fewer MACs.
 struct TapList { int n; int t[16]; };
 
-// A[m][r*nt + i] = W[(r*B + m0 + m)*R + taps[i]]   (W = [reduction dim][B][R] in memory)
-__global__ void permute_sub_kernel(const float* W, float* A, int Rdim, int B, int m0, int M, int R, TapList tl) {
+// A_c[m][r*nt_c + i] = W[(r*B + m0 + m)*R + taps_c[i]] for the (up to) four parity classes c, packed back to back
+// (W = [reduction dim][B][R] in memory)
+struct PermClasses { int ncls; unsigned long long off[5]; TapList tl[4]; };
+__global__ void permute_sub_kernel(const float* W, float* A, int Rdim, int B, int m0, int M, int R, PermClasses pc) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t K = (size_t)Rdim * tl.n;
-  if (i >= (size_t)M * K) return;
-  const int m = (int)(i / K);
-  const int k = (int)(i - (size_t)m * K);
-  const int r = k / tl.n, ti = k - r * tl.n;
-  A[i] = W[((size_t)r * B + m0 + m) * R + tl.t[ti]];
+  if (i >= pc.off[pc.ncls]) return;
+  int c = 0;
+#pragma unroll
+  for (int q = 1; q < 4; ++q) c += (q < pc.ncls && i >= pc.off[q]) ? 1 : 0;
+  const int nt = pc.tl[c].n;
+  const size_t K = (size_t)Rdim * nt, j = i - pc.off[c];
+  const int m = (int)(j / K);
+  const int k = (int)(j - (size_t)m * K);
+  const int r = k / nt, ti = k - r * nt;
+  int tap = pc.tl[c].t[0];
+#pragma unroll
+  for (int q = 1; q < 16; ++q) tap = (q == ti) ? pc.tl[c].t[q] : tap;      // no dynamic indexing of a kernel-argument array
+  A[i] = W[((size_t)r * B + m0 + m) * R + tap];
 }
 __global__ void build_ktab_sub_kernel(KEntry* tab, int K, int Kpad, unsigned shw, int KS2, TapList tl) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1088,7 +1179,10 @@ __global__ void build_ktab_sub_kernel(KEntry* tab, int K, int Kpad, unsigned shw
   KEntry e;
   if (k < K) {
     const int r = k / tl.n, ti = k - r * tl.n;
-    e.choff = (unsigned)r * shw; e.tapsel = (unsigned)tl.t[ti];
+    int tap = tl.t[0];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) tap = (q == ti) ? tl.t[q] : tap;
+    e.choff = (unsigned)r * shw; e.tapsel = (unsigned)tap;
   } else {
     e.choff = 0u; e.tapsel = (unsigned)KS2;
   }
@@ -1100,44 +1194,70 @@ int run_kn_parity(const float* W, int Rdim, int B, int m0, int M, const Gather& 
                   int Mtot, int act, float slope, double flops, void* ws, size_t ws_bytes, hipStream_t s) {
   constexpr int KS2 = KS * KS;
   float* wbase = reinterpret_cast<float*>(ws);
-  KEntry* kbase = reinterpret_cast<KEntry*>(wbase + (size_t)M * Rdim * KS2);
-  size_t woff = 0, koff = 0;
   const unsigned shw = (unsigned)(g.SH * g.SW);
+  ParityClasses par = {};
+  PermClasses pc = {};
+  int maxNpix = 0;
+  bool vec = aligned16(wbase);
+  double flops_issued = 0.0;
   for (int a = 0; a < 2; ++a) {
     for (int b = 0; b < 2; ++b) {
       TapList tl; tl.n = 0;
+      for (int q = 0; q < 16; ++q) tl.t[q] = 0;
       for (int kh = a; kh < KS; kh += 2)
         for (int kw = b; kw < KS; kw += 2) tl.t[tl.n++] = kh * KS + kw;
       const int ph0 = ((a - g.pad) % 2 + 2) % 2, pw0 = ((b - g.pad) % 2 + 2) % 2;
       const int PHa = g.PH > ph0 ? (g.PH - ph0 + 1) / 2 : 0, PWb = g.PW > pw0 ? (g.PW - pw0 + 1) / 2 : 0;
-      if (PHa * PWb == 0) continue;
+      if (PHa * PWb == 0 || tl.n == 0) continue;
+      const int c = par.ncls++;
       const int K = Rdim * tl.n, Kpad = sg_cdiv(K, 64) * 64 + 128;
-      float* A = wbase + woff;
-      KEntry* ktab = kbase + koff;
-      woff += (size_t)M * K; koff += (size_t)Kpad;
-      hipLaunchKernelGGL(permute_sub_kernel, dim3(sg_cdiv((size_t)M * K, 256)), dim3(256), 0, s, W, A, Rdim, B, m0, M, KS2, tl);
-      hipLaunchKernelGGL(build_ktab_sub_kernel, dim3(sg_cdiv(Kpad, 256)), dim3(256), 0, s, ktab, K, Kpad, shw, KS2, tl);
-      Gather gs = g;
-      gs.PH = PHa; gs.PW = PWb; gs.pstep = 2; gs.ph0 = ph0; gs.pw0 = pw0;
-      const int Npix = NB * PHa * PWb;
-      const EpNCHW ep{out, bias, PHa * PWb, Mtot, M, Npix, act, slope, 0, PWb, 2, ph0, pw0, g.PW, g.PH * g.PW};
-      const bool vec = (K % 4 == 0) && aligned16(A);
-      int tile = pick_tile(M, Npix);
-      if (tile == 0 && (!vec || (long)sg_cdiv(M, 128) * sg_cdiv(Npix, 128) < 384)) tile = 1;   // no split-K here
-      SgProfScope prof(sg_igemm_kind(1, KS, tile), s, flops * (4.0 * tl.n * PHa * PWb) / ((double)KS2 * g.PH * g.PW), 0);
-      switch (tile) {
-        case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, 1>(A, K, M, true, gs, Npix, ktab, ep, 1, false, s); break;
-        case 1: launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, 1>(A, K, M, vec, gs, Npix, ktab, ep, 1, false, s); break;
-        default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, 1>(A, K, M, vec, gs, Npix, ktab, ep, 1, false, s); break;
-      }
+      par.K[c] = K; par.PH[c] = PHa; par.PW[c] = PWb; par.ph0[c] = ph0; par.pw0[c] = pw0;
+      par.Npix[c] = NB * PHa * PWb;
+      par.aoff[c] = (unsigned)pc.off[c];
+      pc.tl[c] = tl;
+      pc.off[c + 1] = pc.off[c] + (unsigned long long)M * K;
+      par.ktab[c] = cached_table(TabKey{1, K, Kpad, (long long)shw, KS2, a, b, KS, 0, 0, 0, 0}, (size_t)Kpad * sizeof(KEntry), s,
+                                 [&](void* dst) {
+                                   hipLaunchKernelGGL(build_ktab_sub_kernel, dim3(sg_cdiv(Kpad, 256)), dim3(256), 0, s,
+                                                      reinterpret_cast<KEntry*>(dst), K, Kpad, shw, KS2, tl);
+                                 });
+      SG_ARG_CHECK(par.ktab[c] != nullptr, "conv: device allocation of a k-split table failed");
+      vec = vec && (K % 4 == 0);
+      maxNpix = par.Npix[c] > maxNpix ? par.Npix[c] : maxNpix;
+      flops_issued += flops * (4.0 * tl.n * PHa * PWb) / ((double)KS2 * g.PH * g.PW);
     }
   }
-  (void)ws_bytes;
+  if (par.ncls == 0) return 0;
+  pc.ncls = par.ncls;
+  SG_ARG_CHECK(ws_bytes >= pc.off[pc.ncls] * sizeof(float), "conv: parity workspace too small");
+  hipLaunchKernelGGL(permute_sub_kernel, dim3(sg_cdiv(pc.off[pc.ncls], 256)), dim3(256), 0, s, W, wbase, Rdim, B, m0, M, KS2, pc);
+  int tile = pick_tile(M, maxNpix);
+  long t128 = 0;
+  for (int c = 0; c < par.ncls; ++c) t128 += (long)sg_cdiv(M, 128) * sg_cdiv(par.Npix[c], 128);
+  if (tile == 0 && (!vec || t128 < 384)) tile = 1;   // no split-K here
+  const int tBN = tile == 1 ? 64 : 128;
+  par.tile0[0] = 0;
+  for (int c = 0; c < par.ncls; ++c) par.tile0[c + 1] = par.tile0[c] + sg_cdiv(par.Npix[c], tBN);
+  for (int c = par.ncls + 1; c < 5; ++c) par.tile0[c] = par.tile0[par.ncls];
+  Gather gs = g;
+  gs.PH = par.PH[0]; gs.PW = par.PW[0]; gs.pstep = 2; gs.ph0 = par.ph0[0]; gs.pw0 = par.pw0[0];
+  const EpNCHW ep{out, bias, par.PH[0] * par.PW[0], Mtot, M, par.Npix[0], act, slope, 0, par.PW[0], 2, par.ph0[0], par.pw0[0],
+                  g.PW, g.PH * g.PW};
+  const KEntry* kt0 = reinterpret_cast<const KEntry*>(par.ktab[0]);
+  t_batch = BatchInfo{};
+  t_batch.par = par;
+  {
+    SgProfScope prof(sg_igemm_kind(1, KS, tile), s, flops_issued, 0);
+    switch (tile) {
+      case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, 1>(wbase, par.K[0], M, true, gs, par.Npix[0], kt0, ep, 1, false, s); break;
+      case 1: launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, 1>(wbase, par.K[0], M, vec, gs, par.Npix[0], kt0, ep, 1, false, s); break;
+      default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, 1>(wbase, par.K[0], M, vec, gs, par.Npix[0], kt0, ep, 1, false, s); break;
+    }
+  }
+  t_batch = BatchInfo{};
   return 0;
 }
-inline size_t parity_ws(int M, int Rdim, int KS2) {
-  return (size_t)M * Rdim * KS2 * sizeof(float) + 4 * ((size_t)(sg_cdiv((size_t)Rdim * KS2, 64) * 64 + 128 + 64) * sizeof(KEntry));
-}
+inline size_t parity_ws(int M, int Rdim, int KS2) { return (size_t)M * Rdim * KS2 * sizeof(float) + 64; }
 int run_kn_parity_ks(int KS, const float* W, int Rdim, int B, int m0, int M, const Gather& g, int NB, const float* bias,
                      float* out, int Mtot, int act, float slope, double flops, void* ws, size_t ws_bytes, hipStream_t s) {
   switch (KS) {
@@ -1307,7 +1427,7 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
     SG_ARG_CHECK(ws && ws_bytes >= mnc * sizeof(float) * (size_t)S * NB, "wgrad: workspace too small");
     float* dstp = S > 1 ? reinterpret_cast<float*>(ws) : sp->gwimg;
     const EpRowMajor ep{dstp, nullptr, M, Ncols, Ncols, SG_ACT_NONE, 0.f, mnc};
-    t_batch = BatchInfo{0, 0, nullptr, 0, 0, PQ, S, kcs};
+    t_batch = BatchInfo{}; t_batch.kimg = PQ; t_batch.ksplit = S; t_batch.kcs = kcs;
     t_grid_z = NB * S;
     {
       SgProfScope prof(sg_igemm_kind(2, KS, tile), s, 2.0 * M * (double)Ncols * Kpix, 0);
@@ -1318,7 +1438,7 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
         case 7: launch_nk_general<7>(tile, A, M, Mtot, PQ, g, Ncols, ep, Kpix, 1, s, sp, S); break;
       }
     }
-    t_batch = BatchInfo{0, 0, nullptr, 0, 0, 0, 0, 0};
+    t_batch = BatchInfo{};
     t_grid_z = 0;
     if (S > 1)
       hipLaunchKernelGGL(slab_group_reduce_kernel, dim3(sg_cdiv(mnc * NB, 256)), dim3(256), 0, s, (const float*)ws, sp->gwimg,
@@ -1700,9 +1820,10 @@ __device__ __forceinline__ int wino_reflect(int i, int L) { i = i < 0 ? -i : i; 
 // V = B^T d B of the 4x4 input patch of tile p = (n, ti, tj) on a TH x TW tile grid; the patch starts at (2ti+off, 2tj+off)
 // and is reflected (zero_pad == 0) or zero-extended (zero_pad == 1) outside the plane.  PFAST selects the layout:
 // V[xi][c][p] (1) or V[xi][p][c] (0); rows p in [N*TH*TW, Pstride) are zero padding for the 128-wide GEMM tiles.
+// H x W is the LOGICAL plane (the stored plane is (H >> ush) x (W >> ush): nearest x2 upsampling folded into the read).
 template <int PFAST>
 __global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int C, int H, int W, int TH, int TW,
-                                  int off, int zero_pad, size_t Pstride) {
+                                  int off, int zero_pad, size_t Pstride, int ush) {
   const size_t P = (size_t)N * TH * TW, total = Pstride * C;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -1711,7 +1832,8 @@ __global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict
   float d[4][4];
   if (p < P) {
     const int n = (int)(p / (TH * TW)), r = (int)(p - (size_t)n * TH * TW), ti = r / TW, tj = r - ti * TW;
-    const float* xp = x + ((size_t)n * C + c) * H * W;
+    const int SW = W >> ush;
+    const float* xp = x + ((size_t)n * C + c) * (H >> ush) * SW;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const int ih0 = 2 * ti + off + a;
@@ -1722,7 +1844,7 @@ __global__ void wino_input_kernel(const float* __restrict__ x, float* __restrict
         const int iw0 = 2 * tj + off + b;
         const bool ok = rok && (!zero_pad || (unsigned)iw0 < (unsigned)W);
         const int iw = zero_pad ? (ok ? iw0 : 0) : wino_reflect(iw0, W);
-        const float v = xp[ih * W + iw];
+        const float v = xp[(ih >> ush) * SW + (iw >> ush)];
         d[a][b] = ok ? v : 0.f;
       }
     }
@@ -1844,64 +1966,88 @@ __global__ void wino_wgrad_output_kernel(const float* __restrict__ T, float* __r
   }
 }
 
-bool wino_ok(const sgConvDesc* d) {
-  if (!d || !d->pad_reflect || d->pad != 1 || d->KS != 3 || d->stride != 1 || d->upsample != 1 || d->C2 != 0) return false;
-  if (d->H < 4 || d->W < 4 || (d->H & 1) || (d->W & 1) || d->OH != d->H || d->OW != d->W) return false;
-  const long P = (long)d->N * (d->H / 2) * (d->W / 2);
-  return d->C1 % 128 == 0 && d->Cout % 128 == 0 && P % 128 == 0 && 16.0 * P * (d->C1 > d->Cout ? d->C1 : d->Cout) < 2147483647.0 &&
-         16.0 * d->C1 * d->Cout < 2147483647.0;
+// Winograd applies to 3x3 / stride 1 / pad 1 convs (reflection or zero padding, optionally behind a folded nearest x2
+// upsample) whose channel counts and tile count fill whole GEMM tiles: 128 (the ResnetBlock / VGG convs) or 64 (mask_net's
+// 192 channels).  Below 128 channels the elementwise transforms (16 x the activation bytes) cost more than the GEMM saves.
+int wino_tile(const sgConvDesc* d) {
+  if (!d || d->pad != 1 || d->KS != 3 || d->stride != 1 || d->C2 != 0) return 0;
+  if (d->upsample != 1 && (d->upsample != 2 || d->pad_reflect)) return 0;
+  const int LH = d->H * d->upsample, LW = d->W * d->upsample;
+  if (LH < 4 || LW < 4 || (LH & 1) || (LW & 1) || d->OH != LH || d->OW != LW) return 0;
+  if (d->C1 < 128 || d->Cout < 128) return 0;
+  const long P = (long)d->N * (LH / 2) * (LW / 2);
+  if (!(16.0 * (P + 128.0 * d->N * (LH + LW)) * (d->C1 > d->Cout ? d->C1 : d->Cout) < 2147483647.0 && 16.0 * d->C1 * d->Cout < 2147483647.0))
+    return 0;
+  if (d->C1 % 128 == 0 && d->Cout % 128 == 0 && P % 128 == 0) return 128;
+  if (d->C1 % 64 == 0 && d->Cout % 64 == 0 && P % 64 == 0) return 64;
+  return 0;
 }
+bool wino_ok(const sgConvDesc* d) { return wino_tile(d) != 0; }
 
-// C[m][b*cols + j] = sum_k A[b][m][k] * B[b*cols + j][k]   (16 batches, everything a multiple of the 128-tile)
+// C[m][b*cols + j] = sum_k A[b][m][k] * B[b*cols + j][k]   (16 batches, everything a multiple of the tile)
 void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, int K, double flops, hipStream_t s) {
   EpRowMajor ep{Cout, nullptr, M, 16 * cols, 16 * cols, SG_ACT_NONE, 0.f, 0};
-  t_batch = BatchInfo{cols, 16, nullptr, M * K, 0};
+  t_batch = BatchInfo{}; t_batch.cols_per_batch = cols; t_batch.nbatch = 16; t_batch.a_stride = M * K; t_batch.batch_major = 1;
+  const bool big = M % 128 == 0 && cols % 128 == 0;
   {
-    SgProfScope prof(sg_igemm_kind(0, 3, 0), s, flops, 0);
-    launch_cfg<Cfg128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M, 16 * cols,
-                       K, 1, s);
+    SgProfScope prof(big ? SG_K_WINO_GEMM_128 : SG_K_WINO_GEMM_64, s, flops, 0);
+    if (big)
+      launch_cfg<Cfg128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M, 16 * cols,
+                         K, 1, s);
+    else
+      launch_cfg<Cfg64>(LoadKContig<64, true, false>{A, K, M}, LoadKContig<64, true, false>{B, K, 16 * cols}, ep, M, 16 * cols,
+                        K, 1, s);
   }
-  t_batch = BatchInfo{0, 0, nullptr, 0, 0};
+  t_batch = BatchInfo{};
 }
 
 }  // namespace
 
 extern "C" int sg_conv2d_wino_supported(const sgConvDesc* d) { return wino_ok(d) ? 1 : 0; }
 
-static size_t wino_dgrad_tiles(const sgConvDesc* d) {      // tiles of the (H+2) x (W+2) padded gradient grid, 128-padded
-  const size_t P = (size_t)d->N * (d->H / 2 + 1) * (d->W / 2 + 1);
-  return (P + 127) / 128 * 128;
+static size_t wino_dgrad_tiles(const sgConvDesc* d) {      // reflect: tiles of the (H+2) x (W+2) padded gradient grid
+  const size_t T = (size_t)wino_tile(d);
+  const size_t LH = (size_t)d->H * d->upsample, LW = (size_t)d->W * d->upsample;
+  const size_t P = d->pad_reflect ? (size_t)d->N * (LH / 2 + 1) * (LW / 2 + 1) : (size_t)d->N * (LH / 2) * (LW / 2);
+  return (P + T - 1) / T * T;
 }
 extern "C" size_t sg_conv2d_wino_ws_bytes(const sgConvDesc* d) {
   if (!wino_ok(d)) return 0;
-  const size_t P = (size_t)d->N * (d->H / 2) * (d->W / 2), M = d->Cout, C = d->C1, Pd = wino_dgrad_tiles(d);
+  const size_t LH = (size_t)d->H * d->upsample, LW = (size_t)d->W * d->upsample;
+  const size_t P = (size_t)d->N * (LH / 2) * (LW / 2), M = d->Cout, C = d->C1, Pd = wino_dgrad_tiles(d);
   const size_t a = 16 * (M * C + P * C + M * P);
-  const size_t b = 16 * (M * C + Pd * M + C * Pd) + (size_t)d->N * C * (d->H + 2) * (d->W + 2);
+  const size_t b = 16 * (M * C + Pd * M + C * Pd) + (size_t)d->N * C * (LH + 2) * (LW + 2);
   return (a > b ? a : b) * sizeof(float) + 1024;
 }
 
-// gx [N, C1, H, W]: Winograd over the (H+2) x (W+2) gradient of the reflect-padded input (correlation of the zero-extended
-// gy with the rotated filter), then the reflection fold (sg_pad_upsample_bwd).  1.44x fewer MACs than the direct folded form.
+// gx [N, C1, H, W].  Reflection padding: Winograd over the (H+2) x (W+2) gradient of the reflect-padded input (correlation of
+// the zero-extended gy with the rotated filter), then the reflection fold (sg_pad_upsample_bwd); 1.44x fewer MACs than the
+// direct folded form.  Zero padding: the same correlation straight on the H x W grid (2.25x fewer MACs); behind a folded x2
+// upsample the result is on the upsampled grid and is summed back 2x2.
 extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, void* ws, size_t ws_bytes,
                                     sgStream stream) {
   SG_ARG_CHECK(wino_ok(d), "sg_conv2d_wino_dgrad: unsupported desc");
   SG_ARG_CHECK(gy && w && gx && ws && ws_bytes >= sg_conv2d_wino_ws_bytes(d), "sg_conv2d_wino_dgrad: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const int M = d->C1, K = d->Cout;                 // rows = input channels, reduction over output channels
-  const int TH = d->H / 2 + 1, TW = d->W / 2 + 1;
+  const int LH = d->H * d->upsample, LW = d->W * d->upsample;
+  const int refl = d->pad_reflect;
+  const int TH = LH / 2 + (refl ? 1 : 0), TW = LW / 2 + (refl ? 1 : 0);
   const size_t Pd = wino_dgrad_tiles(d);
   float* U = reinterpret_cast<float*>(ws);          // [16][C1][Cout]
   float* V = U + 16 * (size_t)M * K;                // [16][Pd][Cout]
   float* Mx = V + 16 * Pd * K;                      // [C1][16][Pd]
-  float* gpad = Mx + 16 * Pd * M;                   // [N][C1][H+2][W+2]
-  hipLaunchKernelGGL(wino_weight_kernel, dim3(sg_cdiv((size_t)M * K, 256)), dim3(256), 0, s, w, U, M, K, 1);
-  hipLaunchKernelGGL(wino_input_kernel<0>, dim3(sg_cdiv(Pd * K, 256)), dim3(256), 0, s, gy, V, d->N, K, d->H, d->W, TH, TW, -2,
-                     1, Pd);
-  wino_bgemm(U, V, Mx, M, (int)Pd, K, 2.0 * M * (double)K * 16.0 * Pd, s);
-  hipLaunchKernelGGL(wino_output_kernel, dim3(sg_cdiv((size_t)d->N * TH * TW * M, 256)), dim3(256), 0, s, (const float*)Mx,
-                     (const float*)nullptr, gpad, d->N, M, d->H + 2, d->W + 2, Pd, SG_ACT_NONE, 0.f);
+  float* gpad = Mx + 16 * Pd * M;                   // [N][C1][LH+2][LW+2] (reflect) / [N][C1][LH][LW] (upsample)
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_weight_kernel, dim3(sg_cdiv((size_t)M * K, 256)), dim3(256), 0, s, w, U, M, K, 1); }
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_input_kernel<0>, dim3(sg_cdiv(Pd * K, 256)), dim3(256), 0, s, gy, V, d->N, K, LH, LW, TH, TW,
+                     refl ? -2 : -1, 1, Pd, 0); }
+  wino_bgemm(U, V, Mx, M, (int)Pd, K, 2.0 * M * (double)K * 16.0 * ((double)d->N * TH * TW), s);   // flops of the real tiles
+  const bool direct = !refl && d->upsample == 1;
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_output_kernel, dim3(sg_cdiv((size_t)d->N * TH * TW * M, 256)), dim3(256), 0, s, (const float*)Mx,
+                     (const float*)nullptr, direct ? gx : gpad, d->N, M, 2 * TH, 2 * TW, Pd, SG_ACT_NONE, 0.f); }
   SG_LAUNCH_CHECK("sg_conv2d_wino_dgrad");
-  return sg_pad_upsample_bwd(gpad, gx, d->N * M, d->H, d->W, 1, 1, stream);
+  if (direct) return 0;
+  return sg_pad_upsample_bwd(gpad, gx, d->N * M, d->H, d->W, refl ? 1 : 0, d->upsample, stream);
 }
 
 extern "C" int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y, int act,
@@ -1910,16 +2056,17 @@ extern "C" int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const flo
   SG_ARG_CHECK(x && w && y && ws && ws_bytes >= sg_conv2d_wino_ws_bytes(d), "sg_conv2d_wino_fwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const int M = d->Cout, C = d->C1;
-  const size_t P = (size_t)d->N * (d->H / 2) * (d->W / 2);
+  const int LH = d->H * d->upsample, LW = d->W * d->upsample;
+  const size_t P = (size_t)d->N * (LH / 2) * (LW / 2);
   float* U = reinterpret_cast<float*>(ws);
   float* V = U + 16 * (size_t)M * C;
   float* Mx = V + 16 * P * C;
-  hipLaunchKernelGGL(wino_weight_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, w, U, M, C, 0);
-  hipLaunchKernelGGL(wino_input_kernel<0>, dim3(sg_cdiv(P * C, 256)), dim3(256), 0, s, x, V, d->N, C, d->H, d->W, d->H / 2,
-                     d->W / 2, -1, 0, P);
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_weight_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, w, U, M, C, 0); }
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_input_kernel<0>, dim3(sg_cdiv(P * C, 256)), dim3(256), 0, s, x, V, d->N, C, LH, LW, LH / 2, LW / 2, -1,
+                     d->pad_reflect ? 0 : 1, P, d->upsample == 2 ? 1 : 0); }
   wino_bgemm(U, V, Mx, M, (int)P, C, 2.0 * M * (double)C * 16.0 * P, s);
-  hipLaunchKernelGGL(wino_output_kernel, dim3(sg_cdiv(P * M, 256)), dim3(256), 0, s, (const float*)Mx, bias, y, d->N, M, d->H,
-                     d->W, P, act, slope);
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_output_kernel, dim3(sg_cdiv(P * M, 256)), dim3(256), 0, s, (const float*)Mx, bias, y, d->N, M, LH, LW, P,
+                     act, slope); }
   SG_LAUNCH_CHECK("sg_conv2d_wino_fwd");
   return 0;
 }
@@ -1930,16 +2077,29 @@ extern "C" int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const 
   SG_ARG_CHECK(gy && x && gw && ws && ws_bytes >= sg_conv2d_wino_ws_bytes(d), "sg_conv2d_wino_wgrad: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const int M = d->Cout, C = d->C1;
-  const size_t P = (size_t)d->N * (d->H / 2) * (d->W / 2);
+  const int LH = d->H * d->upsample, LW = d->W * d->upsample;
+  const size_t P = (size_t)d->N * (LH / 2) * (LW / 2);
   float* T = reinterpret_cast<float*>(ws);          // [M][16][C]
   float* Vp = T + 16 * (size_t)M * C;               // [16][C][P]
   float* Yt = Vp + 16 * P * C;                      // [16][M][P]
-  hipLaunchKernelGGL(wino_input_kernel<1>, dim3(sg_cdiv(P * C, 256)), dim3(256), 0, s, x, Vp, d->N, C, d->H, d->W, d->H / 2,
-                     d->W / 2, -1, 0, P);
-  hipLaunchKernelGGL(wino_gy_kernel, dim3(sg_cdiv(P * M, 256)), dim3(256), 0, s, gy, Yt, d->N, M, d->H, d->W);
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_input_kernel<1>, dim3(sg_cdiv(P * C, 256)), dim3(256), 0, s, x, Vp, d->N, C, LH, LW, LH / 2, LW / 2, -1,
+                     d->pad_reflect ? 0 : 1, P, d->upsample == 2 ? 1 : 0); }
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_gy_kernel, dim3(sg_cdiv(P * M, 256)), dim3(256), 0, s, gy, Yt, d->N, M, LH, LW); }
   wino_bgemm(Yt, Vp, T, M, C, (int)P, 2.0 * M * (double)C * 16.0 * P, s);
-  hipLaunchKernelGGL(wino_wgrad_output_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, (const float*)T, gw, M, C);
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_wgrad_output_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, (const float*)T, gw, M, C); }
   SG_LAUNCH_CHECK("sg_conv2d_wino_wgrad");
+  return 0;
+}
+
+extern "C" size_t sg_plan_cache_bytes(void) {
+  std::lock_guard<std::mutex> lk(g_tab_mu);
+  return g_tab_bytes;
+}
+extern "C" int sg_plan_cache_clear(void) {
+  std::lock_guard<std::mutex> lk(g_tab_mu);
+  for (auto& kv : g_tabs) { hipEventSynchronize(kv.second.ready); hipEventDestroy(kv.second.ready); hipFree(kv.second.dev); }
+  g_tabs.clear();
+  g_tab_bytes = 0;
   return 0;
 }
 

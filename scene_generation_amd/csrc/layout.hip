@@ -239,26 +239,86 @@ __global__ void crop_fwd_kernel(const float* __restrict__ feats, const float* __
   }
 }
 
-__global__ void crop_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ boxes,
-                                const int64_t* __restrict__ b2f, float* __restrict__ gf, int C, int H, int W, int B, int HH,
-                                int WW) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)B * HH * WW) return;
-  const int x = i % WW;
-  const int y = (i / WW) % HH;
-  const int b = i / ((size_t)WW * HH);
-  Tap ty, tx;
-  crop_taps(boxes, b, y, x, HH, WW, H, W, ty, tx);
-  float* fp = gf + (size_t)b2f[b] * C * H * W;
-  const float* gp = gout + (size_t)b * C * HH * WW + (size_t)y * WW + x;
-  for (int c = 0; c < C; ++c) {
-    float* f = fp + (size_t)c * H * W;
-    const float g = gp[(size_t)c * HH * WW];
-    const float w00 = ty.w0 * tx.w0, w01 = ty.w0 * tx.w1, w10 = ty.w1 * tx.w0, w11 = ty.w1 * tx.w1;
-    if (w00 != 0.f) atomicAdd(f + ty.i0 * W + tx.i0, g * w00);
-    if (w01 != 0.f) atomicAdd(f + ty.i0 * W + tx.i1, g * w01);
-    if (w10 != 0.f) atomicAdd(f + ty.i1 * W + tx.i0, g * w10);
-    if (w11 != 0.f) atomicAdd(f + ty.i1 * W + tx.i1, g * w11);
+// Gradient w.r.t. feats as a GATHER (bit-reproducible; the first version scattered with fp32 atomics, whose order of
+// additions changed from run to run).  Workgroup = (image n, 256 pixels); the boxes cropping image n are compacted, 256 at a
+// time and in ascending order, into LDS; every pixel then visits, box by box, the few crop pixels whose bilinear footprint
+// covers it: the sample coordinate is affine in the crop index, so the candidates per axis are an index range (taken with one
+// spare element on each side and confirmed with the exact forward taps).  Additions happen in (box, crop row, crop column)
+// order.
+__device__ __forceinline__ void crop_axis_range(float c0, float c1, int n_crop, int size, int u, int& lo, int& hi) {
+  // pixel coordinate of crop index j: p(j) ~ p0 + s*j with p0 = p(0), s = (p(n-1) - p(0)) / (n-1)
+  const float p0 = ((c0 + 1.f) * (float)size - 1.f) * 0.5f;
+  const float p1 = ((c1 + 1.f) * (float)size - 1.f) * 0.5f;
+  lo = 0; hi = n_crop - 1;
+  if (n_crop == 1 || !(fabsf(p0) < 1e8f) || !(fabsf(p1) < 1e8f)) return;      // degenerate: test every index
+  const float s = (p1 - p0) / (float)(n_crop - 1);
+  if (fabsf(s) < 1e-6f) return;
+  // taps of j touch pixel u iff u-1 <= p(j) < u+1
+  float a = ((float)(u - 1) - p0) / s, b = ((float)(u + 1) - p0) / s;
+  if (a > b) { const float t = a; a = b; b = t; }
+  const float fl = floorf(a) - 1.f, fh = ceilf(b) + 1.f;
+  lo = fl < 0.f ? 0 : (fl > (float)(n_crop - 1) ? n_crop : (int)fl);
+  hi = fh > (float)(n_crop - 1) ? n_crop - 1 : (fh < 0.f ? -1 : (int)fh);
+}
+
+template <int CT>
+__global__ void __launch_bounds__(256) crop_bwd_gather_kernel(const float* __restrict__ gout, const float* __restrict__ boxes,
+                                                             const int64_t* __restrict__ b2f, float* __restrict__ gf, int C,
+                                                             int H, int W, int B, int HH, int WW) {
+  __shared__ int list[256];
+  __shared__ int wcnt[4];
+  const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int pix = blockIdx.x * 256 + tid;
+  const bool live = pix < H * W;
+  const int v = live ? pix / W : 0, u = live ? pix - (pix / W) * W : 0;
+  for (int c0 = 0; c0 < C; c0 += CT) {
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = 0.f;
+    for (int b0 = 0; b0 < B; b0 += 256) {
+      // ordered compaction of the boxes of image n among [b0, b0 + 256)
+      const int b = b0 + tid;
+      const bool mine = b < B && (int)b2f[b] == n;
+      const unsigned long long bal = __ballot(mine);
+      if (lane == 0) wcnt[wid] = __popcll(bal);
+      __syncthreads();
+      int base = 0, total = 0;
+      for (int w = 0; w < 4; ++w) { if (w < wid) base += wcnt[w]; total += wcnt[w]; }
+      if (mine) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = b;
+      __syncthreads();
+      if (live) {
+        for (int k = 0; k < total; ++k) {
+          const int bb = list[k];
+          const float x0 = 2.f * boxes[bb * 4 + 0] - 1.f, y0 = 2.f * boxes[bb * 4 + 1] - 1.f;
+          const float x1 = 2.f * boxes[bb * 4 + 2] - 1.f, y1 = 2.f * boxes[bb * 4 + 3] - 1.f;
+          int jlo, jhi, ilo, ihi;
+          crop_axis_range(x0, x1, WW, W, u, jlo, jhi);
+          if (jlo > jhi) continue;
+          crop_axis_range(y0, y1, HH, H, v, ilo, ihi);
+          const float* gp = gout + ((size_t)bb * C + c0) * HH * WW;
+          for (int i = ilo; i <= ihi; ++i) {
+            const Tap ty = make_tap(lin10(i, HH) * y0 + lin01(i, HH) * y1, H);
+            const float wy = (ty.i0 == v ? ty.w0 : 0.f) + (ty.i1 == v ? ty.w1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int j = jlo; j <= jhi; ++j) {
+              const Tap tx = make_tap(lin10(j, WW) * x0 + lin01(j, WW) * x1, W);
+              const float wx = (tx.i0 == u ? tx.w0 : 0.f) + (tx.i1 == u ? tx.w1 : 0.f);
+              if (wx == 0.f) continue;
+              const float wgt = wy * wx;
+#pragma unroll
+              for (int c = 0; c < CT; ++c)
+                if (c0 + c < C) acc[c] += gp[((size_t)c * HH + i) * WW + j] * wgt;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        if (c0 + c < C) gf[((size_t)n * C + c0 + c) * H * W + pix] = acc[c];
+    }
   }
 }
 
@@ -466,9 +526,14 @@ extern "C" int sg_crop_bbox_bwd(const float* gout, const float* boxes, const int
   SG_ARG_CHECK(gout && boxes && box_to_feat && g_feats && N > 0 && C > 0 && B >= 0, "sg_crop_bbox_bwd: bad arguments");
   if (B == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  SgProfScope prof(SG_K_CROP, s, 0, 4.0 * B * C * (double)HH * WW * 5);
-  hipLaunchKernelGGL(crop_bwd_kernel, dim3(sg_cdiv((size_t)B * HH * WW, 256)), dim3(256), 0, s, gout, boxes, box_to_feat,
-                     g_feats, C, H, W, B, HH, WW);
+  SgProfScope prof(SG_K_CROP, s, 0, 4.0 * B * C * (double)HH * WW + 4.0 * N * C * (double)H * W);
+  // writes EVERY element of g_feats (no zero fill needed), additions in a fixed order
+  if (C <= 1)
+    hipLaunchKernelGGL(crop_bwd_gather_kernel<1>, dim3(sg_cdiv(H * W, 256), N), dim3(256), 0, s, gout, boxes, box_to_feat,
+                       g_feats, C, H, W, B, HH, WW);
+  else
+    hipLaunchKernelGGL(crop_bwd_gather_kernel<4>, dim3(sg_cdiv(H * W, 256), N), dim3(256), 0, s, gout, boxes, box_to_feat,
+                       g_feats, C, H, W, B, HH, WW);
   SG_LAUNCH_CHECK("sg_crop_bbox_bwd");
   return 0;
 }

@@ -108,7 +108,8 @@ class Model(nn.Module):
             # nothing on the training step reads the dense layouts (the convs over them run on the factored form): their
             # kernels are deferred until a dense read (ops.ensure_dense; Trainer.step does it for the outputs it returns)
             def layout_of(vecs, masks):
-                return ops.masks_to_layout_deferred(vecs, boxes_gt, masks, seg, N, H, W, False, self.layout_objects_hint)
+                return ops.masks_to_layout_deferred(vecs, boxes_gt, masks, seg, N, H, W, False, self.layout_objects_hint,
+                                                    differentiable=vecs.requires_grad)
         else:
             def layout_of(vecs, masks):
                 return masks_to_layout(vecs, boxes_gt, masks, obj_to_img, H, W, test_mode=False,
@@ -141,7 +142,7 @@ class Model(nn.Module):
             f_wrong = ops.FactoredLayout(Z, objs, wrong_layout_vecs[:, self.num_objs:].detach(), self.num_objs, obj_to_img,
                                          pidx, counts)
             f_wrong._lists = f_gt._lists          # same objects: share the list cache
-            ops.set_hints(gt_layout, factored=f_gt, keep_grad=lazy)
+            ops.set_hints(gt_layout, factored=f_gt)
             ops.set_hints(wrong_layout, factored=f_wrong)
         imgs_pred = self.layout_to_image(gt_layout)
         return imgs_pred, boxes_pred, masks_pred, gt_layout, pred_layout, wrong_layout

@@ -424,6 +424,9 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, upsample=1, act
         if not (x.requires_grad or h.get('keep_grad')):     # a detached layout: no gradient reaches the appearance
             f = f.detached()                                # vectors through its factored form either
         return factored_layout_conv(f, weight, bias, stride, pad, reflect, act, slope, x2)
+    if h.get('pending') is not None and x.requires_grad:
+        raise NotImplementedError('a lazily built layout (Model.lazy_layouts) only carries gradients through its factored '
+                                  'form; this convolution needs the dense tensor -- build the model output densely')
     ensure_dense(x)
     grad_from = int(h.get('grad_from', 0)) if x.requires_grad else 0
     if not (0 < grad_from < x.size(1)):
@@ -1005,11 +1008,12 @@ class MasksToLayoutFn(Function):
         return gv, None, None, None, None, None, None, None, None, None
 
 
-def masks_to_layout_deferred(vecs, boxes, masks, seg_off, N, H, W, avg, max_per_image):
+def masks_to_layout_deferred(vecs, boxes, masks, seg_off, N, H, W, avg, max_per_image, differentiable=False):
     """An (N, D, H, W) layout whose sg_masks_to_layout_fwd launch is DEFERRED until somebody reads it densely
     (ensure_dense): with the factored layout convs nothing on the training step does -- the three dense 428 MB layouts of
     model.py:119-121 are outputs for logging only (train.py:201-203,219).  No autograd history: gradients reach the
-    appearance vectors through the factored form."""
+    appearance vectors through the factored form.  ``differentiable`` marks the result as requiring grad (like the
+    reference's gt_layout) so that consumers can tell it from its ``.detach()``."""
     vecs, boxes = _f32(vecs.detach(), 'vecs'), _f32(boxes.detach(), 'boxes')
     masks = _dev(masks.detach(), 'masks')
     if masks.dtype not in (torch.int64, torch.float32):
@@ -1021,6 +1025,8 @@ def masks_to_layout_deferred(vecs, boxes, masks, seg_off, N, H, W, avg, max_per_
     def fill():
         _call('sg_masks_to_layout_fwd', _p(vecs), _p(boxes), _p(masks), 1 if masks.dtype == torch.int64 else 0, _p(seg_off),
               _p(out), N, O, D, masks.size(1), H, W, 1 if avg else 0, max_per_image, _stream())
+    if differentiable:
+        out.requires_grad_(True)
     return set_hints(out, pending=fill)
 
 
@@ -1220,7 +1226,7 @@ class CropBBoxFn(Function):
         gf = None
         if ctx.needs_input_grad[0]:
             g = _f32(g)
-            gf = torch.zeros(N, C, H, W, dtype=torch.float32, device=g.device)
+            gf = torch.empty(N, C, H, W, dtype=torch.float32, device=g.device)     # the gather writes every element
             _call('sg_crop_bbox_bwd', _p(g), _p(boxes), _p(idx), _p(gf), N, C, H, W, B, HH, WW, _stream())
         return gf, None, None, None, None
 

@@ -86,6 +86,13 @@ CONV_CASES = [
     (2, 128, 0, 32, 32, 128, 3, 1, 1, False, 1, 0),    # big enough for the 128x128 tile
     (8, 128, 0, 8, 8, 128, 3, 1, 1, True, 1, 0),       # Winograd F(2x2,3x3) path (channels, tiles multiples of 128)
     (2, 256, 0, 16, 16, 128, 3, 1, 1, True, 1, 1),     # Winograd, Cin != Cout, fused ReLU
+    (2, 128, 0, 16, 16, 256, 3, 1, 1, False, 1, 1),    # Winograd, ZERO padding (VGG19 convs), fused ReLU
+    (8, 128, 0, 8, 12, 128, 3, 1, 1, False, 1, 0),     # Winograd, zero padding, non-square plane (tiles 8*4*6 = 192: 64-tiles)
+    (3, 192, 0, 8, 8, 192, 3, 1, 1, False, 2, 0),      # Winograd behind the folded x2 upsample, 192 channels (mask_net), 64-tiles
+    (4, 64, 0, 16, 16, 64, 3, 1, 1, False, 1, 1),      # 64 channels: stays on the direct kernel (VGG conv1_2)
+    (2, 3, 0, 32, 32, 64, 3, 1, 1, False, 1, 1),       # VGG conv1_1
+    (2, 16, 0, 15, 17, 8, 3, 2, 1, False, 1, 0),       # stride-2 dgrad: four parity classes of different sizes in one launch
+    (2, 8, 0, 12, 12, 24, 4, 2, 1, False, 1, 0),       # k4 s2 p1: equal classes
 ]
 
 
@@ -158,9 +165,9 @@ def test_conv2d_channel_sparse(hip, N, C, dense, H, Cout, KS, stride, pad, refle
     x2g = x2.to(DEV).requires_grad_() if C2 else None
     if C2:
         cl, cc = active_layout_channels(objs, o2i, N, num_objs, dense, extra=C2)
-        xg._sg_sparse_cat = {C2: (torch.from_numpy(cl).to(DEV), torch.from_numpy(cc).to(DEV))}
+        hip.set_hints(xg, sparse_cat={C2: (torch.from_numpy(cl).to(DEV), torch.from_numpy(cc).to(DEV))})
     else:
-        xg._sg_sparse = (torch.from_numpy(cl).to(DEV), torch.from_numpy(cc).to(DEV))
+        hip.set_hints(xg, sparse=(torch.from_numpy(cl).to(DEV), torch.from_numpy(cc).to(DEV)))
     assert 2 * cl.shape[1] <= C
     yg = hip.conv2d(xg, wg, bg, stride=stride, pad=pad, reflect=reflect, act=1, x2=x2g)
     yg.backward(gy.to(DEV))
@@ -198,7 +205,7 @@ def test_factored_layout_conv_matches_dense(hip, KS, stride, pad, reflect, C2, H
                 plane.append(counts[i]); counts[i] += 1
             pidx = torch.tensor(plane, device=DEV)
             Z = hip.layout_planes(b.boxes.to(DEV), b.masks.to(DEV), hip.segment_offsets(o2i, 4), pidx, 4, max(counts), H, H)
-            layout._sg_factored = hip.FactoredLayout(Z, objs, vecs[:, num_objs:], num_objs, o2i, pidx, counts)
+            hip.set_hints(layout, factored=hip.FactoredLayout(Z, objs, vecs[:, num_objs:], num_objs, o2i, pidx, counts))
         y = hip.conv2d(layout, w, bias, stride=stride, pad=pad, reflect=reflect, act=2, slope=0.2, x2=x2)
         (y * det(tuple(y.shape), 95).to(DEV)).sum().backward()
         outs.append((y.detach(), w.grad, bias.grad, rep.grad, None if x2 is None else x2.grad))
@@ -896,3 +903,400 @@ def test_fast_paths_agree_with_plain_paths(hip):
     close(res[0][0], res[1][0], 2e-4, 'imgs_pred fast vs plain')
     for k, v in res[1][1].items():
         assert abs(res[0][1][k] - v) <= 2e-3 * max(1.0, abs(v)), (k, res[0][1][k], v)
+
+
+# ------------------------------------------------------------------------------------------
+# round 2: pooling for VGG, loss variants, gradient sinks, deterministic crops, drop-in loop
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('shape', [(3, 5, 8, 12), (2, 4, 7, 9), (1, 2, 2, 2), (2, 64, 32, 32)])
+def test_maxpool2(hip, shape):
+    x = det(shape, 301)
+    x[0, 0, :2, :2] = 0.25                                   # a tie: the first element of the window must win
+    xr = x.clone().requires_grad_()
+    yr = F.max_pool2d(xr, 2, 2)
+    gy = det(tuple(yr.shape), 302)
+    yr.backward(gy)
+    xg = x.to(DEV).requires_grad_()
+    yg = hip.maxpool2(xg)
+    yg.backward(gy.to(DEV))
+    assert torch.equal(yg.cpu(), yr)
+    assert torch.equal(xg.grad.cpu(), xr.grad)
+
+
+def test_loss_variants_vs_reference(hip, golden):
+    """--gan_loss_type wgan | lsgan and GANLoss(use_lsgan=False) against the reference goldens (losses.py:93-132,147)."""
+    from scene_generation_amd import losses as Lh
+    g = golden('losses_variants')
+    for name, two in [('wgan_g', False), ('wgan_d', True), ('lsgan_g', False), ('lsgan_d', True)]:
+        gl, dl = Lh.get_gan_losses(name.split('_')[0])
+        sr, sf = [torch.from_numpy(g[k]).to(DEV).requires_grad_() for k in ('sr', 'sf')]
+        v = dl(sr, sf) if two else gl(sf)
+        close(v, g[name], 2e-6, name)
+        v.backward()
+        close(sf.grad, g[name + '_gsf'], 2e-6)
+        if two:
+            close(sr.grad, g[name + '_gsr'], 2e-6)
+    crit = Lh.GANLoss(use_lsgan=False)
+    for t in (True, False):
+        p0, p1 = [torch.from_numpy(g[k]).to(DEV).requires_grad_() for k in ('p0', 'p1')]
+        v = crit([[None, p0], [None, p1]], t)
+        close(v, g['bce_%d' % t], 2e-6)
+        v.backward()
+        close(p0.grad, g['bce_%d_g0' % t], 2e-6)
+        close(p1.grad, g['bce_%d_g1' % t], 2e-6)
+
+
+def test_vgg_loss_vs_reference_golden(hip, golden):
+    """VGGLoss (losses.py:179-224) through the HIP conv / max-pool kernels against the reference's own classes (golden
+    captured on the torchvision shim, tools/make_golden.py::golden_vgg): features, loss, d loss / d x."""
+    from scene_generation_amd import losses as Lh
+    g = golden('vgg_loss')
+    crit = Lh.VGGLoss()
+    assert list(crit.vgg.state_dict().keys()) == g['keys'].tolist()
+    fill_deterministic(crit.vgg)
+    crit = crit.to(DEV)
+    x = torch.from_numpy(g['x']).to(DEV).requires_grad_()
+    feats = crit.vgg(x)
+    close(feats[0][:, :4], g['feat0'], 3e-5, 'relu1_1')
+    close(feats[4], g['feat4'], 3e-5, 'relu5_1')
+    loss = crit(x, torch.from_numpy(g['y']).to(DEV))
+    close(loss, g['loss'], 2e-5, 'vgg loss')
+    loss.backward()
+    close(x.grad, g['gx'], 1e-4, 'd vgg / d x')
+    assert all(p.grad is None for p in crit.parameters())          # frozen network: data gradients only
+
+
+def test_vgg_full_width_vs_oracle(hip):
+    """VGG19 at the widths / plane sizes of the training step (128x128 input: Winograd for the >= 128-channel convs, direct
+    kernels for the 3/64-channel ones) vs the oracle restatement, He-normal weights."""
+    from scene_generation_amd import losses as Lh
+    mine = Lh.VGGLoss()
+    ref = O.VGGLoss()
+    ref.vgg.load_state_dict(mine.vgg.state_dict())
+    mine = mine.to(DEV)
+    x, y = det((8, 3, 128, 128), 311), det((8, 3, 128, 128), 312)
+    xr = x.clone().requires_grad_()
+    lr = ref(xr, y)
+    lr.backward()
+    xg = x.to(DEV).requires_grad_()
+    lg = mine(xg, y.to(DEV))
+    lg.backward()
+    close(lg, lr, 1e-4, 'vgg loss')
+    rel = float((xg.grad.cpu() - xr.grad).norm() / xr.grad.norm())
+    assert rel < 2e-3, 'd vgg / d x relative L2 error %.3e' % rel     # 16 ReLU layers: a few units flip (see _compare_grads)
+
+
+def test_weighted_sum_and_gradient_sinks(hip):
+    """ops.weighted_sum (one launch) and the parameter-gradient sinks of FusedAdam: kernels write straight into the flat
+    gradient buffer; a second backward before zero_grad() ACCUMULATES like torch; untouched parameters are skipped."""
+    from scene_generation_amd.optim import FusedAdam
+    from scene_generation_amd import layers as Lh
+    ts = [det((1,), 320 + i).to(DEV).requires_grad_() for i in range(40)]
+    ws = [0.1 * (i - 7) for i in range(40)]
+    tot = hip.weighted_sum([t.reshape(()) for t in ts], ws)
+    close(tot, sum(w * float(t) for w, t in zip(ws, ts)), 1e-6)
+    tot.backward()
+    for w, t in zip(ws, ts):
+        close(t.grad, torch.tensor([w]), 1e-6)
+    net = nn.Sequential(Lh.Conv2d(3, 8, 3, padding=1), Lh.BatchNorm2d(8), Lh.ReLU(), Lh.Conv2d(8, 4, 3, padding=1)).to(DEV)
+    unused = Lh.Linear(5, 5).to(DEV)
+    fill_deterministic(net)
+    ref = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.Conv2d(8, 4, 3, padding=1))
+    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    opt = FusedAdam(list(net.parameters()) + list(unused.parameters()), lr=1e-3)
+    x = det((2, 3, 8, 8), 330)
+    opt.zero_grad()
+    for rep in range(2):                                    # two backwards, one zero_grad: gradients add up
+        net(x.to(DEV)).pow(2).sum().backward()
+        ref(x).pow(2).sum().backward()
+    for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+        assert p.grad.data_ptr() == opt.fp.grad_view([id(a) for a in opt.fp.params].index(id(p))).data_ptr()
+        close(p.grad, q.grad, 1e-4, n)
+    assert opt._touched == [True] * 6 + [False] * 2
+    before = unused.weight.detach().clone()
+    opt.step()
+    assert torch.equal(unused.weight, before) and opt.steps == [1] * 6 + [0] * 2
+
+
+def test_crop_backward_is_deterministic_and_exact(hip):
+    """the gather form of the crop gradient: bit-identical run to run, equals the transpose of the forward (autograd of
+    F.grid_sample) incl. permuted / repeated / out-of-range boxes and up-sampling crops"""
+    from scene_generation_amd.bilinear import crop_bbox_batch
+    g = torch.Generator().manual_seed(5)
+    feats = det((3, 3, 24, 20), 340)
+    B = 14
+    x0, y0 = torch.rand(B, generator=g) * 0.6, torch.rand(B, generator=g) * 0.6
+    boxes = torch.stack([x0, y0, x0 + 0.05 + 0.5 * torch.rand(B, generator=g), y0 + 0.05 + 0.5 * torch.rand(B, generator=g)], 1)
+    boxes[0] = torch.tensor([0., 0., 1., 1.])
+    boxes[1] = torch.tensor([-0.2, 0.3, 0.4, 1.3])
+    boxes[2] = torch.tensor([0.45, 0.45, 0.5, 0.5])            # tiny box, strongly up-sampled
+    idx = torch.tensor([2, 0, 1, 1, 0, 2, 2, 0, 1, 0, 0, 2, 1, 1])
+    for HH in (8, 32):
+        fr = feats.clone().requires_grad_()
+        out_r = O.crop_bbox_batch(fr, boxes, idx, HH)
+        w = det(tuple(out_r.shape), 341)
+        (out_r * w).sum().backward()
+        grads = []
+        for rep in range(2):
+            fg = feats.to(DEV).requires_grad_()
+            out = crop_bbox_batch(fg, boxes.to(DEV), idx.to(DEV), HH)
+            (out * w.to(DEV)).sum().backward()
+            grads.append(fg.grad.clone())
+        close(out, out_r, 1e-5, 'crop')
+        close(grads[0], fr.grad, 2e-5, 'crop gradient')
+        assert torch.equal(grads[0], grads[1])
+
+
+def test_boxes_to_layout_intended_semantics(hip):
+    """boxes_to_layout (layout.py:28-61) raises TypeError in the reference: the intended semantics --
+    every object paints its vector over its box (an all-ones 8x8 mask, layout.py:50) -- vs the oracle's statement of the
+    same; parity with the reference itself is unpinned for this one function."""
+    from scene_generation_amd.layout import boxes_to_layout, masks_to_layout
+    b = make_batch(N=3, min_objs=2, max_objs=5, size=32, seed=77)
+    vecs = det((b.objs.numel(), 9), 350)
+    for pooling in ('sum', 'avg'):
+        vr = vecs.clone().requires_grad_()
+        ref = O.boxes_to_layout(vr, b.boxes, b.obj_to_img, 24, 32, pooling=pooling)
+        w = det(tuple(ref.shape), 351)
+        (ref * w).sum().backward()
+        vg = vecs.to(DEV).requires_grad_()
+        out = boxes_to_layout(vg, b.boxes.to(DEV), b.obj_to_img.to(DEV), 24, 32, pooling=pooling)
+        (out * w.to(DEV)).sum().backward()
+        close(out, ref, 1e-5, 'boxes_to_layout ' + pooling)
+        close(vg.grad, vr.grad, 2e-5, 'boxes_to_layout gradient')
+    # inside a box (away from its border) the layout is exactly the object's vector; outside every box it is zero
+    one = boxes_to_layout(torch.ones(1, 2, device=DEV), torch.tensor([[0.25, 0.25, 0.75, 0.75]], device=DEV),
+                          torch.zeros(1, dtype=torch.long, device=DEV), 32)
+    assert float(one[0, :, 12:20, 12:20].min()) == 1.0 and float(one[0, :, :6].abs().max()) == 0.0
+
+
+def _trainer_pair(argv, vocab, with_vgg):
+    from scene_generation_amd.trainer import Trainer
+    args = parser.parse_args(argv)
+    ref = O.Trainer(args, vocab)
+    for m in (ref.model, ref.netD, ref.obj_discriminator, ref.mask_discriminator):
+        fill_deterministic(m)
+    tr = Trainer(args, vocab)
+    if with_vgg:
+        ref.criterionVGG.vgg.load_state_dict({k: v.cpu() for k, v in tr.criterionVGG.vgg.state_dict().items()})
+    return args, ref, tr
+
+
+def _snapshot(ref):
+    import copy
+    return ([copy.deepcopy(m.state_dict()) for m in (ref.model, ref.netD, ref.obj_discriminator, ref.mask_discriminator)],
+            [copy.deepcopy(getattr(ref, n).state_dict()) for n in ('optimizer', 'optimizer_d_mask', 'optimizer_d_obj',
+                                                                    'optimizer_d_img')], copy.deepcopy(ref.model.fake_pool))
+
+
+def _restore(tr, snap):
+    import copy
+    for m, sd in zip((tr.model, tr.netD, tr.obj_discriminator, tr.mask_discriminator), snap[0]):
+        m.load_state_dict(sd)
+    for n, sd in zip(('optimizer', 'optimizer_d_mask', 'optimizer_d_obj', 'optimizer_d_img'), snap[1]):
+        getattr(tr, n).load_state_dict(sd)
+
+
+def _step_metrics(tr, ref, out, out_ref, snaps):
+    """measured deviations of one HIP step from the oracle step (recorded to gpurun_out/ before anything is asserted)"""
+    m = {}
+    for n, a, b in zip(['imgs_pred', 'boxes_pred', 'masks_pred', 'layout', 'layout_pred', 'layout_wrong'], out, out_ref):
+        m['out_' + n] = float((a.detach().cpu() - b.detach()).abs().max()) / max(1.0, float(b.detach().abs().max()))
+    for tag, La, Lb in [('g', tr.generator_losses, ref.generator_losses), ('dmask', tr.d_mask_losses, ref.d_mask_losses),
+                        ('dobj', tr.d_obj_losses, ref.d_obj_losses), ('dimg', tr.d_img_losses, ref.d_img_losses)]:
+        a, b = dict(La.items()), dict(Lb.items())
+        assert set(a) == set(b), (sorted(a), sorted(b))
+        for k in b:
+            m['loss_%s_%s' % (tag, k)] = abs(a[k] - b[k]) / max(1.0, abs(b[k]))
+    for n, gr in snaps['ref'].items():
+        gh = snaps['hip'][n]
+        fa = torch.cat([a.reshape(-1).double() for a in gh])
+        fb = torch.cat([(torch.zeros_like(a) if b is None else b).reshape(-1).double() for a, b in zip(gh, gr)])
+        m['cos_' + n] = float(fa @ fb / (fa.norm() * fb.norm() + 1e-30))
+        m['rel_' + n] = float((fa - fb).norm() / (fb.norm() + 1e-30))
+        worst = 0.0
+        for a, b in zip(gh, gr):
+            b = (torch.zeros_like(a) if b is None else b).double()
+            if float(b.norm()) > 1e-3 * float(fb.norm()):
+                worst = max(worst, float((a.double() - b).norm() / b.norm()))
+        m['worst_tensor_rel_' + n] = worst
+    return m
+
+
+def _dump(name, obj):
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name), 'w') as f:
+            json.dump(obj, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _assert_step_metrics(m, tag, out_tol, loss_tol):
+    bad = []
+    for k, v in m.items():
+        if k.startswith('out_') and not v <= out_tol:
+            bad.append((k, v))
+        elif k.startswith('loss_') and not v <= loss_tol:
+            bad.append((k, v))
+        elif k.startswith('cos_') and not v > 0.9995:
+            bad.append((k, v))
+        elif k.startswith('worst_tensor_rel_') and not v <= 3e-2:
+            bad.append((k, v))
+    assert not bad, '%s: %s' % (tag, bad)
+
+
+def test_full_step_at_benchmark_shape_vs_oracle(hip):
+    """BASELINE configs[1] shape -- 128x128, <= 8 objects per image, reference default widths and DEFAULT FLAGS (VGG loss on)
+    -- at N = 8 images (8*4*4 = 128 Winograd tiles in the 1024-channel trunk, i.e. every kernel family the bench line runs:
+    Winograd fwd/dgrad/wgrad, factored 204-channel layout convs, 128x128 tiles + split-K, single-launch parity classes,
+    shared D forwards, gradient sinks) against the oracle Trainer: outputs, all named losses, every parameter gradient of
+    all four optimisers, two iterations (use_gt on / off).  The same two iterations with every fast path switched OFF
+    (Winograd, factored layout, shared D forwards, lazy layouts) are checked against the same oracle run."""
+    from scene_generation_amd import ops
+    argv = ['--image_size', '128,128', '--batch_size', '8', '--output_dir', '/tmp/o']
+    vocab = make_vocab()
+    args, ref, tr_fast = _trainer_pair(argv, vocab, True)
+    from scene_generation_amd.trainer import Trainer
+    tr_plain = Trainer(args, vocab)
+    tr_plain.share_d_forward = False
+    tr_plain.criterionVGG.vgg.load_state_dict(tr_fast.criterionVGG.vgg.state_dict())
+    variants = [('fast', tr_fast, True), ('plain', tr_plain, False)]
+    snaps = {}
+    for name, tr, _ in variants:
+        snaps[name], _h = _grad_snapshots(ref, tr)
+    report = {}
+    saved = (ops.WINOGRAD, ops.FACTORED_LAYOUT)
+    try:
+        for it in range(2):
+            batch = make_batch(N=8, min_objs=3, max_objs=8, size=128, seed=40 + it)
+            noise = det((1, args.mask_noise_dim), 141 + it)
+            pre = _snapshot(ref)
+            pool = pre[2]
+            ref.model.noise_override = noise
+            random.seed(15 + it)
+            out_ref = ref.step(batch, use_gt=(it == 0))
+            for name, tr, fast in variants:
+                import copy
+                _restore(tr, pre)
+                tr.model.noise_override = noise
+                ops.WINOGRAD = ops.FACTORED_LAYOUT = fast
+                random.seed(15 + it)
+                out = tr.step(batch_to(batch, DEV), use_gt=(it == 0))
+                snaps[name]['ref'] = snaps['fast']['ref'] if name != 'fast' else snaps[name]['ref']
+                report['%s_it%d' % (name, it)] = _step_metrics(tr, ref, out, out_ref, snaps[name])
+    finally:
+        ops.WINOGRAD, ops.FACTORED_LAYOUT = saved
+    _dump('parity_benchmark_shape.json', report)
+    for k, m in report.items():
+        _assert_step_metrics(m, k, 3e-4, 2e-3)
+
+
+def test_config4_shape_vs_oracle(hip):
+    """BASELINE configs[3] per-GPU shape (256x256, <= 16 objects per image, default widths, default flags incl. VGG) at
+    N = 2: outputs and every named loss of one G+D step against the oracle."""
+    from scene_generation_amd.synthetic import make_config_batch
+    argv = ['--image_size', '256,256', '--batch_size', '2', '--output_dir', '/tmp/o']
+    args, ref, tr = _trainer_pair(argv, make_vocab(), True)
+    _sync_state(ref, tr)
+    b = make_config_batch('c4', seed=5, N=2)
+    noise = det((1, args.mask_noise_dim), 151)
+    ref.model.noise_override = tr.model.noise_override = noise
+    random.seed(3)
+    out_ref = ref.step(b, use_gt=True)
+    random.seed(3)
+    out = tr.step(batch_to(b, DEV), use_gt=True)
+    m = _step_metrics(tr, ref, out, out_ref, {'ref': {}, 'hip': {}})
+    _dump('parity_config4_shape.json', m)
+    _assert_step_metrics(m, 'config4', 3e-4, 2e-3)
+
+
+def test_step_is_bit_reproducible(hip):
+    """The same G+D step from the same state twice: outputs, losses, every gradient and every updated parameter are
+    bit-identical (segmented sums, split-K slabs and the crop gradient all add in a fixed order; no atomics anywhere)."""
+    from scene_generation_amd.trainer import Trainer
+    args = parser.parse_args(['--image_size', '64,64', '--batch_size', '4', '--output_dir', '/tmp/o'])
+    b = batch_to(make_batch(N=4, min_objs=3, max_objs=6, size=64, seed=9), DEV)
+    res = []
+    for rep in range(2):
+        torch.manual_seed(0)
+        tr = Trainer(args, make_vocab())
+        for m in (tr.model, tr.netD, tr.obj_discriminator, tr.mask_discriminator):
+            fill_deterministic(m)
+        tr.model.noise_override = det((1, 64), 131).to(DEV)
+        grads = {}
+        for n in ('optimizer', 'optimizer_d_mask', 'optimizer_d_obj', 'optimizer_d_img'):
+            o = getattr(tr, n)
+            o.pre_step_hooks.append(lambda o=o, n=n: grads.__setitem__(n, o.fp.grad.clone()))
+        random.seed(3)
+        out = tr.step(b, use_gt=True)
+        losses = {}
+        for L in (tr.generator_losses, tr.d_img_losses, tr.d_obj_losses, tr.d_mask_losses):
+            losses.update(dict(L.items()))
+        params = torch.cat([getattr(tr, n).fp.flat for n in ('optimizer', 'optimizer_d_mask', 'optimizer_d_obj',
+                                                            'optimizer_d_img')])
+        res.append(([o.detach().clone() for o in out], losses, grads, params.clone()))
+        del tr
+    for a, b_ in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b_)
+    assert res[0][1] == res[1][1]
+    for n in res[0][2]:
+        assert torch.equal(res[0][2][n], res[1][2][n]), n
+    assert torch.equal(res[0][3], res[1][3])
+
+
+def test_reference_training_loop_through_the_alias(hip):
+    """train.py:190-215 re-stated statement by statement against the ``scene_generation.*`` names that
+    install_as() provides -- plain ``.detach()`` on the layouts, the one-hot channel slices, the four trainer calls -- gives
+    exactly what Trainer.step gives."""
+    import scene_generation_amd
+    scene_generation_amd.install_as('scene_generation', host_package_dir='')
+    from scene_generation.trainer import Trainer
+    from scene_generation.args import get_args
+    args = get_args(['--image_size', '64,64', '--batch_size', '4', '--output_dir', '/tmp/o'])
+    vocab = make_vocab()
+    batch = batch_to(make_batch(N=4, min_objs=3, max_objs=6, size=64, seed=19), DEV)
+    res = []
+    for loop in ('reference', 'step'):
+        torch.manual_seed(0)
+        checkpoint = {'model_kwargs': {}, 'd_obj_kwargs': {}, 'd_mask_kwargs': {}, 'd_img_kwargs': {}, 'losses': {},
+                      'd_losses': {}, 'losses_ts': []}
+        trainer = Trainer(args, vocab, checkpoint)
+        for m in (trainer.model, trainer.netD, trainer.obj_discriminator, trainer.mask_discriminator):
+            fill_deterministic(m)
+        trainer.model.noise_override = det((1, 64), 171).to(DEV)
+        random.seed(11)
+        if loop == 'step':
+            out = trainer.step(batch, use_gt=True)
+            imgs_pred = out[0]
+        else:
+            imgs, objs, boxes, masks, triples, obj_to_img, triple_to_img, attributes = batch
+            use_gt = True
+            model_out = trainer.model(imgs, objs, triples, obj_to_img, boxes_gt=boxes, masks_gt=masks, attributes=attributes)
+            imgs_pred, boxes_pred, masks_pred, layout, layout_pred, layout_wrong = model_out
+            layout_one_hot = layout[:, :trainer.num_obj, :, :]
+            layout_pred_one_hot = layout_pred[:, :trainer.num_obj, :, :]
+            trainer.train_generator(imgs, imgs_pred, masks, masks_pred, layout, objs, boxes, boxes_pred, obj_to_img, use_gt)
+            imgs_pred_detach = imgs_pred.detach()
+            masks_pred_detach = masks_pred.detach()
+            boxes_pred_detach = boxes.detach()
+            layout_detach = layout.detach()
+            layout_wrong_detach = layout_wrong.detach()
+            trainer.train_mask_discriminator(masks, masks_pred_detach, objs)
+            trainer.train_obj_discriminator(imgs, imgs_pred_detach, objs, boxes, boxes_pred_detach, obj_to_img)
+            trainer.train_image_discriminator(imgs, imgs_pred_detach, layout_detach, layout_wrong_detach)
+            trainer.write_losses(checkpoint, 1)
+            trainer.write_images(1, imgs, imgs_pred, layout_one_hot, layout_pred_one_hot)
+            assert checkpoint['losses_ts'] == [1] and 'total_loss' in checkpoint['losses']
+        losses = {}
+        for L in (trainer.generator_losses, trainer.d_img_losses, trainer.d_obj_losses, trainer.d_mask_losses):
+            losses.update(dict(L.items()))
+        flat = torch.cat([getattr(trainer, n).fp.flat for n in ('optimizer', 'optimizer_d_mask', 'optimizer_d_obj',
+                                                                 'optimizer_d_img')]).clone()
+        res.append((imgs_pred.detach().clone(), losses, flat))
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1] == res[1][1], (res[0][1], res[1][1])
+    assert torch.equal(res[0][2], res[1][2])
