@@ -121,7 +121,7 @@ def main():
         backend = os.environ.get('SG_DIST_BACKEND', 'nccl')
         dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from scene_generation_amd import ops
+    from scene_generation_amd import ops, graphs
     from scene_generation_amd.args import parser
     from scene_generation_amd.synthetic import make_batch, make_vocab
     from scene_generation_amd.pipeline import DeviceBatchPrefetcher
@@ -175,7 +175,7 @@ def main():
             d = float(t.item())
         return d
 
-    for i in range(a.warmup):
+    for i in range(max(a.warmup, 4)):             # >= 4: two eager steps, the hipGraph capture, one replay (graphs.py)
         one_step(tr, i)
     # headline pass: exactly K steps, no per-launch instrumentation
     dt = timed(tr, a.steps, a.warmup)
@@ -201,7 +201,7 @@ def main():
                                                         'on (weight %g)' % a.vgg if a.vgg > 0 else 'off (SURVEY 8d)'),
                    'global_batch': B * world, 'image_size': S, 'parallelism': 'dp%d' % world,
                    'share_d_forward': not a.no_share_d_forward, 'vgg_features_weight': a.vgg,
-                   'dense_layout_outputs': False},
+                   'dense_layout_outputs': False, 'hip_graphs': graphs.ENABLED},
         # wall time the host needed to ISSUE the K steps (no sync): close to ms_per_step => launch-bound
         'host_issue_ms_per_step': 1e3 * host_issue / a.steps,
     }
@@ -247,9 +247,9 @@ def main():
         # (1) the reference's DEFAULT flags: VGG19 perceptual loss on (args.py:73), random-init VGG weights
         if a.vgg == 0:
             tr2 = make_trainer(10.0)
-            for i in range(2):
+            for i in range(4):                    # 2 eager steps + the hipGraph capture + 1 replay before timing
                 one_step(tr2, i)
-            d2 = timed(tr2, n2, 2)
+            d2 = timed(tr2, n2, 4)
             sec['default_flags_vgg_on'] = {'images_per_s': B * n2 / d2, 'ms_per_step': 1e3 * d2 / n2, 'steps': n2,
                                            'note': '--vgg_features_weight 10 (args.py:73), He-normal VGG19 weights'}
             del tr2
@@ -261,9 +261,9 @@ def main():
             tr3 = make_trainer(a.vgg)
             tr3.share_d_forward = False
             tr3.dense_layout_outputs = True
-            for i in range(2):
+            for i in range(4):
                 one_step(tr3, i)
-            d3 = timed(tr3, n2, 2)
+            d3 = timed(tr3, n2, 4)
             sec['fast_paths_off'] = {'images_per_s': B * n2 / d3, 'ms_per_step': 1e3 * d3 / n2, 'steps': n2,
                                      'note': 'SG_WINOGRAD=0 SG_FACTORED_LAYOUT=0 --no_share_d_forward, dense layouts written'}
             del tr3

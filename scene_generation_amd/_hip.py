@@ -10,7 +10,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'sg2im_hip.h')
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libsg2im_hip.so')
+LIB_PATH = os.environ.get('SG_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libsg2im_hip.so')   # SG_LIB_PATH: kernel-variant builds
 
 
 class sgConvDesc(ctypes.Structure):

@@ -241,7 +241,10 @@ const void* cached_table(TabKey key, size_t bytes, hipStream_t s, Build build) {
     g_tab_bytes += bytes;
     it = g_tabs.emplace(key, e).first;
   } else if (it->second.stream != s) {
-    hipStreamWaitEvent(s, it->second.ready, 0);
+    // (a capturing stream must not wait on an event recorded outside the capture; a graph is only ever captured after the
+    //  eager warm-up iterations that built the table, so the table is long complete)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs == hipStreamCaptureStatusNone) hipStreamWaitEvent(s, it->second.ready, 0);
   }
   return it->second.dev;
 }
@@ -1976,8 +1979,9 @@ int wino_tile(const sgConvDesc* d) {
   if (LH < 4 || LW < 4 || (LH & 1) || (LW & 1) || d->OH != LH || d->OW != LW) return 0;
   if (d->C1 < 128 || d->Cout < 128) return 0;
   const long P = (long)d->N * (LH / 2) * (LW / 2);
-  if (!(16.0 * (P + 128.0 * d->N * (LH + LW)) * (d->C1 > d->Cout ? d->C1 : d->Cout) < 2147483647.0 && 16.0 * d->C1 * d->Cout < 2147483647.0))
-    return 0;
+  // 32-bit element offsets into the transformed operands (the reflect dgrad works on the (LH+2) x (LW+2) grid, 128-padded)
+  const double Pmax = (double)d->N * (LH / 2 + 1) * (LW / 2 + 1) + 128.0;
+  if (!(16.0 * Pmax * (d->C1 > d->Cout ? d->C1 : d->Cout) < 2147483647.0 && 16.0 * d->C1 * d->Cout < 2147483647.0)) return 0;
   if (d->C1 % 128 == 0 && d->Cout % 128 == 0 && P % 128 == 0) return 128;
   if (d->C1 % 64 == 0 && d->Cout % 64 == 0 && P % 64 == 0) return 64;
   return 0;

@@ -74,6 +74,17 @@ class GlobalGenerator(nn.Module):
                     norm_layer(narrow), relu]
         seq += [ReflectionPad2d(3), Conv2d(widths[0], output_nc, kernel_size=7, padding=0), Tanh()]
         self.model = FusedSequential(*seq)
+        # everything behind the first convolution has static shapes (N x ngf x H x W in, the image out) whatever the scene
+        # graphs look like: replayed as one hipGraph forward and one backward (graphs.py); the stem sees the per-batch
+        # object lists (factored layout conv) and stays eager.  Only the image is handed out as a copy: callers keep it
+        # across iterations (train.py:203,219)
+        from .graphs import GraphedSegment
+        self._tail = GraphedSegment(self._run_tail, params=[p for m in list(self.model)[2:] for p in m.parameters()],
+                                    clone_outputs=True, name='GlobalGenerator[2:]')
+
+    def _run_tail(self, h):
+        return self.model(h, start=2)
 
     def forward(self, input):
-        return self.model(input)
+        h = self.model(input, end=2)          # ReflectionPad2d(3) + Conv7x7 over the layout
+        return self._tail(h)

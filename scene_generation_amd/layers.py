@@ -175,8 +175,10 @@ class Flatten(nn.Module):
 # ---------------------------------------------------------------------------------------------
 
 class FusedSequential(nn.Sequential):
-    def forward(self, x, skip=None):
-        mods = list(self)
+    def forward(self, x, skip=None, start=0, end=None):
+        """``start`` / ``end``: run only modules [start, end) (the generator splits itself into a dynamic-shape stem and a
+        static-shape remainder that is replayed as a hipGraph)"""
+        mods = list(self)[start:end]
         n = len(mods)
         i = 0
         while i < n:

@@ -131,6 +131,9 @@ class Vgg19(nn.Module):
         if not requires_grad:
             for p in self.parameters():
                 p.requires_grad = False
+        # static shapes, frozen parameters: one hipGraph for the forward and one for the data gradient (graphs.py)
+        from .graphs import GraphedSegment
+        self._graphed = GraphedSegment(self._features, params=list(self.parameters()), name='Vgg19')
 
     def load_torchvision_state_dict(self, sd):
         """``sd``: torchvision vgg19 state_dict (keys ``features.<i>.weight|bias``) or a path to one"""
@@ -145,13 +148,16 @@ class Vgg19(nn.Module):
                     raise KeyError('VGG19 weights: no entry for features.%s' % idx)
                 p.copy_(src.to(p.device, p.dtype))
 
-    def forward(self, X):
+    def _features(self, X):
         h_relu1 = self.slice1(X)
         h_relu2 = self.slice2(h_relu1)
         h_relu3 = self.slice3(h_relu2)
         h_relu4 = self.slice4(h_relu3)
         h_relu5 = self.slice5(h_relu4)
         return [h_relu1, h_relu2, h_relu3, h_relu4, h_relu5]
+
+    def forward(self, X):
+        return self._graphed(X)
 
 
 class VGGLoss(nn.Module):

@@ -25,22 +25,23 @@ def _L():
     return _hip.lib()
 
 
-# raw handle of the current stream without building a torch.cuda.Stream object (this runs once per kernel launch)
+# raw handle of the current stream without building a torch.cuda.Stream object (this runs once per kernel launch: the
+# handle and the tensor addresses are passed to ctypes as plain ints, no c_void_p objects)
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_cur_dev = torch.cuda.current_device
 
 
 def _stream_handle():
     if _raw_stream is not None:
-        return _raw_stream(torch.cuda.current_device())
+        return _raw_stream(_cur_dev())
     return torch.cuda.current_stream().cuda_stream
 
 
-def _stream():
-    return ctypes.c_void_p(_stream_handle())
+_stream = _stream_handle
 
 
 def _p(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()
 
 
 def _dev(t, name='tensor'):
@@ -125,6 +126,23 @@ def _sink_of(param):
     return sk
 
 
+_CAPTURE = None          # while a backward is being captured into a hipGraph: [forced sink mode, [(optimiser, index), ...]]
+
+
+@contextlib.contextmanager
+def capture_deliveries(mode):
+    """Backward capture of a graphed segment (graphs.py): the overwrite-vs-add decision of the sinks is fixed to ``mode``
+    (it would otherwise be taken from the optimiser's state at capture time and then frozen into the graph), and the
+    notifications to the optimisers are collected instead of issued (the graph replays re-issue them)."""
+    global _CAPTURE
+    assert _CAPTURE is None
+    _CAPTURE = [mode, []]
+    try:
+        yield _CAPTURE[1]
+    finally:
+        _CAPTURE = None
+
+
 class GradOut(object):
     """where the gradient of ``param`` goes: ``buf`` is what the kernel writes; ``finish()`` is what backward returns"""
     __slots__ = ('sink', 'buf', 'mode')
@@ -133,7 +151,7 @@ class GradOut(object):
         sk = self.sink = _sink_of(param)
         if sk is None:
             self.buf, self.mode = torch.empty_like(param), 2
-        elif not sk.opt()._touched[sk.i]:
+        elif (_CAPTURE[0] == 0) if _CAPTURE is not None else (not sk.opt()._touched[sk.i]):
             self.buf, self.mode = sk.view, 0               # first contribution since zero_grad(): write in place
         else:
             self.buf, self.mode = torch.empty_like(param), 1
@@ -144,7 +162,10 @@ class GradOut(object):
         sk = self.sink
         if self.mode == 1:
             _call('sg_axpy', _p(sk.view), _p(self.buf), 1.0, self.buf.numel(), _stream())
-        sk.opt()._on_grad(sk.i)
+        if _CAPTURE is not None:
+            _CAPTURE[1].append((sk.opt(), sk.i))
+        else:
+            sk.opt()._on_grad(sk.i)
         return None
 
 
@@ -349,6 +370,11 @@ def skip_param_grads(params):
 
 def _wants_grad(t):
     return t is not None and t.data_ptr() not in _SKIP_PARAM_GRADS
+
+
+def skip_state_key():
+    """hashable summary of the skip set (part of the key of captured graphs: it changes what a backward computes)"""
+    return len(_SKIP_PARAM_GRADS)
 
 
 # ---- layout hints -------------------------------------------------------------------------------------
@@ -1184,10 +1210,9 @@ def factored_layout_conv(f, weight, bias, stride, pad, reflect, act, slope, x2):
     N = f.Z.size(0)
     clist, ccnt, extra_pos, L = f.lists(C2)
     w_full = weight
-    if not _wants_grad(weight):
-        # a discriminator inside the generator step (skip_param_grads): no gradient may reach the parameter through the
-        # per-image filters either -- otherwise its AccumulateGrad (and the DP reducer hook) fires with a zero gradient
-        weight = weight.detach()
+    # (a discriminator inside the generator step runs under skip_param_grads: PerImageConvFn then returns no gradient for
+    #  the per-image filters, the None propagates through the assembly below and the parameter's AccumulateGrad never
+    #  fires; the SAME recorded forward still yields the weight gradient when the discriminator step differentiates it)
     # per-object filters  W_eff[o] = W[:, class_o] + sum_d repr[o, d] W[:, num_objs + d]      -> [O, M * KS2]
     table = weight[:, :f.num_objs].permute(1, 0, 2, 3).reshape(f.num_objs, M * KS2).contiguous()
     w_rep = weight[:, f.num_objs:cfull].permute(0, 2, 3, 1).reshape(M * KS2, R)
@@ -1380,8 +1405,17 @@ def scale_(t, alpha):
 
 
 # ---- profiler ----
+_PROF_ON = False
+
+
 def prof_enable(on=True):
+    global _PROF_ON
+    _PROF_ON = bool(on)
     _L().sg_prof_enable(1 if on else 0)
+
+
+def prof_is_enabled():
+    return _PROF_ON
 
 
 def prof_reset():

@@ -1300,3 +1300,46 @@ def test_reference_training_loop_through_the_alias(hip):
     assert torch.equal(res[0][0], res[1][0])
     assert res[0][1] == res[1][1], (res[0][1], res[1][1])
     assert torch.equal(res[0][2], res[1][2])
+
+
+def test_graphed_segments_are_bit_identical_to_eager(hip):
+    """hipGraph replay of the generator tail and of VGG19 (graphs.py) vs the eager launches: five G+D steps with the
+    reference's default flags give bit-identical losses and parameters (the first two steps are eager in both runs, the
+    third captures, the rest replay; box_net-less use_gt=False steps alternate)."""
+    from scene_generation_amd import graphs
+    from scene_generation_amd.trainer import Trainer
+    args = parser.parse_args(['--image_size', '64,64', '--batch_size', '4', '--output_dir', '/tmp/o'])
+    batches = [batch_to(make_batch(N=4, min_objs=3, max_objs=6, size=64, seed=60 + i), DEV) for i in range(2)]
+    res = []
+    saved = graphs.ENABLED
+    try:
+        for enabled in (True, False):
+            graphs.ENABLED = enabled
+            torch.manual_seed(0)
+            tr = Trainer(args, make_vocab())
+            for m in (tr.model, tr.netD, tr.obj_discriminator, tr.mask_discriminator):
+                fill_deterministic(m)
+            tr.model.noise_override = det((1, 64), 181).to(DEV)
+            random.seed(21)
+            hist = []
+            for it in range(5):
+                out = tr.step(batches[it % 2], use_gt=(it % 2 == 0))
+                losses = {}
+                for L in (tr.generator_losses, tr.d_img_losses, tr.d_obj_losses, tr.d_mask_losses):
+                    losses.update(dict(L.items()))
+                hist.append((losses, out[0].detach().clone()))
+            if enabled:
+                tail = tr.model.layout_to_image._tail
+                assert any(e not in (None, False) for e in tail.entries.values()), 'the generator tail was never captured'
+                assert any(e not in (None, False) for e in tr.criterionVGG.vgg._graphed.entries.values())
+            flat = torch.cat([getattr(tr, n).fp.flat for n in ('optimizer', 'optimizer_d_mask', 'optimizer_d_obj',
+                                                              'optimizer_d_img')]).clone()
+            res.append((hist, flat, list(tr.optimizer.steps)))
+            del tr
+    finally:
+        graphs.ENABLED = saved
+    for (la, ia), (lb, ib) in zip(res[0][0], res[1][0]):
+        assert la == lb, (la, lb)
+        assert torch.equal(ia, ib)
+    assert torch.equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2]

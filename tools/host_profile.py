@@ -10,8 +10,9 @@ tr = Trainer(args, make_vocab(), device='cuda')
 b = batch_to(make_batch(N=32, min_objs=3, max_objs=8, size=128, seed=1), 'cuda')
 tr.model.objs_host, tr.model.obj_to_img_host = b.objs.tolist(), b.obj_to_img.tolist()
 tr.model.layout_objects_hint = 9
+tr.dense_layout_outputs = False
 random.seed(0)
-for i in range(3):
+for i in range(5):
     tr.step(b, use_gt=bool(i % 2))
 torch.cuda.synchronize()
 pr = cProfile.Profile()
@@ -21,4 +22,5 @@ for i in range(3):
 pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
-st.sort_stats('tottime').print_stats(28)
+st.sort_stats('tottime').print_stats(40)
+st.sort_stats('cumulative').print_stats(25)
