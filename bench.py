@@ -180,14 +180,25 @@ def main():
     for i in range(a.warmup):
         one_step(tr, i)
     # headline pass: exactly K steps, no per-launch instrumentation
+    calls0, replays0 = ops.CALLS[0], graphs.REPLAYS[0]
     dt = timed(tr, a.steps, a.warmup)
     host_issue = issue[0]
+    calls, replays = (ops.CALLS[0] - calls0) / a.steps, (graphs.REPLAYS[0] - replays0) / a.steps
+    # host cost of ISSUING one step, measured with an idle GPU in front of it: once the step is GPU-bound the number above
+    # mostly measures back-pressure of the full launch queue, not host work
+    iso = []
+    for i in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        one_step(tr, a.warmup + a.steps + i)
+        iso.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
     # roofline pass: the SAME K steps again with a HIP event pair around every kernel launch on the launch stream
     dt_prof = None
     if not a.no_prof:
         ops.prof_reset()
         ops.prof_enable(True)
-        dt_prof = timed(tr, a.steps, a.warmup + a.steps)
+        dt_prof = timed(tr, a.steps, a.warmup + a.steps + 3)
         ops.prof_enable(False)
     # sanity: the step really trained (finite losses)
     total = dict(tr.generator_losses.items())['total_loss']
@@ -206,6 +217,11 @@ def main():
                    'dense_layout_outputs': False, 'hip_graphs': graphs.ENABLED},
         # wall time the host needed to ISSUE the K steps (no sync): close to ms_per_step => launch-bound
         'host_issue_ms_per_step': 1e3 * host_issue / a.steps,
+        # the same for a single step issued into an idle GPU (no queue back-pressure): the host-side cost of a step
+        'host_issue_isolated_ms_per_step': 1e3 * sum(iso) / len(iso),
+        # C-ABI calls (each launches 1..4 kernels) and hipGraph launches the host issues per step; the kernels inside a
+        # replayed graph are dispatched by the GPU front-end without host involvement
+        'host_calls_per_step': calls, 'graph_replays_per_step': replays,
     }
     if world > 1:
         out['rccl_ranks'] = dist.get_world_size()

@@ -238,6 +238,17 @@ int sg_crop_bbox_fwd(const float* feats, const float* boxes, const int64_t* box_
  * footprint covers each image pixel, summed in (box, crop row, crop column) order => bit-reproducible */
 int sg_crop_bbox_bwd(const float* gout, const float* boxes, const int64_t* box_to_feat, float* g_feats, int N, int C,
                      int H, int W, int B, int HH, int WW, sgStream stream);
+/* Per-image filters of the factored layout convs: layout = sum_o [one_hot(class_o) | repr_o] (x) S_o (model.py:165-168,
+ * layout.py:85-86) => conv(layout | x2, w)[n] = sum_j wimg[n][:, j] (*) plane_j with
+ *   wimg[n][m][j][t] = w[m][class_o][t] + sum_d repr[o][d] w[m][C + d][t]   for the j-th object o of image n (j < cnt_n)
+ *                    = w[m][C + R + (j - cnt_n)][t]                         for the C2 channels of the second source
+ * w [M][C + R + C2][KS2], repr [O][R], objs [O] class ids, seg_off [N + 1] object offsets per image, wimg [N][M][L][KS2].
+ * _bwd: gw [M][C + R + C2][KS2] (written completely) and / or grepr [O][R] from gwimg; sums in index order. */
+int sg_factored_weights_fwd(const float* w, const float* repr, const int64_t* objs, const int32_t* seg_off, float* wimg,
+                            int N, int O, int M, int L, int KS2, int C, int R, int C2, sgStream stream);
+int sg_factored_weights_bwd(const float* gwimg, const float* w, const float* repr, const int64_t* objs,
+                            const int32_t* seg_off, const int64_t* img_idx, float* gw, float* grepr, int N, int O, int M,
+                            int L, int KS2, int C, int R, int C2, sgStream stream);
 /* VectorPool.query on device (utils.py:62-90): plan = int32[4][O] rows {class, src_kind, src_idx, slot}
  * out[i] = src_kind ? pool[class][src_idx] : vectors[src_idx]; then pool[class][slot] = vectors[i] (slot>=0) */
 int sg_vector_pool_exchange(float* pool, const float* vectors, const int32_t* plan, float* out, int O, int R,

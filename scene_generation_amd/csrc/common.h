@@ -27,14 +27,14 @@ void sg_set_error(const char* fmt, ...);
   } while (0)
 
 // ---- profiler kinds (bench.py roofline leg) -------------------------------------------------
-// ids 0..35: one per igemm instantiation family: (gather family f, kernel size index k, tile t) -> f*12 + k*3 + t
+// ids 0..47: one per igemm instantiation family: (gather family f, kernel size index k, tile t) -> f*16 + k*4 + t
 //   f: 0 = K=(c,taps) conv-style gather   (conv fwd, convT dgrad)      -> "igemm_kn0_*"
 //      1 = K=(c,taps) transposed gather   (conv dgrad, convT fwd)      -> "igemm_kn1_*"
 //      2 = K=(img,pix) weight-gradient    (conv / convT wgrad)         -> "igemm_nk_*"
-//   k: KS in {1,3,4,7};  t: tile {128x128, 64x64, 32x128}
+//   k: KS in {1,3,4,7};  t: tile {128x128, 64x64, 32x128, 64x128}
 enum {
-  SG_K_IGEMM_BASE = 0, SG_K_IGEMM_COUNT = 36,
-  SG_K_LINEAR = 36, SG_K_LAYOUT_FWD, SG_K_LAYOUT_BWD, SG_K_INSTNORM, SG_K_BATCHNORM, SG_K_ADAM, SG_K_SEGSUM,
+  SG_K_IGEMM_BASE = 0, SG_K_IGEMM_COUNT = 48,
+  SG_K_LINEAR = 48, SG_K_LAYOUT_FWD, SG_K_LAYOUT_BWD, SG_K_INSTNORM, SG_K_BATCHNORM, SG_K_ADAM, SG_K_SEGSUM,
   SG_K_CROP, SG_K_OTHER,
   // the batched dense GEMMs of the Winograd convs, one kind per template instantiation (they used to be lumped into
   // igemm_kn0_k3_t128 together with the direct 3x3 convs) and the elementwise Winograd transforms
@@ -42,7 +42,7 @@ enum {
 };
 static inline int sg_igemm_kind(int family, int KS, int tile) {
   const int k = KS == 1 ? 0 : (KS == 3 ? 1 : (KS == 4 ? 2 : 3));
-  return SG_K_IGEMM_BASE + family * 12 + k * 3 + tile;
+  return SG_K_IGEMM_BASE + family * 16 + k * 4 + tile;
 }
 extern int g_sg_prof_on;
 void sg_prof_begin(int kind, hipStream_t s);

@@ -414,7 +414,7 @@ __device__ __forceinline__ int axis_offset(int a, int k, int L, int reflect, int
   return (reflect || inside) ? i : -1;
 }
 
-template <int BN, int KS, bool TWO, bool MASK = true>
+template <int BN, int KS, bool TWO, bool MASK = true, int NS = SG_NSUB>
 struct LoadGatherNK {
   Gather g; int Ncols;
   const int* chan_list; const int* chan_cnt; int L;     // optional per-image active-channel lists
@@ -424,7 +424,7 @@ struct LoadGatherNK {
   // img1[16], img2[16]
   static constexpr int NEG = 2 * KS;
   static constexpr int BUF = (2 * KS + 1) * BK + 2 * BK;
-  static constexpr int LDS_INTS = 2 * SG_NSUB * BUF;
+  static constexpr int LDS_INTS = 2 * NS * BUF;
   static constexpr int COLS = BN / 16;
   struct Stage { float r[COLS]; unsigned ok; };
   int kl_, tid_, nr_, kbeg_, kend_;
@@ -457,7 +457,7 @@ struct LoadGatherNK {
       secmask_ |= second ? (1u << j) : 0u;
     }
   }
-  __device__ __forceinline__ int* buf_of(int k0) const { return lds_ + (((k0 - kbeg_) / BK) % (2 * SG_NSUB)) * BUF; }
+  __device__ __forceinline__ int* buf_of(int k0) const { return lds_ + (((k0 - kbeg_) / BK) % (2 * NS)) * BUF; }
   __device__ __forceinline__ void prefetch(Stage&, int k0) const {
     int* buf = buf_of(k0);
     const int phw = g.PH * g.PW;
@@ -516,13 +516,13 @@ struct LoadGatherNK {
 // is then a function of the pixel alone: 16 lanes compute it one k-tile ahead into LDS (prefetch()) and a gathered
 // element costs 1 add + 1 load (the general loader above spends 2 LDS reads, 2 adds and a validity test per
 // element).  EpWgrad un-permutes the columns on the way out.
-template <int BN, bool TWO, bool MASK = true>
+template <int BN, bool TWO, bool MASK = true, int NS = SG_NSUB>
 struct LoadTapNK {
   Gather g; int KS, Ccols, cpad;
   const int* chan_list; const int* chan_cnt; int L;     // optional per-image active-channel lists (image = blockIdx.z)
   FastDiv dPQ, dPW;
   static constexpr int BUF = 2 * BK;                    // off1[16], off2[16]
-  static constexpr int LDS_INTS = 2 * SG_NSUB * BUF;
+  static constexpr int LDS_INTS = 2 * NS * BUF;
   static constexpr int COLS = BN / 16;
   struct Stage { float r[COLS]; unsigned ok; };
   int kl_, tid_, nr_, kbeg_, kend_, kh_, kw_;
@@ -548,7 +548,7 @@ struct LoadTapNK {
       secmask_ |= second ? (1u << j) : 0u;
     }
   }
-  __device__ __forceinline__ int* buf_of(int k0) const { return lds_ + (((k0 - kbeg_) / BK) % (2 * SG_NSUB)) * BUF; }
+  __device__ __forceinline__ int* buf_of(int k0) const { return lds_ + (((k0 - kbeg_) / BK) % (2 * NS)) * BUF; }
   __device__ __forceinline__ void prefetch(Stage&, int k0) const {
     if (tid_ < BK) {
       int* buf = buf_of(k0);
@@ -853,10 +853,19 @@ template <int KS> struct CfgFor {
   using C128 = TileCfg<128, 128, 2, SG_NSUB>;
   using C64 = TileCfg<64, 64, 2, SG_NSUB>;
   using C32 = TileCfg<32, 128, 1, SG_NSUB>;
+  using C64W = TileCfg<64, 128, 2, SG_NSUB>;     // 64 rows x 128 pixels: twice the MFMAs per gathered element of 64x64
 };
-using Cfg128 = CfgFor<3>::C128;      // dense layers / wgrad use the KS-independent depths
+using Cfg128 = CfgFor<3>::C128;      // dense layers use the KS-independent depths
 using Cfg64 = CfgFor<3>::C64;
 using Cfg32 = CfgFor<3>::C32;
+// Two sub-tiles per k-tile (32 deep) where the operands are cheap to address -- the weight-gradient GEMMs (one offset per
+// pixel per tile) and the dense Winograd GEMMs: the loads of a tile are issued a whole 32-deep MFMA block ahead, which hides
+// the global-load latency two waves per SIMD cannot.  Measured on MI355X (tools/bench_conv.py): Winograd wgrad +17 %, dgrad
+// +7 %, fwd +4 %, mask_net 3x3 wgrad +31 %; the im2col gathers (one dword per lane per element) LOSE 5-15 % and stay at 1.
+constexpr int NSW = 2;
+using CfgW128 = TileCfg<128, 128, 2, NSW>;
+using CfgW64 = TileCfg<64, 64, 2, NSW>;
+using CfgW32 = TileCfg<32, 128, 1, NSW>;
 
 inline int pick_tile(int M, int N) {
   static int force = -2;
@@ -864,10 +873,14 @@ inline int pick_tile(int M, int N) {
   if (force >= 0) return force;
   if (M <= 32) return 2;
   // measured (tools/bench_conv.py): 128x128 tiles win when M is large (>= 512 rows, split-K fills the chip) or when
-  // there are enough of them anyway; 64x64 tiles otherwise
+  // there are enough of them anyway; 64-row tiles otherwise -- 128 pixels wide (tile 3) while that still leaves >= 3
+  // workgroups per CU, else 64x64
   const long t128 = (long)sg_cdiv(M, 128) * sg_cdiv(N, 128);
   const bool low_waste = sg_cdiv(M, 128) * 128 * 20 <= M * 23 && N >= 512;
   if (M >= 96 && low_waste && (M >= 512 || t128 >= 384)) return 0;
+  static int wide = -1;
+  if (wide < 0) { const char* e = getenv("SG_TILE3"); wide = e ? atoi(e) : 1; }
+  if (wide && (long)sg_cdiv(M, 64) * sg_cdiv(N, 128) >= 768) return 3;
   return 1;
 }
 
@@ -1005,7 +1018,8 @@ int launch_ab(const float* A, int K, int M, bool vec, const Gather& g, int Npix,
 // Cout=1 heads of the PatchGANs (91 tiles of 32x128, K=8192)
 inline int kn_tiles(int M, int Npix) {
   const int t = pick_tile(M, Npix);
-  return t == 0 ? sg_cdiv(M, 128) * sg_cdiv(Npix, 128) : (t == 1 ? sg_cdiv(M, 64) * sg_cdiv(Npix, 64) : sg_cdiv(Npix, 128));
+  return t == 0 ? sg_cdiv(M, 128) * sg_cdiv(Npix, 128)
+                : (t == 1 ? sg_cdiv(M, 64) * sg_cdiv(Npix, 64) : (t == 3 ? sg_cdiv(M, 64) * sg_cdiv(Npix, 128) : sg_cdiv(Npix, 128)));
 }
 inline int kn_splits(int M, int Npix, int K) {
   static int force = -2;
@@ -1035,7 +1049,7 @@ int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* b
   const bool vec = (K % 4 == 0) && aligned16(A);
   int tile = pick_tile(M, Npix);
   if (!vec && tile == 0) tile = 1;                  // the scalar-A variant is only instantiated for the small tiles
-  const int tBM = tile == 0 ? 128 : (tile == 1 ? 64 : 32), tBN = tile == 1 ? 64 : 128;
+  const int tBM = tile == 0 ? 128 : (tile == 2 ? 32 : 64), tBN = tile == 1 ? 64 : 128;
   // mask-free kernels: reflection padding (every tap valid), full pixel tiles, full M tiles; a K tail is legal because
   // the A operand... would need masking -- so also require K % 16 == 0
   const bool nomask = MODE == 0 && vec && g.reflect && (Npix % tBN == 0) && (M % tBM == 0) && (K % BK == 0);
@@ -1059,6 +1073,7 @@ int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* b
     switch (tile) {
       case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, MODE>(A, K, M, true, g, Npix, ktab, ep, splits, nomask, s); break;
       case 1: launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, nomask, s); break;
+      case 3: launch_ab<typename CfgFor<KS>::C64W, 64, 128, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, nomask, s); break;
       default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, nomask, s); break;
     }
   }
@@ -1127,7 +1142,7 @@ int run_kn_sparse(const float* W, int M, int K, const Gather& g, int NB, const f
   float* Wc = reinterpret_cast<float*>(ktab + (size_t)NB * Kpad);
   int* kcnt = reinterpret_cast<int*>(Wc + (size_t)NB * M * Kc);
   int tile = pick_tile(M, Npix);
-  const int tBM = tile == 0 ? 128 : (tile == 1 ? 64 : 32), tBN = tile == 1 ? 64 : 128;
+  const int tBM = tile == 0 ? 128 : (tile == 2 ? 32 : 64), tBN = tile == 1 ? 64 : 128;
   const bool nomask = g.reflect && (PHW % tBN == 0) && (M % tBM == 0);
   {
     const int work = M * Kc > Kpad ? M * Kc : Kpad;
@@ -1144,6 +1159,7 @@ int run_kn_sparse(const float* W, int M, int K, const Gather& g, int NB, const f
     switch (tile) {
       case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, 0>(Wc, Kc, M, true, g, Npix, ktab, ep, 1, nomask, s); break;
       case 1: launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, 0>(Wc, Kc, M, true, g, Npix, ktab, ep, 1, nomask, s); break;
+      case 3: launch_ab<typename CfgFor<KS>::C64W, 64, 128, KS, 0>(Wc, Kc, M, true, g, Npix, ktab, ep, 1, nomask, s); break;
       default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, 0>(Wc, Kc, M, true, g, Npix, ktab, ep, 1, nomask, s); break;
     }
   }
@@ -1254,6 +1270,7 @@ int run_kn_parity(const float* W, int Rdim, int B, int m0, int M, const Gather& 
     switch (tile) {
       case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, 1>(wbase, par.K[0], M, true, gs, par.Npix[0], kt0, ep, 1, false, s); break;
       case 1: launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, 1>(wbase, par.K[0], M, vec, gs, par.Npix[0], kt0, ep, 1, false, s); break;
+      case 3: launch_ab<typename CfgFor<KS>::C64W, 64, 128, KS, 1>(wbase, par.K[0], M, vec, gs, par.Npix[0], kt0, ep, 1, false, s); break;
       default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, 1>(wbase, par.K[0], M, vec, gs, par.Npix[0], kt0, ep, 1, false, s); break;
     }
   }
@@ -1376,11 +1393,11 @@ void launch_nk_general(int tile, const float* A, int M, int Mtot, int PQ, const 
   const FastDiv dPQ((unsigned)PQ);
   const int* sl = sp ? sp->list : nullptr; const int* sc = sp ? sp->cnt : nullptr; const int L = sp ? sp->L : 0;
   if (tile == 2)
-    launch_cfg<Cfg32>(LoadPixK<32>{A, M, Mtot, PQ, dPQ}, LoadGatherNK<128, KS, false>{g, Ncols, sl, sc, L, zdiv}, ep, M, Ncols,
-                      Kpix, splits, s);
+    launch_cfg<CfgW32>(LoadPixK<32>{A, M, Mtot, PQ, dPQ}, LoadGatherNK<128, KS, false, true, NSW>{g, Ncols, sl, sc, L, zdiv}, ep,
+                       M, Ncols, Kpix, splits, s);
   else
-    launch_cfg<Cfg64>(LoadPixK<64>{A, M, Mtot, PQ, dPQ}, LoadGatherNK<64, KS, false>{g, Ncols, sl, sc, L, zdiv}, ep, M, Ncols,
-                      Kpix, splits, s);
+    launch_cfg<CfgW64>(LoadPixK<64>{A, M, Mtot, PQ, dPQ}, LoadGatherNK<64, KS, false, true, NSW>{g, Ncols, sl, sc, L, zdiv}, ep,
+                       M, Ncols, Kpix, splits, s);
 }
 
 template <class CFG, int BMv, int BNv>
@@ -1390,7 +1407,7 @@ void launch_nk_tap(const float* A, int M, int Mtot, int PQ, bool vecA, const Gat
   const int* sl = sp ? sp->list : nullptr; const int* sc = sp ? sp->cnt : nullptr; const int L = sp ? sp->L : 0;
   const int Nv = KS * KS * cpad;
   const bool two = g.C2 > 0;
-#define SG_TAP_B(TWOv, MASKv) LoadTapNK<BNv, TWOv, MASKv>{g, KS, Ccols, cpad, sl, sc, L, dPQ, dPW}
+#define SG_TAP_B(TWOv, MASKv) LoadTapNK<BNv, TWOv, MASKv, CFG::NSUB>{g, KS, Ccols, cpad, sl, sc, L, dPQ, dPW}
   if (vecA) {
     const LoadPixKVec<BMv> al{A, M, Mtot, PQ, dPQ};
     if (two) launch_cfg<CFG>(al, SG_TAP_B(true, true), ep, M, Nv, Kpix, splits, s);
@@ -1466,11 +1483,11 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
       const EpWgrad ep{dst, M, pl.cpad, KS2, mn};
       const bool vecA = (PQ % 4 == 0) && aligned16(A);
       // mask-free gather: reflection padding and whole 16-pixel k-tiles (split chunks are multiples of 64)
-      const bool nomask = g.reflect && (Kpix % BK == 0) && (!sp || PQ % BK == 0);
+      const bool nomask = g.reflect && (Kpix % (BK * NSW) == 0) && (!sp || PQ % (BK * NSW) == 0);
       switch (pl.tile) {
-        case 0: launch_nk_tap<Cfg128, 128, 128>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
-        case 1: launch_nk_tap<Cfg64, 64, 64>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
-        default: launch_nk_tap<Cfg32, 32, 128>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
+        case 0: launch_nk_tap<CfgW128, 128, 128>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
+        case 1: launch_nk_tap<CfgW64, 64, 64>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
+        default: launch_nk_tap<CfgW32, 32, 128>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
       }
     } else {
       const EpRowMajor ep{dst, nullptr, M, Ncols, Ncols, SG_ACT_NONE, 0.f, mn};
@@ -1970,8 +1987,10 @@ __global__ void wino_wgrad_output_kernel(const float* __restrict__ T, float* __r
 }
 
 // Winograd applies to 3x3 / stride 1 / pad 1 convs (reflection or zero padding, optionally behind a folded nearest x2
-// upsample) whose channel counts and tile count fill whole GEMM tiles: 128 (the ResnetBlock / VGG convs) or 64 (mask_net's
-// 192 channels).  Below 128 channels the elementwise transforms (16 x the activation bytes) cost more than the GEMM saves.
+// upsample) with >= 128 channels on both sides whose channel counts and tile count fill whole 128-wide GEMM tiles (the
+// ResnetBlock and VGG19 convs).  Below 128 channels the elementwise transforms (16 x the activation bytes) cost more than the
+// GEMM saves; 64-wide tiles (mask_net's 192 channels) were measured SLOWER than the direct kernel there (60 TFLOP/s in the
+// 64x64 dense GEMM + the transforms vs 120 TFLOP/s direct) and are not used.
 int wino_tile(const sgConvDesc* d) {
   if (!d || d->pad != 1 || d->KS != 3 || d->stride != 1 || d->C2 != 0) return 0;
   if (d->upsample != 1 && (d->upsample != 2 || d->pad_reflect)) return 0;
@@ -1983,7 +2002,6 @@ int wino_tile(const sgConvDesc* d) {
   const double Pmax = (double)d->N * (LH / 2 + 1) * (LW / 2 + 1) + 128.0;
   if (!(16.0 * Pmax * (d->C1 > d->Cout ? d->C1 : d->Cout) < 2147483647.0 && 16.0 * d->C1 * d->Cout < 2147483647.0)) return 0;
   if (d->C1 % 128 == 0 && d->Cout % 128 == 0 && P % 128 == 0) return 128;
-  if (d->C1 % 64 == 0 && d->Cout % 64 == 0 && P % 64 == 0) return 64;
   return 0;
 }
 bool wino_ok(const sgConvDesc* d) { return wino_tile(d) != 0; }
@@ -1992,14 +2010,9 @@ bool wino_ok(const sgConvDesc* d) { return wino_tile(d) != 0; }
 void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, int K, double flops, hipStream_t s) {
   EpRowMajor ep{Cout, nullptr, M, 16 * cols, 16 * cols, SG_ACT_NONE, 0.f, 0};
   t_batch = BatchInfo{}; t_batch.cols_per_batch = cols; t_batch.nbatch = 16; t_batch.a_stride = M * K; t_batch.batch_major = 1;
-  const bool big = M % 128 == 0 && cols % 128 == 0;
   {
-    SgProfScope prof(big ? SG_K_WINO_GEMM_128 : SG_K_WINO_GEMM_64, s, flops, 0);
-    if (big)
-      launch_cfg<Cfg128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M, 16 * cols,
-                         K, 1, s);
-    else
-      launch_cfg<Cfg64>(LoadKContig<64, true, false>{A, K, M}, LoadKContig<64, true, false>{B, K, 16 * cols}, ep, M, 16 * cols,
+    SgProfScope prof(SG_K_WINO_GEMM_128, s, flops, 0);
+    launch_cfg<CfgW128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M, 16 * cols,
                         K, 1, s);
   }
   t_batch = BatchInfo{};

@@ -549,3 +549,116 @@ extern "C" int sg_vector_pool_exchange(float* pool, const float* vectors, const 
   SG_LAUNCH_CHECK("sg_vector_pool_exchange");
   return 0;
 }
+
+// ================================================================================================
+// Per-image filters of the factored layout convs (ops.factored_layout_conv).
+//   layout = sum_o vecs[o] (x) S_o with vecs[o] = [one_hot(class_o) | repr_o] (model.py:165-168, layout.py:85-86), so
+//   conv(layout, W)[n] = sum_{o in n} W_eff[o] (*) S_o,   W_eff[o] = W[:, class_o] + sum_d repr[o, d] W[:, C + d]
+// wimg[n][m][j][t]: j < cnt_n -> W_eff of the j-th object of image n; cnt_n <= j < cnt_n + C2 -> W[m][C + R + (j - cnt_n)][t]
+// (the channels of a concatenated second source, e.g. the image next to the layout in the image discriminator); else 0.
+// Replaces an embedding lookup + GEMM + index_put + cat chain of ATen launches; sums run in index order (deterministic).
+// ================================================================================================
+namespace {
+
+__global__ void factored_weights_fwd_kernel(const float* __restrict__ W, const float* __restrict__ repr,
+                                            const int64_t* __restrict__ objs, const int32_t* __restrict__ seg, float* __restrict__ wimg,
+                                            int N, int M, int L, int KS2, int C, int R, int C2) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * M * L * KS2) return;
+  const int t = (int)(i % KS2);
+  const int j = (int)((i / KS2) % L);
+  const int m = (int)((i / ((size_t)KS2 * L)) % M);
+  const int n = (int)(i / ((size_t)KS2 * L * M));
+  const int cnt = seg[n + 1] - seg[n];
+  const int Ct = C + R + C2;
+  const float* Wm = W + (size_t)m * Ct * KS2 + t;
+  float v = 0.f;
+  if (j < cnt) {
+    const int o = seg[n] + j;
+    v = Wm[(size_t)objs[o] * KS2];
+    const float* r = repr + (size_t)o * R;
+    for (int d = 0; d < R; ++d) v += r[d] * Wm[(size_t)(C + d) * KS2];
+  } else if (j < cnt + C2) {
+    v = Wm[(size_t)(C + R + (j - cnt)) * KS2];
+  }
+  wimg[i] = v;
+}
+
+// gW[m][c][t] for the three channel blocks: classes (sum over the objects of that class, ascending), appearance dims
+// (sum_o repr[o][d] g[o]), second-source channels (sum over images)
+__global__ void factored_weights_bwd_w_kernel(const float* __restrict__ gwimg, const float* __restrict__ repr,
+                                              const int64_t* __restrict__ objs, const int32_t* __restrict__ seg,
+                                              const int64_t* __restrict__ img_idx, float* __restrict__ gW, int N, int O, int M,
+                                              int L, int KS2, int C, int R, int C2) {
+  const int Ct = C + R + C2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * Ct * KS2) return;
+  const int t = (int)(i % KS2);
+  const int c = (int)((i / KS2) % Ct);
+  const int m = (int)(i / ((size_t)KS2 * Ct));
+  float s = 0.f;
+  if (c < C + R) {
+    for (int o = 0; o < O; ++o) {
+      float wgt;
+      if (c < C) { if ((int)objs[o] != c) continue; wgt = 1.f; }
+      else wgt = repr[(size_t)o * R + (c - C)];
+      const int n = (int)img_idx[o], j = o - seg[n];
+      s += wgt * gwimg[(((size_t)n * M + m) * L + j) * KS2 + t];
+    }
+  } else {
+    const int e = c - C - R;
+    for (int n = 0; n < N; ++n) s += gwimg[(((size_t)n * M + m) * L + (seg[n + 1] - seg[n]) + e) * KS2 + t];
+  }
+  gW[i] = s;
+}
+
+// grepr[o][d] = sum_{m,t} gwimg[n_o][m][j_o][t] * W[m][C + d][t]: one wave per (o, d)
+__global__ void __launch_bounds__(256) factored_weights_bwd_repr_kernel(const float* __restrict__ gwimg, const float* __restrict__ W,
+                                                                       const int32_t* __restrict__ seg,
+                                                                       const int64_t* __restrict__ img_idx,
+                                                                       float* __restrict__ grepr, int O, int M, int L, int KS2,
+                                                                       int C, int R, int C2) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= O * R) return;
+  const int o = w / R, d = w - o * R;
+  const int n = (int)img_idx[o], j = o - seg[n];
+  const int Ct = C + R + C2;
+  float s = 0.f;
+  for (int q = lane; q < M * KS2; q += 64) {
+    const int m = q / KS2, t = q - m * KS2;
+    s += gwimg[(((size_t)n * M + m) * L + j) * KS2 + t] * W[((size_t)m * Ct + C + d) * KS2 + t];
+  }
+  s = sg_wave_sum(s);
+  if (lane == 0) grepr[w] = s;
+}
+
+}  // namespace
+
+extern "C" int sg_factored_weights_fwd(const float* w, const float* repr, const int64_t* objs, const int32_t* seg_off,
+                                       float* wimg, int N, int O, int M, int L, int KS2, int C, int R, int C2, sgStream stream) {
+  SG_ARG_CHECK(w && repr && objs && seg_off && wimg && N > 0 && O >= 0 && M > 0 && L > 0 && KS2 > 0 && C >= 0 && R >= 0 && C2 >= 0,
+               "sg_factored_weights_fwd: bad arguments");
+  const size_t n = (size_t)N * M * L * KS2;
+  hipLaunchKernelGGL(factored_weights_fwd_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, repr, objs, seg_off,
+                     wimg, N, M, L, KS2, C, R, C2);
+  SG_LAUNCH_CHECK("sg_factored_weights_fwd");
+  return 0;
+}
+
+extern "C" int sg_factored_weights_bwd(const float* gwimg, const float* w, const float* repr, const int64_t* objs,
+                                       const int32_t* seg_off, const int64_t* img_idx, float* gw, float* grepr, int N, int O,
+                                       int M, int L, int KS2, int C, int R, int C2, sgStream stream) {
+  SG_ARG_CHECK(gwimg && w && repr && objs && seg_off && img_idx && (gw || grepr) && N > 0 && O > 0,
+               "sg_factored_weights_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (gw) {
+    const size_t n = (size_t)M * (C + R + C2) * KS2;
+    hipLaunchKernelGGL(factored_weights_bwd_w_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, s, gwimg, repr, objs, seg_off, img_idx, gw,
+                       N, O, M, L, KS2, C, R, C2);
+  }
+  if (grepr && R > 0)
+    hipLaunchKernelGGL(factored_weights_bwd_repr_kernel, dim3(sg_cdiv((size_t)O * R, 4)), dim3(256), 0, s, gwimg, w, seg_off, img_idx,
+                       grepr, O, M, L, KS2, C, R, C2);
+  SG_LAUNCH_CHECK("sg_factored_weights_bwd");
+  return 0;
+}

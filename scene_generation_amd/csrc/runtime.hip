@@ -35,11 +35,11 @@ void init_names() {
   if (g_names_init) return;
   const char* fam[3] = {"kn0", "kn1", "nk"};
   const int ks[4] = {1, 3, 4, 7};
-  const int tl[3] = {128, 64, 32};
+  const char* tl[4] = {"128", "64", "32", "64x128"};
   for (int f = 0; f < 3; ++f)
     for (int k = 0; k < 4; ++k)
-      for (int t = 0; t < 3; ++t)
-        snprintf(g_names[f * 12 + k * 3 + t], 32, "igemm_%s_k%d_t%d", fam[f], ks[k], tl[t]);
+      for (int t = 0; t < 4; ++t)
+        snprintf(g_names[f * 16 + k * 4 + t], 32, "igemm_%s_k%d_t%s", fam[f], ks[k], tl[t]);
   for (int i = SG_K_IGEMM_COUNT; i < SG_K_COUNT; ++i) snprintf(g_names[i], 32, "%s", kTail[i - SG_K_IGEMM_COUNT]);
   g_names_init = true;
 }

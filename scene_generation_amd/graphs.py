@@ -20,6 +20,7 @@ from torch.autograd import Function
 from . import ops
 
 ENABLED = os.environ.get('SG_GRAPHS', '1') != '0'
+REPLAYS = [0]                    # hipGraph launches issued by this process
 
 
 def _flat(out):
@@ -39,6 +40,7 @@ class _GraphedFn(Function):
     def forward(ctx, entry, x):
         entry.static_in.copy_(x)
         entry.fwd.replay()
+        REPLAYS[0] += 1
         ctx.entry = entry
         outs = [o.detach() for o in entry.static_out]
         if entry.clone_outputs:
@@ -54,6 +56,7 @@ class _GraphedFn(Function):
             else:
                 buf.copy_(g)
         e.bwd.replay()
+        REPLAYS[0] += 1
         for opt, i in e.deliveries:           # what ops.GradOut.finish() tells the optimiser on the eager path
             opt._on_grad(i)
         return None, (e.static_gin.detach() if e.static_gin is not None else None)
@@ -108,6 +111,7 @@ class GraphedSegment(object):
         else:
             e.static_in.copy_(x)
             e.fwd.replay()
+            REPLAYS[0] += 1
             outs = [o.detach() for o in e.static_out]
             if e.clone_outputs:
                 outs = [o.clone() for o in outs]

@@ -138,9 +138,9 @@ class Model(nn.Module):
                 counts[i] += 1
             pidx = to_device_async(torch.tensor(plane, dtype=torch.int64), dev)
             Z = ops.layout_planes(boxes_gt, masks_gt, seg, pidx, N, max(counts), H, W)
-            f_gt = ops.FactoredLayout(Z, objs, scene_layout_vecs[:, self.num_objs:], self.num_objs, obj_to_img, pidx, counts)
+            f_gt = ops.FactoredLayout(Z, objs, scene_layout_vecs[:, self.num_objs:], self.num_objs, obj_to_img, pidx, counts, seg)
             f_wrong = ops.FactoredLayout(Z, objs, wrong_layout_vecs[:, self.num_objs:].detach(), self.num_objs, obj_to_img,
-                                         pidx, counts)
+                                         pidx, counts, seg)
             f_wrong._lists = f_gt._lists          # same objects: share the list cache
             ops.set_hints(gt_layout, factored=f_gt)
             ops.set_hints(wrong_layout, factored=f_wrong)

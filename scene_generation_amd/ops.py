@@ -76,9 +76,11 @@ def workspace(nbytes, device):
 
 
 _fn_cache = {}
+CALLS = [0]                       # C-ABI calls issued by this process (bench.py reports calls per step)
 
 
 def _call(name, *args):
+    CALLS[0] += 1
     fn = _fn_cache.get(name)
     if fn is None:
         fn = _fn_cache[name] = getattr(_L(), name)
@@ -1092,22 +1094,29 @@ class FactoredLayout(object):
     (image, plane).  A conv over the layout is then a conv over <= J planes with per-image weights
     W_eff[o] = W[:, class_o] + sum_d repr[o, d] W[:, num_objs + d] -- 204 -> <= 9 "channels"."""
 
-    def __init__(self, Z, objs, repr_vecs, num_objs, img_idx, plane_idx, counts_host):
+    def __init__(self, Z, objs, repr_vecs, num_objs, img_idx, plane_idx, counts_host, seg=None):
         self.Z, self.objs, self.repr, self.num_objs = Z, objs, repr_vecs, int(num_objs)
         self.img_idx, self.plane_idx = img_idx, plane_idx          # int64 [O] on the device
         self.counts_host = list(counts_host)                       # objects per image (host ints)
+        if seg is None:                                            # int32 [N + 1] object offsets per image
+            off = [0]
+            for c in self.counts_host:
+                off.append(off[-1] + c)
+            from .utils import to_device_async
+            seg = to_device_async(torch.tensor(off, dtype=torch.int32), Z.device)
+        self.seg = seg
         self._lists = {}
 
     def detached(self):
         if not self.repr.requires_grad:
             return self
         f = FactoredLayout(self.Z, self.objs, self.repr.detach(), self.num_objs, self.img_idx, self.plane_idx,
-                           self.counts_host)
+                           self.counts_host, self.seg)
         f._lists = self._lists
         return f
 
     def with_planes(self, Z):
-        f = FactoredLayout(Z, self.objs, self.repr, self.num_objs, self.img_idx, self.plane_idx, self.counts_host)
+        f = FactoredLayout(Z, self.objs, self.repr, self.num_objs, self.img_idx, self.plane_idx, self.counts_host, self.seg)
         f._lists = self._lists
         return f
 
@@ -1199,6 +1208,42 @@ class PerImageConvFn(Function):
         return None, gx2, gwimg, gb, None, None, None, None, None, None, None, None, None
 
 
+class FactoredWeightsFn(Function):
+    """per-image filters of a factored layout conv and their gradients w.r.t. the conv weight and the appearance
+    vectors (sg_factored_weights_fwd / _bwd)"""
+
+    @staticmethod
+    def forward(ctx, weight, repr_vecs, objs, seg, img_idx, N, L, C, C2):
+        weight, repr_vecs = _f32(weight, 'conv weight'), _f32(repr_vecs, 'appearance vectors')
+        M, Ct, KS, _ = weight.shape
+        O, R = repr_vecs.shape
+        assert Ct == C + R + C2 and seg.dtype == torch.int32 and seg.numel() == N + 1
+        wimg = torch.empty(N, M, L, KS, KS, dtype=torch.float32, device=weight.device)
+        _call('sg_factored_weights_fwd', _p(weight), _p(repr_vecs), _p(_i64(objs)), _p(seg), _p(wimg), N, O, M, L, KS * KS, C, R,
+              C2, _stream())
+        ctx.cfg = (N, O, M, L, KS * KS, C, R, C2)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(weight, repr_vecs, objs, seg, img_idx)
+        return wimg
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return (None,) * 9
+        weight, repr_vecs, objs, seg, img_idx = ctx.saved_tensors
+        N, O, M, L, KS2, C, R, C2 = ctx.cfg
+        need_w = ctx.needs_input_grad[0] and _wants_grad(weight)
+        need_r = ctx.needs_input_grad[1]
+        if not (need_w or need_r):
+            return (None,) * 9
+        g = _f32(g)
+        ow = GradOut(weight) if need_w else None
+        grepr = torch.empty_like(repr_vecs) if need_r else None
+        _call('sg_factored_weights_bwd', _p(g), _p(weight), _p(repr_vecs), _p(objs), _p(seg), _p(_i64(img_idx)),
+              _p(ow.buf) if need_w else None, _p(grepr), N, O, M, L, KS2, C, R, C2, _stream())
+        return (ow.finish() if need_w else None, grepr) + (None,) * 7
+
+
 def factored_layout_conv(f, weight, bias, stride, pad, reflect, act, slope, x2):
     """conv2d([layout | x2], weight) computed from the factored layout ``f`` (see FactoredLayout)."""
     M, Ctot, KS, _ = weight.shape
@@ -1209,22 +1254,13 @@ def factored_layout_conv(f, weight, bias, stride, pad, reflect, act, slope, x2):
     assert Ctot == cfull + C2, 'weight has %d input channels, layout %d + second source %d' % (Ctot, cfull, C2)
     N = f.Z.size(0)
     clist, ccnt, extra_pos, L = f.lists(C2)
+    # per-image filters (sg_factored_weights_fwd):  W_eff[o] = W[:, class_o] + sum_d repr[o, d] W[:, num_objs + d] for the
+    # objects of the image, then the filters of the second source's channels.  (A discriminator inside the generator step
+    # runs under skip_param_grads: PerImageConvFn then returns no gradient for the filters and the parameter's
+    # AccumulateGrad never fires; the SAME recorded forward still yields the weight gradient when the discriminator
+    # step differentiates it.)
     w_full = weight
-    # (a discriminator inside the generator step runs under skip_param_grads: PerImageConvFn then returns no gradient for
-    #  the per-image filters, the None propagates through the assembly below and the parameter's AccumulateGrad never
-    #  fires; the SAME recorded forward still yields the weight gradient when the discriminator step differentiates it)
-    # per-object filters  W_eff[o] = W[:, class_o] + sum_d repr[o, d] W[:, num_objs + d]      -> [O, M * KS2]
-    table = weight[:, :f.num_objs].permute(1, 0, 2, 3).reshape(f.num_objs, M * KS2).contiguous()
-    w_rep = weight[:, f.num_objs:cfull].permute(0, 2, 3, 1).reshape(M * KS2, R)
-    w_eff = embedding(table, f.objs) + linear(f.repr.contiguous(), w_rep.contiguous())
-    rows, cols, vals = f.img_idx, f.plane_idx, w_eff.view(-1, M, KS2)
-    if C2:
-        w_x2 = weight[:, cfull:].permute(1, 0, 2, 3).reshape(1, C2, M, KS2).expand(N, C2, M, KS2)
-        rows = torch.cat([rows, torch.arange(N, device=rows.device).repeat_interleave(C2)])
-        cols = torch.cat([cols, extra_pos[:, :C2].reshape(-1)])
-        vals = torch.cat([vals, w_x2.reshape(N * C2, M, KS2)])
-    wimg = torch.zeros(N, L, M, KS2, dtype=torch.float32, device=weight.device).index_put((rows, cols), vals)
-    wimg = wimg.permute(0, 2, 1, 3).reshape(N, M, L, KS, KS).contiguous()
+    wimg = FactoredWeightsFn.apply(weight, f.repr, f.objs, f.seg, f.img_idx, N, L, f.num_objs, C2)
     planes = f.Z if x2 is None else torch.cat([f.Z, x2.detach()], 1)
     return PerImageConvFn.apply(planes, x2, wimg, bias, clist, ccnt, w_full.detach(), cfull, stride, pad, reflect, act,
                                 float(slope))
