@@ -213,6 +213,12 @@ int sg_concat_channels(const float* a, const float* b, float* out, int N, int Ca
 /* ---------------------------------------------------------------------------------------------
  * Layout scatter and bilinear crops (layout.py:64-155, bilinear.py:67-130)
  * ------------------------------------------------------------------------------------------- */
+/* grid_sample geometry of the bilinear operators below (masks_to_layout, crop_bbox): 0 (default) = align_corners=False,
+ * what torch >= 1.3 executes for the reference's calls (layout.py:51,86,88; bilinear.py:130); 1 = align_corners=True, the
+ * default of the PyTorch 1.0 the reference was written for (requirements.txt:8) -- needed to run its released checkpoints
+ * with the geometry they were trained with.  Process-wide switch (the second piece of global state next to the profiler). */
+int sg_set_legacy_align_corners(int on);
+int sg_get_legacy_align_corners(void);
 /* seg_off[N+1] from a sorted, gap-free obj_to_img */
 int sg_segment_offsets(const int64_t* obj_to_img, int O, int N, int32_t* seg_off, sgStream stream);
 /* out[n,d,h,w] = sum_{o in image n, ascending} vecs[o,d] * bilinear(mask_o, box_o)(h,w)   (align_corners=False,

@@ -42,12 +42,23 @@ def _bilinear_taps(px, size):
     return i0.clamp(0, size - 1), i1.clamp(0, size - 1), w0 * in0, w1 * in1
 
 
+# The authors ran PyTorch 1.0 (requirements.txt:8), where F.grid_sample without an ``align_corners`` argument meant
+# align_corners=True; their released checkpoints were trained with that geometry.  LEGACY_ALIGN_CORNERS switches the whole
+# oracle to it (the HIP path has the same switch: scene_generation_amd.set_legacy_align_corners).
+LEGACY_ALIGN_CORNERS = False
+
+
 def bilinear_sample(src, gx, gy):
     """src (B,C,Hs,Ws); gx (B,Wo) / gy (B,Ho) separable normalised grids in [-1,1] space.
-    Returns (B,C,Ho,Wo).  Un-normalisation: p = ((g+1)/2)*size - 0.5  (align_corners=False)."""
+    Returns (B,C,Ho,Wo).  Un-normalisation: p = ((g+1)/2)*size - 0.5  (align_corners=False) or, in legacy mode,
+    p = ((g+1)/2)*(size-1)  (align_corners=True)."""
     B, C, Hs, Ws = src.shape
-    px = ((gx + 1) * Ws - 1) / 2
-    py = ((gy + 1) * Hs - 1) / 2
+    if LEGACY_ALIGN_CORNERS:
+        px = (gx + 1) / 2 * (Ws - 1)
+        py = (gy + 1) / 2 * (Hs - 1)
+    else:
+        px = ((gx + 1) * Ws - 1) / 2
+        py = ((gy + 1) * Hs - 1) / 2
     x0, x1, wx0, wx1 = _bilinear_taps(px, Ws)
     y0, y1, wy0, wy1 = _bilinear_taps(py, Hs)
     bidx = torch.arange(B)[:, None, None]

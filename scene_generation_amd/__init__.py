@@ -45,3 +45,12 @@ def install_as(name='scene_generation', host_package_dir=None):
     for sub in _SUBMODULES:
         sys.modules['%s.%s' % (name, sub)] = importlib.import_module('%s.%s' % (__name__, sub))
     return pkg
+
+
+def set_legacy_align_corners(on=True):
+    """Switch every bilinear operator (masks_to_layout, boxes_to_layout, crop_bbox_batch, test-mode compositing) to the
+    ``align_corners=True`` geometry of the PyTorch 1.0 the reference was written for (requirements.txt:8; SURVEY section 0
+    item 4) -- use it when loading the authors' released checkpoints.  Default off: the reference as executed by
+    torch >= 1.3.  Also settable with SG_LEGACY_ALIGN_CORNERS=1."""
+    from . import _hip
+    _hip.lib().sg_set_legacy_align_corners(1 if on else 0)

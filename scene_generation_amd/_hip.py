@@ -93,6 +93,8 @@ def lib():
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = L
+    if os.environ.get('SG_LEGACY_ALIGN_CORNERS', '0') == '1':
+        L.sg_set_legacy_align_corners(1)
     return L
 
 

@@ -47,6 +47,68 @@ __global__ void csr_fill_kernel(const int64_t* __restrict__ edges, int T, int O,
     if (edges[2 * t + 1] == i) ent[w++] = t | (1 << PASS_SHIFT);
 }
 
+// The whole CSR in ONE launch and O(T) work: a stable counting sort of the 2T (pass, t) entries by destination node, done by
+// one workgroup with the per-node counters / cursors in LDS (O <= CSR_LDS_NODES; larger graphs use the three kernels above,
+// whose node threads each scan all T triples).  Entries are placed 256 at a time in (pass, t) order; inside a chunk the
+// rank of an entry among the chunk's earlier entries with the same destination comes from an LDS scan, so the order inside
+// every node's list is exactly (pass, t) ascending -- the order the reference's CPU scatter_add applies the updates.
+constexpr int CSR_LDS_NODES = 8192;
+__global__ void __launch_bounds__(256) csr_build_kernel(const int64_t* __restrict__ edges, int T, int O, int32_t* __restrict__ off,
+                                                       int32_t* __restrict__ ent) {
+  __shared__ int cur[CSR_LDS_NODES];
+  __shared__ int dch[256];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < O; i += 256) cur[i] = 0;
+  __syncthreads();
+  for (int e = tid; e < 2 * T; e += 256) {
+    const int pass = e >= T, t = e - pass * T;
+    atomicAdd(&cur[(int)edges[2 * t + pass]], 1);            // integer LDS atomics: the counts do not depend on the order
+  }
+  __syncthreads();
+  // exclusive scan of the counts: cur[i] becomes the cursor (= start) of node i, off[] the CSR offsets
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < O; base += 256) {
+    const int i = base + tid;
+    const int c = i < O ? cur[i] : 0;
+    dch[tid] = c;
+    __syncthreads();
+    int incl = c;
+    for (int d = 1; d < 256; d <<= 1) {                     // Hillis-Steele over the chunk
+      const int u = tid >= d ? dch[tid - d] : 0;
+      __syncthreads();
+      incl += u;
+      dch[tid] = incl;
+      __syncthreads();
+    }
+    const int carry = carry_s;
+    if (i < O) { cur[i] = carry + incl - c; off[i] = carry + incl - c; }
+    __syncthreads();
+    if (tid == 255) carry_s = carry + incl;
+    __syncthreads();
+  }
+  if (tid == 0) off[O] = carry_s;
+  // stable placement
+  for (int base = 0; base < 2 * T; base += 256) {
+    const int e = base + tid;
+    const bool live = e < 2 * T;
+    const int pass = live && e >= T, t = live ? e - pass * T : 0;
+    const int d = live ? (int)edges[2 * t + pass] : -1;
+    dch[tid] = d;
+    __syncthreads();
+    int before = 0, after = 0;
+    if (live) {
+      for (int j = 0; j < tid; ++j) before += dch[j] == d;
+      for (int j = tid + 1; j < 256; ++j) after += dch[j] == d;
+      ent[cur[d] + before] = t | (pass << PASS_SHIFT);
+    }
+    __syncthreads();
+    if (live && after == 0) cur[d] += before + 1;            // the chunk's last entry of this node advances its cursor
+    __syncthreads();
+  }
+}
+
 __global__ void gather_concat_kernel(const float* __restrict__ obj, const float* __restrict__ pred,
                                      const int64_t* __restrict__ edges, float* __restrict__ out, int T, int Do, int Dp) {
   const int t = blockIdx.x;
@@ -166,6 +228,11 @@ extern "C" int sg_build_csr(const int64_t* edges, int T, int O, int32_t* csr_off
   SG_ARG_CHECK(edges && csr_off && csr_ent && T >= 0 && O > 0, "sg_build_csr: bad arguments");
   SG_ARG_CHECK(T < (1 << PASS_SHIFT), "sg_build_csr: too many triples");
   hipStream_t s = (hipStream_t)stream;
+  if (O <= CSR_LDS_NODES) {
+    hipLaunchKernelGGL(csr_build_kernel, dim3(1), dim3(256), 0, s, edges, T, O, csr_off, csr_ent);
+    SG_LAUNCH_CHECK("sg_build_csr");
+    return 0;
+  }
   hipLaunchKernelGGL(csr_count_kernel, dim3(sg_cdiv(O, 64)), dim3(64), 0, s, edges, T, O, csr_off);
   hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(64), 0, s, csr_off, O);
   hipLaunchKernelGGL(csr_fill_kernel, dim3(sg_cdiv(O, 64)), dim3(64), 0, s, edges, T, O, csr_off, csr_ent);

@@ -695,6 +695,8 @@ struct BatchInfo {
   // batch_major: tiles are numbered batch-major (all tiles of batch 0, then batch 1, ...), so that with the XCD remap
   // below every XCD works on whole batches and their operands stay in ITS L2 (batched Winograd GEMMs)
   int batch_major;
+  // xcd_splitk: plain split-K launch (grid.z = splits, a multiple of 8, (tiles * splits) % 8 == 0): see the kernel
+  int xcd_splitk;
   ParityClasses par;
 };
 // per-class hooks: loaders / epilogues that can run a parity class overload these; everything else ignores the call
@@ -746,7 +748,19 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     set_class_b(bl, bi.par, c);
     set_class_ep(ep, bi.par, c);
   }
-  int kbeg = blockIdx.z * kchunk;
+  int zblk = blockIdx.z;
+  if (bi.xcd_splitk) {
+    // split-K slabs pinned to XCDs: workgroups are handed to the 8 XCDs round-robin in linear (z, x) order; re-number them
+    // so that XCD i runs k-chunks i, i+8, ... of EVERY tile.  Each XCD then streams only its 1/8 of both operands through
+    // its own L2 (a tile-major order makes all 8 L2s fetch most of both operands: measured 5x the algorithmic bytes on
+    // the mask_net weight gradient, which made that kernel HBM-bound at 3.2 TB/s).
+    const unsigned lin = blockIdx.z * gridDim.x + blockIdx.x, xcd = lin & 7u, idx = lin >> 3;
+    zblk = (int)(xcd + 8u * (idx / gridDim.x));
+    const int t = (int)(idx % gridDim.x);
+    m0 = (t / tiles_n) * BM;
+    n0 = (t % tiles_n) * BN;
+  }
+  int kbeg = zblk * kchunk;
   int kend = min(K, kbeg + kchunk);
   if (bi.ksplit > 0) {
     const int img = blockIdx.z / bi.ksplit, q = blockIdx.z - img * bi.ksplit;
@@ -843,7 +857,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     __syncthreads();
     buf ^= 1;
   }
-  ep.store(acc, m0 + wm0, n0 + wn0, lane, blockIdx.z);
+  ep.store(acc, m0 + wm0, n0 + wn0, lane, bi.xcd_splitk ? zblk : (int)blockIdx.z);
 }
 
 // tile configurations.  Measured on MI355X (tools/bench_conv.py): these kernels are limited by the vector-memory
@@ -858,14 +872,16 @@ template <int KS> struct CfgFor {
 using Cfg128 = CfgFor<3>::C128;      // dense layers use the KS-independent depths
 using Cfg64 = CfgFor<3>::C64;
 using Cfg32 = CfgFor<3>::C32;
-// Two sub-tiles per k-tile (32 deep) where the operands are cheap to address -- the weight-gradient GEMMs (one offset per
-// pixel per tile) and the dense Winograd GEMMs: the loads of a tile are issued a whole 32-deep MFMA block ahead, which hides
-// the global-load latency two waves per SIMD cannot.  Measured on MI355X (tools/bench_conv.py): Winograd wgrad +17 %, dgrad
-// +7 %, fwd +4 %, mask_net 3x3 wgrad +31 %; the im2col gathers (one dword per lane per element) LOSE 5-15 % and stay at 1.
-constexpr int NSW = 2;
+// Two sub-tiles per k-tile (32 deep) for the dense Winograd GEMMs: the loads of a tile are issued a whole 32-deep MFMA block
+// ahead, which hides the global-load latency two waves per SIMD cannot.  Measured on MI355X: 92.5 -> 101.5 TFLOP/s over the
+// 54 launches of a step (wgrad +17 %, dgrad +7 %, fwd +4 %).  The weight-gradient GEMMs gain on some shapes (mask_net +31 %)
+// and lose on others (-3..-10 % on the 128-tile ones); over the step it is a wash, so they stay at depth NSW = 1 like the
+// im2col gathers (which LOSE 5-15 % at depth 2: one dword per lane per element, 80 KB of LDS = 2 workgroups per CU).
+constexpr int NSW = 1;
 using CfgW128 = TileCfg<128, 128, 2, NSW>;
 using CfgW64 = TileCfg<64, 64, 2, NSW>;
 using CfgW32 = TileCfg<32, 128, 1, NSW>;
+using CfgD128 = TileCfg<128, 128, 2, 2>;     // dense Winograd GEMMs
 
 inline int pick_tile(int M, int N) {
   static int force = -2;
@@ -902,7 +918,12 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
   if (splits > 1) kchunk = sg_cdiv(sg_cdiv(K, splits), CFG::BKT) * CFG::BKT;
   if (t_fixed_kchunk > 0) kchunk = t_fixed_kchunk;
   dim3 grid(tiles, 1, t_grid_z > 0 ? t_grid_z : ((splits > 1 || t_fixed_kchunk > 0) ? sg_cdiv(K, kchunk) : 1));
-  hipLaunchKernelGGL((igemm_kernel<CFG, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, N, K, kchunk, t_batch);
+  BatchInfo bi = t_batch;
+  static int xs = -1;
+  if (xs < 0) { const char* e = getenv("SG_XCD_SPLITK"); xs = e ? atoi(e) : 1; }
+  bi.xcd_splitk = (xs && t_grid_z == 0 && t_fixed_kchunk == 0 && bi.cols_per_batch == 0 && bi.par.ncls == 0 && bi.ksplit == 0 &&
+                   grid.z >= 8 && grid.z % 8 == 0) ? 1 : 0;
+  hipLaunchKernelGGL((igemm_kernel<CFG, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, N, K, kchunk, bi);
   return 0;
 }
 
@@ -1382,6 +1403,11 @@ inline NkPlan nk_plan(int M, int C, int KS2, int Kpix, bool two) {
   const int maxs = Kpix / (BK * 8) > 0 ? Kpix / (BK * 8) : 1;
   if (s > maxs) s = maxs;
   if (s > 64) s = 64;
+  if (s >= 6) {                                   // multiples of 8: the k-chunks are pinned to the 8 XCDs (xcd_splitk)
+    int s8 = (s + 7) / 8 * 8;
+    if (s8 > maxs) s8 = maxs / 8 * 8;
+    if (s8 >= 8) s = s8;
+  }
   p.splits = s < 1 ? 1 : s;
   return p;
 }
@@ -2012,7 +2038,7 @@ void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, in
   t_batch = BatchInfo{}; t_batch.cols_per_batch = cols; t_batch.nbatch = 16; t_batch.a_stride = M * K; t_batch.batch_major = 1;
   {
     SgProfScope prof(SG_K_WINO_GEMM_128, s, flops, 0);
-    launch_cfg<CfgW128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M, 16 * cols,
+    launch_cfg<CfgD128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M, 16 * cols,
                         K, 1, s);
   }
   t_batch = BatchInfo{};

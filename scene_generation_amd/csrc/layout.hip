@@ -28,10 +28,14 @@ __device__ __forceinline__ float lin10(int j, int n) {
 
 struct Tap { int i0, i1; float w0, w1; };
 
-// align_corners=False un-normalisation + bilinear taps with zeros padding
-__device__ __forceinline__ Tap make_tap(float g, int size) {
+// un-normalisation (align_corners=False: what torch >= 1.3 executes for the reference's grid_sample calls; ac != 0: the
+// align_corners=True geometry of the PyTorch 1.0 the reference was written for) + bilinear taps with zeros padding
+__device__ __forceinline__ float tap_coord(float g, int size, int ac) {
+  return ac ? (g + 1.f) * 0.5f * (float)(size - 1) : ((g + 1.f) * (float)size - 1.f) * 0.5f;
+}
+__device__ __forceinline__ Tap make_tap(float g, int size, int ac = 0) {
   Tap t;
-  const float p = ((g + 1.f) * (float)size - 1.f) * 0.5f;
+  const float p = tap_coord(g, size, ac);
   if (!(fabsf(p) < 1e8f)) {              // NaN / inf (degenerate box): propagate NaN like grid_sample
     t.i0 = t.i1 = 0;
     t.w0 = t.w1 = (p != p) ? p : 0.f;    // inf coordinate => fully outside => 0
@@ -84,7 +88,7 @@ template <bool I64, int VEC>
 __global__ void __launch_bounds__(256) layout_fwd_kernel(const float* __restrict__ vecs, const float* __restrict__ boxes,
                                                         const void* __restrict__ masks, const int32_t* __restrict__ seg,
                                                         float* __restrict__ out, int D, int M, int H, int W, int avg,
-                                                        int cap) {
+                                                        int cap, int ac) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int PXT = 256 * VEC;
   const int n = blockIdx.y;
@@ -115,12 +119,12 @@ __global__ void __launch_bounds__(256) layout_fwd_kernel(const float* __restrict
     for (int j = 0; j < nc; ++j) {
       const size_t o = (size_t)(o_beg + c0 + j);
       const float x0 = boxes[o * 4 + 0], y0 = boxes[o * 4 + 1], x1 = boxes[o * 4 + 2], y1 = boxes[o * 4 + 3];
-      const Tap ty = make_tap(box_coord(Y, y0, y1), M);
+      const Tap ty = make_tap(box_coord(Y, y0, y1), M, ac);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         float sv = 0.f;
         if (live && w0 + v < W) {
-          const Tap tx = make_tap(box_coord(lin01(w0 + v, W), x0, x1), M);
+          const Tap tx = make_tap(box_coord(lin01(w0 + v, W), x0, x1), M, ac);
           sv = sample_mask<I64>(masks, o, M, ty, tx);
         }
         S[(size_t)j * PXT + tid * VEC + v] = sv;
@@ -163,7 +167,7 @@ template <bool I64>
 __global__ void __launch_bounds__(256) layout_bwd_vecs_kernel(const float* __restrict__ gout, const float* __restrict__ boxes,
                                                              const void* __restrict__ masks, const int32_t* __restrict__ seg,
                                                              float* __restrict__ gv, int D, int M, int H, int W, int avg,
-                                                             int d_begin) {
+                                                             int d_begin, int ac) {
   __shared__ float red[16];
   constexpr int OC = 8;
   const int n = blockIdx.y, d = d_begin + blockIdx.x;
@@ -183,8 +187,8 @@ __global__ void __launch_bounds__(256) layout_bwd_vecs_kernel(const float* __res
       for (int j = 0; j < OC; ++j) {
         if (c0 + j < cnt) {
           const size_t o = (size_t)(o_beg + c0 + j);
-          const Tap ty = make_tap(box_coord(Y, boxes[o * 4 + 1], boxes[o * 4 + 3]), M);
-          const Tap tx = make_tap(box_coord(X, boxes[o * 4 + 0], boxes[o * 4 + 2]), M);
+          const Tap ty = make_tap(box_coord(Y, boxes[o * 4 + 1], boxes[o * 4 + 3]), M, ac);
+          const Tap tx = make_tap(box_coord(X, boxes[o * 4 + 0], boxes[o * 4 + 2]), M, ac);
           acc[j] += g * sample_mask<I64>(masks, o, M, ty, tx);
         }
       }
@@ -208,25 +212,25 @@ __global__ void zero_cols_kernel(float* __restrict__ p, int rows, int ld, int wi
 
 // ---------------- crops ---------------------------------------------------------------------------
 __device__ __forceinline__ void crop_taps(const float* __restrict__ boxes, int b, int y, int x, int HH, int WW, int H, int W,
-                                          Tap& ty, Tap& tx) {
+                                          Tap& ty, Tap& tx, int ac) {
   const float x0 = 2.f * boxes[b * 4 + 0] - 1.f, y0 = 2.f * boxes[b * 4 + 1] - 1.f;
   const float x1 = 2.f * boxes[b * 4 + 2] - 1.f, y1 = 2.f * boxes[b * 4 + 3] - 1.f;
   const float gx = lin10(x, WW) * x0 + lin01(x, WW) * x1;     // bilinear.py:266-274
   const float gy = lin10(y, HH) * y0 + lin01(y, HH) * y1;
-  tx = make_tap(gx, W);
-  ty = make_tap(gy, H);
+  tx = make_tap(gx, W, ac);
+  ty = make_tap(gy, H, ac);
 }
 
 __global__ void crop_fwd_kernel(const float* __restrict__ feats, const float* __restrict__ boxes,
                                 const int64_t* __restrict__ b2f, float* __restrict__ out, int C, int H, int W, int B, int HH,
-                                int WW) {
+                                int WW, int ac) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)B * HH * WW) return;
   const int x = i % WW;
   const int y = (i / WW) % HH;
   const int b = i / ((size_t)WW * HH);
   Tap ty, tx;
-  crop_taps(boxes, b, y, x, HH, WW, H, W, ty, tx);
+  crop_taps(boxes, b, y, x, HH, WW, H, W, ty, tx, ac);
   const float* fp = feats + (size_t)b2f[b] * C * H * W;
   float* op = out + (size_t)b * C * HH * WW + (size_t)y * WW + x;
   for (int c = 0; c < C; ++c) {
@@ -245,10 +249,10 @@ __global__ void crop_fwd_kernel(const float* __restrict__ feats, const float* __
 // covers it: the sample coordinate is affine in the crop index, so the candidates per axis are an index range (taken with one
 // spare element on each side and confirmed with the exact forward taps).  Additions happen in (box, crop row, crop column)
 // order.
-__device__ __forceinline__ void crop_axis_range(float c0, float c1, int n_crop, int size, int u, int& lo, int& hi) {
+__device__ __forceinline__ void crop_axis_range(float c0, float c1, int n_crop, int size, int u, int& lo, int& hi, int ac) {
   // pixel coordinate of crop index j: p(j) ~ p0 + s*j with p0 = p(0), s = (p(n-1) - p(0)) / (n-1)
-  const float p0 = ((c0 + 1.f) * (float)size - 1.f) * 0.5f;
-  const float p1 = ((c1 + 1.f) * (float)size - 1.f) * 0.5f;
+  const float p0 = tap_coord(c0, size, ac);
+  const float p1 = tap_coord(c1, size, ac);
   lo = 0; hi = n_crop - 1;
   if (n_crop == 1 || !(fabsf(p0) < 1e8f) || !(fabsf(p1) < 1e8f)) return;      // degenerate: test every index
   const float s = (p1 - p0) / (float)(n_crop - 1);
@@ -264,7 +268,7 @@ __device__ __forceinline__ void crop_axis_range(float c0, float c1, int n_crop, 
 template <int CT>
 __global__ void __launch_bounds__(256) crop_bwd_gather_kernel(const float* __restrict__ gout, const float* __restrict__ boxes,
                                                              const int64_t* __restrict__ b2f, float* __restrict__ gf, int C,
-                                                             int H, int W, int B, int HH, int WW) {
+                                                             int H, int W, int B, int HH, int WW, int ac) {
   __shared__ int list[256];
   __shared__ int wcnt[4];
   const int n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -292,16 +296,16 @@ __global__ void __launch_bounds__(256) crop_bwd_gather_kernel(const float* __res
           const float x0 = 2.f * boxes[bb * 4 + 0] - 1.f, y0 = 2.f * boxes[bb * 4 + 1] - 1.f;
           const float x1 = 2.f * boxes[bb * 4 + 2] - 1.f, y1 = 2.f * boxes[bb * 4 + 3] - 1.f;
           int jlo, jhi, ilo, ihi;
-          crop_axis_range(x0, x1, WW, W, u, jlo, jhi);
+          crop_axis_range(x0, x1, WW, W, u, jlo, jhi, ac);
           if (jlo > jhi) continue;
-          crop_axis_range(y0, y1, HH, H, v, ilo, ihi);
+          crop_axis_range(y0, y1, HH, H, v, ilo, ihi, ac);
           const float* gp = gout + ((size_t)bb * C + c0) * HH * WW;
           for (int i = ilo; i <= ihi; ++i) {
-            const Tap ty = make_tap(lin10(i, HH) * y0 + lin01(i, HH) * y1, H);
+            const Tap ty = make_tap(lin10(i, HH) * y0 + lin01(i, HH) * y1, H, ac);
             const float wy = (ty.i0 == v ? ty.w0 : 0.f) + (ty.i1 == v ? ty.w1 : 0.f);
             if (wy == 0.f) continue;
             for (int j = jlo; j <= jhi; ++j) {
-              const Tap tx = make_tap(lin10(j, WW) * x0 + lin01(j, WW) * x1, W);
+              const Tap tx = make_tap(lin10(j, WW) * x0 + lin01(j, WW) * x1, W, ac);
               const float wx = (tx.i0 == u ? tx.w0 : 0.f) + (tx.i1 == u ? tx.w1 : 0.f);
               if (wx == 0.f) continue;
               const float wgt = wy * wx;
@@ -350,15 +354,15 @@ __global__ void pool_scatter_kernel(float* __restrict__ pool, const float* __res
 template <bool I64>
 __global__ void __launch_bounds__(256) layout_mass_kernel(const float* __restrict__ vecs, const float* __restrict__ boxes,
                                                          const void* __restrict__ masks, double* __restrict__ mass, int D,
-                                                         int M, int H, int W) {
+                                                         int M, int H, int W, int ac) {
   __shared__ double red[256];
   const size_t o = blockIdx.x;
   const float x0 = boxes[o * 4 + 0], y0 = boxes[o * 4 + 1], x1 = boxes[o * 4 + 2], y1 = boxes[o * 4 + 3];
   double s = 0.0;
   for (int p = threadIdx.x; p < H * W; p += 256) {
     const int h = p / W, w = p - h * W;
-    const Tap ty = make_tap(box_coord(lin01(h, H), y0, y1), M);
-    const Tap tx = make_tap(box_coord(lin01(w, W), x0, x1), M);
+    const Tap ty = make_tap(box_coord(lin01(h, H), y0, y1), M, ac);
+    const Tap tx = make_tap(box_coord(lin01(w, W), x0, x1), M, ac);
     s += (double)sample_mask<I64>(masks, o, M, ty, tx);
   }
   double v = 0.0;
@@ -397,7 +401,7 @@ template <bool I64>
 __global__ void __launch_bounds__(256) layout_test_fwd_kernel(const float* __restrict__ vecs, const float* __restrict__ boxes,
                                                              const void* __restrict__ masks, const int32_t* __restrict__ seg,
                                                              const int32_t* __restrict__ order, float* __restrict__ out,
-                                                             int D, int M, int H, int W, int avg) {
+                                                             int D, int M, int H, int W, int avg, int ac) {
   const int n = blockIdx.y;
   const int beg = seg[n], cnt = seg[n + 1] - beg;
   const int HW = H * W;
@@ -409,8 +413,8 @@ __global__ void __launch_bounds__(256) layout_test_fwd_kernel(const float* __res
   float sv = 0.f;
   for (int r = 0; r < cnt; ++r) {
     const size_t o = (size_t)(beg + order[beg + r]);
-    const Tap ty = make_tap(box_coord(Y, boxes[o * 4 + 1], boxes[o * 4 + 3]), M);
-    const Tap tx = make_tap(box_coord(X, boxes[o * 4 + 0], boxes[o * 4 + 2]), M);
+    const Tap ty = make_tap(box_coord(Y, boxes[o * 4 + 1], boxes[o * 4 + 3]), M, ac);
+    const Tap tx = make_tap(box_coord(X, boxes[o * 4 + 0], boxes[o * 4 + 2]), M, ac);
     const float v = sample_mask<I64>(masks, o, M, ty, tx);
     if (v > 0.5f) { win = (int)o; sv = v; break; }
   }
@@ -421,6 +425,13 @@ __global__ void __launch_bounds__(256) layout_test_fwd_kernel(const float* __res
 }
 
 }  // namespace
+
+// grid_sample geometry of every bilinear operator of this file: 0 = align_corners=False (what torch >= 1.3 executes for the
+// reference's calls, the default and the parity target), 1 = align_corners=True (the PyTorch 1.0 the reference was written
+// and its released checkpoints were trained with: requirements.txt:8).  Process-wide; set it before the first step.
+static int g_align_corners = 0;
+extern "C" int sg_set_legacy_align_corners(int on) { g_align_corners = on ? 1 : 0; return 0; }
+extern "C" int sg_get_legacy_align_corners(void) { return g_align_corners; }
 
 extern "C" int sg_segment_offsets(const int64_t* obj_to_img, int O, int N, int32_t* seg_off, sgStream stream) {
   SG_ARG_CHECK(obj_to_img && seg_off && O >= 0 && N > 0, "sg_segment_offsets: bad arguments");
@@ -454,7 +465,7 @@ extern "C" int sg_masks_to_layout_fwd(const float* vecs, const float* boxes, con
     hipFuncSetAttribute(reinterpret_cast<const void*>(&layout_fwd_kernel<I64, VEC>),                                    \
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                                    \
     hipLaunchKernelGGL((layout_fwd_kernel<I64, VEC>), grid, dim3(256), lds_bytes, s, vecs, boxes, masks, seg_off, out, \
-                       D, M, H, W, avg, cap);                                                                           \
+                       D, M, H, W, avg, cap, g_align_corners);                                                          \
   } while (0)
   if (masks_i64) { if (use_vec == 4) LAUNCH_LAYOUT(true, 4); else LAUNCH_LAYOUT(true, 1); }
   else { if (use_vec == 4) LAUNCH_LAYOUT(false, 4); else LAUNCH_LAYOUT(false, 1); }
@@ -477,15 +488,15 @@ extern "C" int sg_masks_to_layout_test_fwd(const float* vecs, const float* boxes
   SgProfScope prof(SG_K_LAYOUT_FWD, s, 0, 4.0 * N * D * (double)H * W);
   const dim3 grid(sg_cdiv(H * W, 256), N);
   if (masks_i64) {
-    hipLaunchKernelGGL((layout_mass_kernel<true>), dim3(O), dim3(256), 0, s, vecs, boxes, masks, mass, D, M, H, W);
+    hipLaunchKernelGGL((layout_mass_kernel<true>), dim3(O), dim3(256), 0, s, vecs, boxes, masks, mass, D, M, H, W, g_align_corners);
     hipLaunchKernelGGL(layout_order_kernel, dim3(N), dim3(64), 0, s, (const double*)mass, seg_off, order);
     hipLaunchKernelGGL((layout_test_fwd_kernel<true>), grid, dim3(256), 0, s, vecs, boxes, masks, seg_off,
-                       (const int32_t*)order, out, D, M, H, W, avg);
+                       (const int32_t*)order, out, D, M, H, W, avg, g_align_corners);
   } else {
-    hipLaunchKernelGGL((layout_mass_kernel<false>), dim3(O), dim3(256), 0, s, vecs, boxes, masks, mass, D, M, H, W);
+    hipLaunchKernelGGL((layout_mass_kernel<false>), dim3(O), dim3(256), 0, s, vecs, boxes, masks, mass, D, M, H, W, g_align_corners);
     hipLaunchKernelGGL(layout_order_kernel, dim3(N), dim3(64), 0, s, (const double*)mass, seg_off, order);
     hipLaunchKernelGGL((layout_test_fwd_kernel<false>), grid, dim3(256), 0, s, vecs, boxes, masks, seg_off,
-                       (const int32_t*)order, out, D, M, H, W, avg);
+                       (const int32_t*)order, out, D, M, H, W, avg, g_align_corners);
   }
   SG_LAUNCH_CHECK("sg_masks_to_layout_test_fwd");
   return 0;
@@ -502,8 +513,8 @@ extern "C" int sg_masks_to_layout_bwd_vecs(const float* gout, const float* boxes
     hipLaunchKernelGGL(zero_cols_kernel, dim3(sg_cdiv((size_t)O * d_begin, 256)), dim3(256), 0, s, g_vecs, O, D, d_begin);
   SgProfScope prof(SG_K_LAYOUT_BWD, s, 0, 4.0 * N * (D - d_begin) * (double)H * W);
   const dim3 grid(D - d_begin, N);
-  if (masks_i64) hipLaunchKernelGGL(layout_bwd_vecs_kernel<true>, grid, dim3(256), 0, s, gout, boxes, masks, seg_off, g_vecs, D, M, H, W, avg, d_begin);
-  else hipLaunchKernelGGL(layout_bwd_vecs_kernel<false>, grid, dim3(256), 0, s, gout, boxes, masks, seg_off, g_vecs, D, M, H, W, avg, d_begin);
+  if (masks_i64) hipLaunchKernelGGL(layout_bwd_vecs_kernel<true>, grid, dim3(256), 0, s, gout, boxes, masks, seg_off, g_vecs, D, M, H, W, avg, d_begin, g_align_corners);
+  else hipLaunchKernelGGL(layout_bwd_vecs_kernel<false>, grid, dim3(256), 0, s, gout, boxes, masks, seg_off, g_vecs, D, M, H, W, avg, d_begin, g_align_corners);
   SG_LAUNCH_CHECK("sg_masks_to_layout_bwd_vecs");
   return 0;
 }
@@ -516,7 +527,7 @@ extern "C" int sg_crop_bbox_fwd(const float* feats, const float* boxes, const in
   hipStream_t s = (hipStream_t)stream;
   SgProfScope prof(SG_K_CROP, s, 0, 4.0 * B * C * (double)HH * WW + 4.0 * N * C * (double)H * W);
   hipLaunchKernelGGL(crop_fwd_kernel, dim3(sg_cdiv((size_t)B * HH * WW, 256)), dim3(256), 0, s, feats, boxes, box_to_feat, out,
-                     C, H, W, B, HH, WW);
+                     C, H, W, B, HH, WW, g_align_corners);
   SG_LAUNCH_CHECK("sg_crop_bbox_fwd");
   return 0;
 }
@@ -530,10 +541,10 @@ extern "C" int sg_crop_bbox_bwd(const float* gout, const float* boxes, const int
   // writes EVERY element of g_feats (no zero fill needed), additions in a fixed order
   if (C <= 1)
     hipLaunchKernelGGL(crop_bwd_gather_kernel<1>, dim3(sg_cdiv(H * W, 256), N), dim3(256), 0, s, gout, boxes, box_to_feat,
-                       g_feats, C, H, W, B, HH, WW);
+                       g_feats, C, H, W, B, HH, WW, g_align_corners);
   else
     hipLaunchKernelGGL(crop_bwd_gather_kernel<4>, dim3(sg_cdiv(H * W, 256), N), dim3(256), 0, s, gout, boxes, box_to_feat,
-                       g_feats, C, H, W, B, HH, WW);
+                       g_feats, C, H, W, B, HH, WW, g_align_corners);
   SG_LAUNCH_CHECK("sg_crop_bbox_bwd");
   return 0;
 }

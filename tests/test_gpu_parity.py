@@ -1343,3 +1343,32 @@ def test_graphed_segments_are_bit_identical_to_eager(hip):
         assert torch.equal(ia, ib)
     assert torch.equal(res[0][1], res[1][1])
     assert res[0][2] == res[1][2]
+
+
+def test_legacy_align_corners_switch(hip, golden):
+    """set_legacy_align_corners(True): the align_corners=True geometry of PyTorch 1.0 (what the reference's released
+    checkpoints were trained with) against the reference goldens captured with that default; restored afterwards."""
+    import scene_generation_amd
+    from scene_generation_amd.layout import masks_to_layout
+    from scene_generation_amd.bilinear import crop_bbox_batch
+    g = golden('legacy_align_corners')
+    d = lambda k: torch.from_numpy(g[k]).to(DEV)
+    scene_generation_amd.set_legacy_align_corners(True)
+    try:
+        close(masks_to_layout(d('vecs'), d('boxes'), d('masks'), d('obj_to_img'), 16), g['out'], 1e-5, 'layout')
+        with torch.no_grad():
+            close(masks_to_layout(d('vecs'), d('boxes'), d('masks'), d('obj_to_img'), 16, test_mode=True), g['out_test'], 1e-5)
+        v2 = d('v2').requires_grad_()
+        out2 = masks_to_layout(v2, d('b2'), d('m2'), d('o2'), 20, 28)
+        close(out2, g['out2'], 1e-5)
+        (out2 * d('w2')).sum().backward()
+        close(v2.grad, g['gv2'], 2e-5)
+        f = d('feats').requires_grad_()
+        crop = crop_bbox_batch(f, d('cb'), d('idx'), 8)
+        close(crop, g['crop'], 1e-5)
+        (crop * d('wc')).sum().backward()
+        close(f.grad, g['gf'], 2e-5)
+    finally:
+        scene_generation_amd.set_legacy_align_corners(False)
+    out = masks_to_layout(d('vecs'), d('boxes'), d('masks'), d('obj_to_img'), 16)
+    assert float((out.cpu() - torch.from_numpy(g['out'])).abs().max()) > 1e-3      # the default geometry is back

@@ -197,6 +197,31 @@ def test_vgg_loss_vs_reference(golden):
     close(x.grad, g['gx'], 1e-5)
 
 
+def test_legacy_align_corners_vs_reference(golden):
+    """align_corners=True geometry (the PyTorch 1.0 semantics of the reference's grid_sample calls) behind the oracle's
+    LEGACY_ALIGN_CORNERS switch: layout (train + test mode), layout gradient, permuted crops + gradient."""
+    g = golden('legacy_align_corners')
+    O.LEGACY_ALIGN_CORNERS = True
+    try:
+        close(O.masks_to_layout(T(g['vecs']), T(g['boxes']), T(g['masks']), T(g['obj_to_img']), 16), g['out'], 1e-5)
+        close(O.masks_to_layout(T(g['vecs']), T(g['boxes']), T(g['masks']), T(g['obj_to_img']), 16, test_mode=True),
+              g['out_test'], 1e-5)
+        v2 = T(g['v2']).clone().requires_grad_()
+        out2 = O.masks_to_layout(v2, T(g['b2']), T(g['m2']), T(g['o2']), 20, 28)
+        close(out2, g['out2'], 1e-5)
+        (out2 * T(g['w2'])).sum().backward()
+        close(v2.grad, g['gv2'], 1e-5)
+        f = T(g['feats']).clone().requires_grad_()
+        crop = O.crop_bbox_batch(f, T(g['cb']), T(g['idx']), 8)
+        close(crop, g['crop'], 1e-5)
+        (crop * T(g['wc'])).sum().backward()
+        close(f.grad, g['gf'], 1e-5)
+    finally:
+        O.LEGACY_ALIGN_CORNERS = False
+    # and the default geometry really is different
+    assert (O.masks_to_layout(T(g['vecs']), T(g['boxes']), T(g['masks']), T(g['obj_to_img']), 16) - T(g['out'])).abs().max() > 1e-3
+
+
 def test_state_dict_keys_match_reference(golden):
     g = golden('state_dict_keys_full')
     args = parser.parse_args(['--vgg_features_weight', '0', '--output_dir', '/tmp/o'])

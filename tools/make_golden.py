@@ -480,6 +480,47 @@ def golden_losses2():
     npz('losses_variants', **arrs)
 
 
+def golden_legacy():
+    """The reference under ``align_corners=True`` -- what its grid_sample calls (layout.py:51,86,88; bilinear.py:130) meant on
+    the PyTorch 1.0 it was written for (requirements.txt:8).  Captured by making True the default of F.grid_sample while
+    the reference's functions run; pins the ``legacy_align_corners`` switch of the oracle and of the HIP kernels."""
+    import torch.nn.functional as F
+    from scene_generation.layout import masks_to_layout
+    from scene_generation.bilinear import crop_bbox_batch
+    real = F.grid_sample
+
+    def legacy(input, grid, mode='bilinear', padding_mode='zeros', align_corners=None):
+        return real(input, grid, mode=mode, padding_mode=padding_mode, align_corners=True)
+    F.grid_sample = legacy
+    try:
+        vecs, boxes, masks, o2i = demo_layout_inputs()
+        out = masks_to_layout(vecs, boxes, masks, o2i, 16)
+        out_t = masks_to_layout(vecs, boxes, masks, o2i, 16, test_mode=True)
+        g = torch.Generator().manual_seed(13)
+        counts = [3, 1, 4]
+        O = sum(counts)
+        o2 = torch.cat([torch.full((c,), i, dtype=torch.long) for i, c in enumerate(counts)])
+        v2 = det((O, 7), 221).requires_grad_()
+        x0, y0 = torch.rand(O, generator=g) * 0.5, torch.rand(O, generator=g) * 0.5
+        b2 = torch.stack([x0, y0, x0 + 0.1 + 0.4 * torch.rand(O, generator=g), y0 + 0.1 + 0.4 * torch.rand(O, generator=g)], 1)
+        b2[0] = torch.tensor([0., 0., 1., 1.])
+        m2 = torch.rand(O, 16, 16, generator=g)
+        out2 = masks_to_layout(v2, b2, m2, o2, 20, 28)
+        w2 = probe_weight(out2.shape, 222)
+        gv2, = grads_of((out2 * w2).sum(), [v2])
+        feats = det((3, 4, 20, 24), 231).requires_grad_()
+        idx = torch.tensor([1, 0, 1, 2, 0, 2])
+        cb = b2[:6].clone()
+        cb[1] = torch.tensor([0.25, 0.25, 0.75, 0.75])
+        crop = crop_bbox_batch(feats, cb, idx, 8)
+        wc = probe_weight(crop.shape, 232)
+        gf, = grads_of((crop * wc).sum(), [feats])
+    finally:
+        F.grid_sample = real
+    npz('legacy_align_corners', vecs=vecs, boxes=boxes, masks=masks, obj_to_img=o2i, out=out, out_test=out_t,
+        v2=v2, b2=b2, m2=m2, o2=o2, out2=out2, w2=w2, gv2=gv2, feats=feats, idx=idx, cb=cb, crop=crop, wc=wc, gf=gf)
+
+
 def golden_args():
     """flag names + defaults of the reference parser (args.py:10-109)"""
     import json
@@ -491,6 +532,6 @@ def golden_args():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     install_shims()
-    which = sys.argv[1:] or ['gconv', 'layout', 'crop', 'modules', 'losses', 'losses2', 'vgg', 'step', 'testmode', 'args']
+    which = sys.argv[1:] or ['gconv', 'layout', 'crop', 'modules', 'losses', 'losses2', 'vgg', 'legacy', 'step', 'testmode', 'args']
     for w in which:
         globals()['golden_' + w]()
