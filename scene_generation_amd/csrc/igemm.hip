@@ -750,10 +750,9 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   }
   int zblk = blockIdx.z;
   if (bi.xcd_splitk) {
-    // split-K slabs pinned to XCDs: workgroups are handed to the 8 XCDs round-robin in linear (z, x) order; re-number them
-    // so that XCD i runs k-chunks i, i+8, ... of EVERY tile.  Each XCD then streams only its 1/8 of both operands through
-    // its own L2 (a tile-major order makes all 8 L2s fetch most of both operands: measured 5x the algorithmic bytes on
-    // the mask_net weight gradient, which made that kernel HBM-bound at 3.2 TB/s).
+    // experiment (SG_XCD_SPLITK=1, grid.z a multiple of 8): split-K slabs pinned to XCDs -- workgroups are handed to the 8
+    // XCDs round-robin in linear (z, x) order; re-numbered so that XCD i runs k-chunks i, i+8, ... of every tile.  Measured
+    // neutral (532.9 vs 531.6 images/s, identical conv micro-benchmarks), so it is off by default.
     const unsigned lin = blockIdx.z * gridDim.x + blockIdx.x, xcd = lin & 7u, idx = lin >> 3;
     zblk = (int)(xcd + 8u * (idx / gridDim.x));
     const int t = (int)(idx % gridDim.x);
@@ -920,7 +919,7 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
   dim3 grid(tiles, 1, t_grid_z > 0 ? t_grid_z : ((splits > 1 || t_fixed_kchunk > 0) ? sg_cdiv(K, kchunk) : 1));
   BatchInfo bi = t_batch;
   static int xs = -1;
-  if (xs < 0) { const char* e = getenv("SG_XCD_SPLITK"); xs = e ? atoi(e) : 1; }
+  if (xs < 0) { const char* e = getenv("SG_XCD_SPLITK"); xs = e ? atoi(e) : 0; }     // measured neutral on MI355X: off
   bi.xcd_splitk = (xs && t_grid_z == 0 && t_fixed_kchunk == 0 && bi.cols_per_batch == 0 && bi.par.ncls == 0 && bi.ksplit == 0 &&
                    grid.z >= 8 && grid.z % 8 == 0) ? 1 : 0;
   hipLaunchKernelGGL((igemm_kernel<CFG, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, N, K, kchunk, bi);
@@ -1271,7 +1270,10 @@ int run_kn_parity(const float* W, int Rdim, int B, int m0, int M, const Gather& 
   pc.ncls = par.ncls;
   SG_ARG_CHECK(ws_bytes >= pc.off[pc.ncls] * sizeof(float), "conv: parity workspace too small");
   hipLaunchKernelGGL(permute_sub_kernel, dim3(sg_cdiv(pc.off[pc.ncls], 256)), dim3(256), 0, s, W, wbase, Rdim, B, m0, M, KS2, pc);
-  int tile = pick_tile(M, maxNpix);
+  long sumNpix = 0;
+  for (int c = 0; c < par.ncls; ++c) sumNpix += par.Npix[c];
+  int tile = pick_tile(M, (int)sumNpix);          // all classes share the launch: the chip sees the sum of their tiles
+  (void)maxNpix;
   long t128 = 0;
   for (int c = 0; c < par.ncls; ++c) t128 += (long)sg_cdiv(M, 128) * sg_cdiv(par.Npix[c], 128);
   if (tile == 0 && (!vec || t128 < 384)) tile = 1;   // no split-K here
@@ -1403,11 +1405,6 @@ inline NkPlan nk_plan(int M, int C, int KS2, int Kpix, bool two) {
   const int maxs = Kpix / (BK * 8) > 0 ? Kpix / (BK * 8) : 1;
   if (s > maxs) s = maxs;
   if (s > 64) s = 64;
-  if (s >= 6) {                                   // multiples of 8: the k-chunks are pinned to the 8 XCDs (xcd_splitk)
-    int s8 = (s + 7) / 8 * 8;
-    if (s8 > maxs) s8 = maxs / 8 * 8;
-    if (s8 >= 8) s = s8;
-  }
   p.splits = s < 1 ? 1 : s;
   return p;
 }
