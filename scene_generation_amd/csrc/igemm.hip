@@ -249,12 +249,30 @@ const void* cached_table(TabKey key, size_t bytes, hipStream_t s, Build build) {
   return it->second.dev;
 }
 
+// SG_BUFLOAD (masked variants): the gathered elements are fetched with raw BUFFER loads whose hardware range check does the
+// masking -- invalid taps / k tails / pixel tails carry an offset of 2^29 elements in the LDS tap table, which lands beyond
+// num_records (2^31 bytes) and makes the load return 0.  No address select, no validity bits, no zero-select before the LDS
+// store: ~20 of the ~60 VALU instructions per k-tile of the 64x64 kernel (the f32 MFMA competes with VALU work for the SIMD).
+#ifndef SG_BUFLOAD
+#define SG_BUFLOAD 0
+#endif
+constexpr int TAP_INVALID = SG_BUFLOAD ? (1 << 29) : -1;
+#if SG_BUFLOAD
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sg_rsrc(const float* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x80000000u, 0x00020000);
+}
+__device__ __forceinline__ float sg_bufload(__amdgpu_buffer_rsrc_t r, unsigned elem) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(elem << 2), 0, 0));
+}
+#endif
+
 template <int BN, int KS, int MODE, bool TWO, bool MASK = true>
 struct LoadGatherKN {
   Gather g; int Npix; const KEntry* ktab;
   static constexpr int KS2 = KS * KS;
   static constexpr int LDS_INTS = (KS2 + 1) * BN;
   static constexpr int ROWS = BN * BK / 256;
+  static constexpr bool BUF = SG_BUFLOAD && MASK;
   struct Stage { float r[ROWS]; unsigned ok; KEntry e[ROWS]; };
   unsigned img1_, img2_, img2b_;
   int nl_, kr_;
@@ -281,7 +299,9 @@ struct LoadGatherKN {
     constexpr int G = 256 / BN;
     for (int t = grp; t <= KS2; t += G) {
       const int kh = t / KS, kw = t - kh * KS;
-      tab[t * BN + nl_] = (okn && t < KS2) ? tap_offset<MODE>(g, ah, aw, kh, kw) : -1;
+      int v = (okn && t < KS2) ? tap_offset<MODE>(g, ah, aw, kh, kw) : -1;
+      if (BUF && v < 0) v = TAP_INVALID;
+      tab[t * BN + nl_] = v;
     }
     tab_ = tab + nl_;
   }
@@ -292,6 +312,24 @@ struct LoadGatherKN {
     for (int i = 0; i < ROWS; ++i) st.e[i] = e[i];
   }
   __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
+#if SG_BUFLOAD
+    if (BUF) {
+      const __amdgpu_buffer_rsrc_t r1 = sg_rsrc(g.src1);
+#pragma unroll
+      for (int i = 0; i < ROWS; ++i) {
+        const unsigned choff = st.e[i].choff, ts = st.e[i].tapsel;
+        const unsigned tp = (unsigned)tab_[(ts & 255u) * BN];
+        if (TWO) {
+          const bool second = (ts & 256u) != 0u;                  // scalar
+          const unsigned t2 = (second && g.bcast2) ? (tp >= (unsigned)TAP_INVALID ? tp : 0u) : tp;
+          st.r[i] = sg_bufload(second ? sg_rsrc(g.src2) : r1, (second ? img2_ : img1_) + choff + t2);
+        } else {
+          st.r[i] = sg_bufload(r1, img1_ + choff + tp);
+        }
+      }
+      return;
+    }
+#endif
     st.ok = 0;
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
@@ -309,7 +347,10 @@ struct LoadGatherKN {
       st.ok |= ok ? (1u << i) : 0u;
     }
   }
-  __device__ __forceinline__ void store(const Stage& st, float* T) const { store_krun<ROWS, MASK>(T, nl_, kr_, st.r, st.ok); }
+  __device__ __forceinline__ void store(const Stage& st, float* T) const {
+    if (BUF) store_krun<ROWS, false>(T, nl_, kr_, st.r, 0u);
+    else store_krun<ROWS, MASK>(T, nl_, kr_, st.r, st.ok);
+  }
 };
 
 // n / d for 0 <= n < 2^31 as one v_mul_hi + shift (the k-loop splits a pixel index every tile: a hardware-less
@@ -881,6 +922,7 @@ using CfgW128 = TileCfg<128, 128, 2, NSW>;
 using CfgW64 = TileCfg<64, 64, 2, NSW>;
 using CfgW32 = TileCfg<32, 128, 1, NSW>;
 using CfgD128 = TileCfg<128, 128, 2, 2>;     // dense Winograd GEMMs
+using CfgD128x64 = TileCfg<128, 64, 2, 1>;   // experiment (SG_WINO_TILE=1): half-width tiles, 4-5 workgroups per CU
 
 inline int pick_tile(int M, int N) {
   static int force = -2;
@@ -2108,8 +2150,17 @@ void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, in
   t_batch = BatchInfo{}; t_batch.cols_per_batch = cols; t_batch.nbatch = 16; t_batch.a_stride = M * K; t_batch.batch_major = 1;
   {
     SgProfScope prof(SG_K_WINO_GEMM_128, s, flops, 0);
-    launch_cfg<CfgD128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M, 16 * cols,
-                        K, 1, s);
+    static int wt = -1;
+    if (wt < 0) { const char* e = getenv("SG_WINO_TILE"); wt = e ? atoi(e) : 0; }
+    if (wt == 1)
+      launch_cfg<CfgD128x64>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<64, true, false>{B, K, 16 * cols}, ep, M,
+                             16 * cols, K, 1, s);
+    else if (wt == 2)
+      launch_cfg<Cfg128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M,
+                         16 * cols, K, 1, s);
+    else
+      launch_cfg<CfgD128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M,
+                          16 * cols, K, 1, s);
   }
   t_batch = BatchInfo{};
 }
