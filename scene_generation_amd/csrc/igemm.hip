@@ -55,6 +55,31 @@ constexpr int LDK = BK + 4;
 // loads, or selects placed right behind the loads, made hipcc wait vmcnt(0) before the MFMAs: 4-5x slower.)
 // Offsets are 32-bit: the host rejects tensors of >= 2^31 elements.
 
+// SG_BUFLOAD (masked variants): the gathered elements are fetched with raw BUFFER loads whose hardware range check does the
+// masking -- invalid taps / k tails / pixel tails carry an offset of 2^29 elements in the LDS tap table, which lands beyond
+// num_records (2^31 bytes) and makes the load return 0.  No address select, no validity bits, no zero-select before the LDS
+// store: ~20 of the ~60 VALU instructions per k-tile of the 64x64 kernel (the f32 MFMA competes with VALU work for the SIMD).
+#ifndef SG_BUFLOAD
+#define SG_BUFLOAD 1     // measured on MI355X: 537 -> 554 images/s, conv fwd / dgrad micro-benchmarks +7..20 %
+#endif
+constexpr int TAP_INVALID = SG_BUFLOAD ? (1 << 29) : -1;
+#if SG_BUFLOAD
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sg_rsrc(const float* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x80000000u, 0x00020000);
+}
+__device__ __forceinline__ float sg_bufload(__amdgpu_buffer_rsrc_t r, unsigned elem) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(elem << 2), 0, 0));
+}
+typedef unsigned sg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 sg_bufload4(__amdgpu_buffer_rsrc_t r, unsigned elem) {
+  const sg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(elem << 2), 0, 0);
+  return make_float4(__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y), __builtin_bit_cast(float, v.z),
+                     __builtin_bit_cast(float, v.w));
+}
+#endif
+constexpr unsigned ELEM_INVALID = 1u << 29;      // element offset that the range check of a buffer load rejects
+
+
 // rows of length K contiguous in memory: elem(x, k) = base[x*ld + k].  VEC: ld%4==0 and 16-B aligned base.
 template <int BX, bool VEC, bool MASK = true>
 struct LoadKContig {
@@ -79,15 +104,23 @@ struct LoadKContig {
         st.r[p * 4 + 0] = v.x; st.r[p * 4 + 1] = v.y; st.r[p * 4 + 2] = v.z; st.r[p * 4 + 3] = v.w;
       } else if (VEC) {                           // kend % 4 == 0 here, so k < kend covers the whole float4
         const bool ok = xok && k < kend;
+#if SG_BUFLOAD
+        const float4 v = sg_bufload4(sg_rsrc(base), ok ? row + (unsigned)k : ELEM_INVALID);      // rejected => zeros
+#else
         const float4 v = *reinterpret_cast<const float4*>(base + row + (ok ? k : 0));
-        st.r[p * 4 + 0] = v.x; st.r[p * 4 + 1] = v.y; st.r[p * 4 + 2] = v.z; st.r[p * 4 + 3] = v.w;
         st.ok |= ok ? (15u << (p * 4)) : 0u;
+#endif
+        st.r[p * 4 + 0] = v.x; st.r[p * 4 + 1] = v.y; st.r[p * 4 + 2] = v.z; st.r[p * 4 + 3] = v.w;
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const bool ok = xok && k + i < kend;
+#if SG_BUFLOAD
+          st.r[p * 4 + i] = sg_bufload(sg_rsrc(base), ok ? row + (unsigned)(k + i) : ELEM_INVALID);
+#else
           st.r[p * 4 + i] = base[row + (ok ? k + i : 0)];
           st.ok |= ok ? (1u << (p * 4 + i)) : 0u;
+#endif
         }
       }
     }
@@ -96,7 +129,7 @@ struct LoadKContig {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int xl = xr_ + p * 64;
-      if (xl < BX && VEC && !MASK) {
+      if (xl < BX && (SG_BUFLOAD || (VEC && !MASK))) {      // (buffer loads already returned zeros for the masked elements)
         *reinterpret_cast<float4*>(T + xl * LDK + kq_) = make_float4(st.r[p * 4], st.r[p * 4 + 1], st.r[p * 4 + 2], st.r[p * 4 + 3]);
       } else if (xl < BX) {
         float4 v;
@@ -249,23 +282,6 @@ const void* cached_table(TabKey key, size_t bytes, hipStream_t s, Build build) {
   return it->second.dev;
 }
 
-// SG_BUFLOAD (masked variants): the gathered elements are fetched with raw BUFFER loads whose hardware range check does the
-// masking -- invalid taps / k tails / pixel tails carry an offset of 2^29 elements in the LDS tap table, which lands beyond
-// num_records (2^31 bytes) and makes the load return 0.  No address select, no validity bits, no zero-select before the LDS
-// store: ~20 of the ~60 VALU instructions per k-tile of the 64x64 kernel (the f32 MFMA competes with VALU work for the SIMD).
-#ifndef SG_BUFLOAD
-#define SG_BUFLOAD 0
-#endif
-constexpr int TAP_INVALID = SG_BUFLOAD ? (1 << 29) : -1;
-#if SG_BUFLOAD
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t sg_rsrc(const float* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x80000000u, 0x00020000);
-}
-__device__ __forceinline__ float sg_bufload(__amdgpu_buffer_rsrc_t r, unsigned elem) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(elem << 2), 0, 0));
-}
-#endif
-
 template <int BN, int KS, int MODE, bool TWO, bool MASK = true>
 struct LoadGatherKN {
   Gather g; int Npix; const KEntry* ktab;
@@ -392,17 +408,23 @@ struct LoadPixKVec {
     for (int i = 0; i < Q; ++i) {
       const int m = m0_ + row_ + 64 * i;
       const bool ok = kok && m < M && (row_ + 64 * i < BM);
+#if SG_BUFLOAD
+      st.r[i] = sg_bufload4(sg_rsrc(base), ok ? p0 + (unsigned)m * (unsigned)PQ : ELEM_INVALID);       // rejected => zeros
+#else
       st.r[i] = *reinterpret_cast<const float4*>(base + (ok ? p0 + (unsigned)m * (unsigned)PQ : 0u));
       st.ok |= ok ? (1u << i) : 0u;
+#endif
     }
   }
   __device__ __forceinline__ void store(const Stage& st, float* T) const {
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
       if (row_ + 64 * i < BM) {
-        const bool ok = (st.ok >> i) & 1u;
         float4 v = st.r[i];
+#if !SG_BUFLOAD
+        const bool ok = (st.ok >> i) & 1u;
         if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         *reinterpret_cast<float4*>(T + (row_ + 64 * i) * LDK + kq_) = v;
       }
     }
@@ -431,13 +453,18 @@ struct LoadPixK {
     for (int i = 0; i < ROWS; ++i) {
       const int m = m0_ + mr_ + 16 * i;
       const bool ok = !MASK || (kok && m < M);
+#if SG_BUFLOAD
+      st.r[i] = sg_bufload(sg_rsrc(base), ok ? p0 + (unsigned)m * (unsigned)PQ : ELEM_INVALID);
+#else
       st.r[i] = base[ok ? p0 + (unsigned)m * (unsigned)PQ : 0u];
       st.ok |= ok ? (1u << i) : 0u;
+#endif
     }
   }
   __device__ __forceinline__ void store(const Stage& st, float* T) const {
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) T[(mr_ + 16 * i) * LDK + kl_] = (!MASK || ((st.ok >> i) & 1u)) ? st.r[i] : 0.f;
+    for (int i = 0; i < ROWS; ++i)
+      T[(mr_ + 16 * i) * LDK + kl_] = (SG_BUFLOAD || !MASK || ((st.ok >> i) & 1u)) ? st.r[i] : 0.f;
   }
 };
 
@@ -603,13 +630,31 @@ struct LoadTapNK {
       const bool valid = kok && (ih | iw) >= 0;
       const unsigned shw = (unsigned)(g.SH * g.SW);
       const unsigned tp = (unsigned)(ih * g.SW + iw);
-      buf[tid_] = valid ? (int)(img * (unsigned)g.C1 * shw + tp) : -1;
-      if (TWO) buf[BK + tid_] = (int)(g.bcast2 ? img * (unsigned)g.C2 : img * (unsigned)g.C2 * shw + tp);
+      buf[tid_] = valid ? (int)(img * (unsigned)g.C1 * shw + tp) : ((SG_BUFLOAD && MASK) ? (int)ELEM_INVALID : -1);
+      if (TWO) buf[BK + tid_] = (SG_BUFLOAD && MASK && !valid) ? (int)ELEM_INVALID
+                                    : (int)(g.bcast2 ? img * (unsigned)g.C2 : img * (unsigned)g.C2 * shw + tp);
     }
   }
   __device__ __forceinline__ void load(Stage& st, int k0, int) const {
     const int* buf = buf_of(k0);
     const int o1 = buf[kl_];
+#if SG_BUFLOAD
+    if (MASK) {        // invalid pixels carry ELEM_INVALID: the buffer load's range check returns zeros, nothing to select
+      const unsigned u1 = (unsigned)o1, u2 = TWO ? (unsigned)buf[BK + kl_] : 0u;
+      const __amdgpu_buffer_rsrc_t r1 = sg_rsrc(g.src1);
+#pragma unroll
+      for (int j = 0; j < COLS; ++j) {
+        if (TWO) {
+          const bool second = (secmask_ >> j) & 1u;
+          st.r[j] = second ? sg_bufload(sg_rsrc(g.src2), u2 + choff_[j]) : sg_bufload(r1, u1 + choff_[j]);
+        } else {
+          st.r[j] = sg_bufload(r1, u1 + choff_[j]);
+        }
+      }
+      st.ok = 1u;
+      return;
+    }
+#endif
     const bool ok = !MASK || o1 >= 0;
     const unsigned b1 = ok ? (unsigned)o1 : 0u;         // invalid pixel: element 0 of the channel plane, zeroed in store()
     const unsigned b2 = (TWO && ok) ? (unsigned)buf[BK + kl_] : 0u;
