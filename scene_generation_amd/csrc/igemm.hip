@@ -70,11 +70,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sg_rsrc(const float* p) {
 __device__ __forceinline__ float sg_bufload(__amdgpu_buffer_rsrc_t r, unsigned elem) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(elem << 2), 0, 0));
 }
-typedef unsigned sg_u32x4 __attribute__((ext_vector_type(4)));
+// (the result is moved with memcpy: naming the builtin's vector type and indexing it made hipcc 7.2 select a ONE-dword load)
 __device__ __forceinline__ float4 sg_bufload4(__amdgpu_buffer_rsrc_t r, unsigned elem) {
-  const sg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(elem << 2), 0, 0);
-  return make_float4(__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y), __builtin_bit_cast(float, v.z),
-                     __builtin_bit_cast(float, v.w));
+  const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(elem << 2), 0, 0);
+  static_assert(sizeof(v) == 16, "raw_buffer_load_b128 must return 16 bytes");
+  float4 f;
+  __builtin_memcpy(&f, &v, 16);
+  return f;
 }
 #endif
 constexpr unsigned ELEM_INVALID = 1u << 29;      // element offset that the range check of a buffer load rejects
