@@ -785,10 +785,6 @@ struct BatchInfo {
   int batch_major;
   // xcd_splitk: plain split-K launch (grid.z = splits, a multiple of 8, (tiles * splits) % 8 == 0): see the kernel
   int xcd_splitk;
-  // tune (experiments, SG_TUNE): bit 0 = workgroups of the second resident "layer" (linear id / 256 odd) start ~half a k-tile
-  // late, so that the two waves sharing a SIMD do not run their MFMA bursts and their load phases in lock-step;
-  // bit 1 = raised wave priority during the MFMA burst
-  int tune;
   ParityClasses par;
 };
 // per-class hooks: loaders / epilogues that can run a parity class overload these; everything else ignores the call
@@ -900,9 +896,6 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
 
   const int lr = lane & 31, lk = lane >> 5;
   int buf = 0;
-  if ((bi.tune & 1) && (((blockIdx.x + blockIdx.z * gridDim.x) >> 8) & 1)) {
-    __builtin_amdgcn_s_sleep(8 * NSUB * TM * TN / 2);      // x64 cycles = half the MFMA time of one k-tile
-  }
   for (int k0 = kbeg; k0 < kend; k0 += BKT) {
     const bool more = k0 + BKT < kend;
     if (more) {
@@ -925,7 +918,6 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[j][h] = *reinterpret_cast<const float4*>(B_ + j * 32 * LDK + h * 4);
       }
-      if (bi.tune & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -941,7 +933,6 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
           }
         }
       }
-      if (bi.tune & 2) __builtin_amdgcn_s_setprio(0);
     }
     if (more) {
 #pragma unroll
@@ -1018,9 +1009,6 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
   BatchInfo bi = t_batch;
   static int xs = -1;
   if (xs < 0) { const char* e = getenv("SG_XCD_SPLITK"); xs = e ? atoi(e) : 0; }     // measured neutral on MI355X: off
-  static int tune = -1;
-  if (tune < 0) { const char* e = getenv("SG_TUNE"); tune = e ? atoi(e) : 0; }
-  bi.tune = tune;
   bi.xcd_splitk = (xs && t_grid_z == 0 && t_fixed_kchunk == 0 && bi.cols_per_batch == 0 && bi.par.ncls == 0 && bi.ksplit == 0 &&
                    grid.z >= 8 && grid.z % 8 == 0) ? 1 : 0;
   hipLaunchKernelGGL((igemm_kernel<CFG, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, N, K, kchunk, bi);
