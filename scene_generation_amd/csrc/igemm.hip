@@ -2067,11 +2067,14 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
   if (i >= RC) return;
   const int c = (int)(i % Cc);
   const size_t r = i / Cc;
+  // flip: 0 = w[r][c]; 1 = transposed and rotated by 180 degrees (w[c][r], taps reversed); 2 = transposed only (the adjoint
+  // of the forward transform: same taps, channel roles swapped)
   const float* g = w + (flip ? ((size_t)c * R + r) * 9 : i * 9);
   float t[4][3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const float g0 = flip ? g[8 - j] : g[j], g1 = flip ? g[5 - j] : g[3 + j], g2 = flip ? g[2 - j] : g[6 + j];
+    const bool rot = flip == 1;
+    const float g0 = rot ? g[8 - j] : g[j], g1 = rot ? g[5 - j] : g[3 + j], g2 = rot ? g[2 - j] : g[6 + j];
     t[0][j] = g0; t[1][j] = 0.5f * (g0 + g1 + g2); t[2][j] = 0.5f * (g0 - g1 + g2); t[3][j] = g2;
   }
 #pragma unroll
@@ -2125,6 +2128,101 @@ __global__ void wino_gy_kernel(const float* __restrict__ gy, float* __restrict__
     const float v[4] = {t[i][0], t[i][0] + t[i][1], t[i][0] - t[i][1], -t[i][1]};
 #pragma unroll
     for (int j = 0; j < 4; ++j) Yt[((size_t)(i * 4 + j) * M + m) * P + p] = v[j];
+  }
+}
+
+// ---- adjoint ("transposed") Winograd for the data gradient of the reflection-padded convs -----------------------------------
+// y_tile = A^T [sum_c U[c] (.) (B^T d B)] A  ==>  g_d = B [sum_co U[co][ci] (.) (A gy_tile A^T)] B^T, overlap-added into the
+// padded gradient grid and folded by the reflection.  The GEMM runs over the N*(H/2)*(W/2) OUTPUT tiles (512 at 8x8, batch 32)
+// instead of the 800 (-> 896 padded) tiles of the (H+2)x(W+2) grid the correlation form needs: 1.75x fewer MACs.
+//
+// Ytp[xi][p][m] = (A gy A^T)[xi] of the 2x2 gradient tile p, small planes, LDS-staged (lanes along the channel m)
+__global__ void __launch_bounds__(256) wino_gy_small_kernel(const float* __restrict__ gy, float* __restrict__ Ytp, int N, int M, int H,
+                                                           int W) {
+  extern __shared__ __attribute__((aligned(16))) float pl[];
+  const int HW = H * W, pitch = HW + 1, TH = H / 2, TW = W / 2;
+  const int n = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
+  const float* src = gy + ((size_t)n * M + c0) * HW;
+  for (int i = tid * 4; i < 64 * HW; i += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(src + i);
+    const int ch = i / HW, px = i - ch * HW;
+    float* d = pl + ch * pitch + px;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  const int c = tid & 63, g = tid >> 6;
+  const float* pc = pl + c * pitch;
+  const size_t P = (size_t)N * TH * TW;
+  for (int t = g; t < TH * TW; t += 4) {
+    const int ti = t / TW, tj = t - ti * TW;
+    const float a0 = pc[(2 * ti) * W + 2 * tj], a1 = pc[(2 * ti) * W + 2 * tj + 1];
+    const float b0 = pc[(2 * ti + 1) * W + 2 * tj], b1 = pc[(2 * ti + 1) * W + 2 * tj + 1];
+    const float tt[4][2] = {{a0, a1}, {a0 + b0, a1 + b1}, {a0 - b0, a1 - b1}, {-b0, -b1}};
+    const size_t p = (size_t)n * TH * TW + t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float v[4] = {tt[i][0], tt[i][0] + tt[i][1], tt[i][0] - tt[i][1], -tt[i][1]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Ytp[((size_t)(i * 4 + j) * P + p) * M + c0 + c] = v[j];
+    }
+  }
+}
+
+// gx[n][c][H][W] from G[p][xi][c] (row length 16*C): per channel, the 4x4 patches B G B^T of the tiles are overlap-added in
+// tile order into a padded (H+2)x(W+2) plane (private to the thread: no synchronisation, fixed order), the reflection is
+// folded, and the 64 channel planes of the workgroup -- one contiguous block of memory -- are written with coalesced float4s.
+__global__ void __launch_bounds__(64) wino_patch_fold_kernel(const float* __restrict__ G, float* __restrict__ gx, int N, int C, int H,
+                                                            int W) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int HW = H * W, PW = W + 2, PP = (H + 2) * PW, TH = H / 2, TW = W / 2;
+  const int n = blockIdx.y, c0 = blockIdx.x * 64, c = threadIdx.x;
+  float* acc = lds + c * (PP + 1);
+  float* stage = lds + 64 * (PP + 1);              // [64][HW + 1]
+  for (int i = 0; i < PP; ++i) acc[i] = 0.f;
+  const size_t ld = (size_t)16 * C;
+  for (int t = 0; t < TH * TW; ++t) {
+    const int ti = t / TW, tj = t - ti * TW;
+    const float* src = G + ((size_t)n * TH * TW + t) * ld + c0 + c;
+    float q[4][4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) q[i >> 2][i & 3] = src[(size_t)i * C];
+    float r[4][4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      r[0][v] = q[0][v]; r[1][v] = q[1][v] - q[2][v] + q[3][v]; r[2][v] = -q[0][v] + q[1][v] + q[2][v]; r[3][v] = -q[3][v];
+    }
+    float* dst = acc + (2 * ti) * PW + 2 * tj;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      dst[a * PW + 0] += r[a][0];
+      dst[a * PW + 1] += r[a][1] - r[a][2] + r[a][3];
+      dst[a * PW + 2] += -r[a][0] + r[a][1] + r[a][2];
+      dst[a * PW + 3] += -r[a][3];
+    }
+  }
+  float* so = stage + c * (HW + 1);
+  for (int a = 0; a < H; ++a) {
+    for (int b = 0; b < W; ++b) {
+      float v = acc[(a + 1) * PW + b + 1];
+      const int ra = a == 1 ? 0 : -1, rb = a == H - 2 ? H + 1 : -1;        // padded rows folded onto row a
+      const int ca = b == 1 ? 0 : -1, cb = b == W - 2 ? W + 1 : -1;        // padded columns folded onto column b
+      if (ra >= 0) v += acc[ra * PW + b + 1];
+      if (rb >= 0) v += acc[rb * PW + b + 1];
+      if (ca >= 0) v += acc[(a + 1) * PW + ca];
+      if (cb >= 0) v += acc[(a + 1) * PW + cb];
+      if (ra >= 0 && ca >= 0) v += acc[ra * PW + ca];
+      if (ra >= 0 && cb >= 0) v += acc[ra * PW + cb];
+      if (rb >= 0 && ca >= 0) v += acc[rb * PW + ca];
+      if (rb >= 0 && cb >= 0) v += acc[rb * PW + cb];
+      so[a * W + b] = v;
+    }
+  }
+  __syncthreads();
+  float* dstg = gx + ((size_t)n * C + c0) * HW;
+  for (int i = c * 4; i < 64 * HW; i += 256) {
+    const int ch = i / HW, px = i - ch * HW;
+    const float* sp = stage + ch * (HW + 1) + px;
+    *reinterpret_cast<float4*>(dstg + i) = make_float4(sp[0], sp[1], sp[2], sp[3]);
   }
 }
 
@@ -2243,6 +2341,33 @@ extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const 
   const int M = d->C1, K = d->Cout;                 // rows = input channels, reduction over output channels
   const int LH = d->H * d->upsample, LW = d->W * d->upsample;
   const int refl = d->pad_reflect;
+  static int adj = -1;
+  if (adj < 0) { const char* e = getenv("SG_WINO_ADJOINT"); adj = e ? atoi(e) : 1; }
+  if (adj && refl && d->upsample == 1 && d->H * d->W <= 256 && (d->H * d->W) % 4 == 0 && M % 64 == 0 && K % 64 == 0 &&
+      aligned16(gy) && aligned16(gx)) {
+    // adjoint Winograd over the output tiles (see wino_gy_small_kernel / wino_patch_fold_kernel)
+    const int HW = d->H * d->W;
+    const size_t P = (size_t)d->N * (d->H / 2) * (d->W / 2);
+    float* UT = reinterpret_cast<float*>(ws);       // [16][C1][Cout]
+    float* Ytp = UT + 16 * (size_t)M * K;           // [16][P][Cout]
+    float* G = Ytp + 16 * P * K;                    // [P][16][C1]
+    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0);
+      hipLaunchKernelGGL(wino_weight_kernel, dim3(sg_cdiv((size_t)M * K, 256)), dim3(256), 0, s, w, UT, M, K, 2); }
+    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0);
+      const size_t lds = (size_t)64 * (HW + 1) * sizeof(float);
+      if (lds > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gy_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(wino_gy_small_kernel, dim3(K / 64, d->N), dim3(256), lds, s, gy, Ytp, d->N, K, d->H, d->W); }
+    // G[p][xi*C1 + ci] = sum_co Ytp[xi][p][co] * UT[xi][ci][co]
+    wino_bgemm(Ytp, UT, G, (int)P, M, K, 2.0 * M * (double)K * 16.0 * P, s);
+    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0);
+      const size_t lds = (size_t)64 * ((d->H + 2) * (d->W + 2) + 1 + HW + 1) * sizeof(float);
+      if (lds > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_patch_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(wino_patch_fold_kernel, dim3(M / 64, d->N), dim3(64), lds, s, (const float*)G, gx, d->N, M, d->H, d->W); }
+    SG_LAUNCH_CHECK("sg_conv2d_wino_dgrad");
+    return 0;
+  }
   const int TH = LH / 2 + (refl ? 1 : 0), TW = LW / 2 + (refl ? 1 : 0);
   const size_t Pd = wino_dgrad_tiles(d);
   float* U = reinterpret_cast<float*>(ws);          // [16][C1][Cout]
