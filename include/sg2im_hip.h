@@ -238,6 +238,13 @@ int sg_masks_to_layout_test_fwd(const float* vecs, const float* boxes, const voi
 int sg_masks_to_layout_bwd_vecs(const float* gout, const float* boxes, const void* masks, int masks_i64,
                                 const int64_t* obj_to_img, const int32_t* seg_off, float* g_vecs, int N, int O, int D,
                                 int M, int H, int W, int avg, int d_begin, sgStream stream);
+/* gradients of masks_to_layout w.r.t. the masks (float masks only) and / or the boxes (layout.py:85-86 is differentiable in
+ * both): g_masks [O, M, M], g_boxes [O, 4] (either may be null); ws >= sg_masks_to_layout_bwd_geom_ws_bytes (O x H x W
+ * floats: the per-object gradient map sum_d gout[n,d] * vecs[o,d]); gather formulation, deterministic */
+size_t sg_masks_to_layout_bwd_geom_ws_bytes(int O, int H, int W);
+int sg_masks_to_layout_bwd_geom(const float* gout, const float* vecs, const float* boxes, const void* masks, int masks_i64,
+                                const int64_t* obj_to_img, const int32_t* seg_off, float* g_masks, float* g_boxes, void* ws,
+                                size_t ws_bytes, int N, int O, int D, int M, int H, int W, int avg, sgStream stream);
 int sg_crop_bbox_fwd(const float* feats, const float* boxes, const int64_t* box_to_feat, float* out, int N, int C, int H,
                      int W, int B, int HH, int WW, sgStream stream);
 /* g_feats [N, C, H, W] is written completely (no zero fill needed): a gather over the crop pixels whose bilinear

@@ -673,3 +673,131 @@ extern "C" int sg_factored_weights_bwd(const float* gwimg, const float* w, const
   SG_LAUNCH_CHECK("sg_factored_weights_bwd");
   return 0;
 }
+
+// ================================================================================================
+// masks_to_layout: gradients w.r.t. the masks and the boxes (layout.py:85-86 is differentiable in both; no loss of the
+// training step uses them -- pred_layout only feeds TensorBoard -- but the operator surface offers them).
+//   out[n,d,h,w] = sum_o vecs[o,d] * S_o[h,w],  S_o = bilinear(mask_o; px(w; x0,x1), py(h; y0,y1))
+// Stage 1: T_o[h,w] = sum_d gout[n_o,d,h,w] * vecs[o,d]  (/ objects of the image for 'avg' pooling).
+// Stage 2 (masks): g_mask[o,y,x] = sum_{h,w} T_o[h,w] * wy(h -> y) * wx(w -> x) as a GATHER over the pixels whose footprint
+//   covers the mask element (the sample coordinate is affine in the pixel index: candidate ranges + exact tap check), summed
+//   in (h, w) order: deterministic.
+// Stage 3 (boxes): g_box[o] = sum_{h,w} T_o[h,w] * (dS/dpx * dpx/dx0, dS/dpy * dpy/dy0, dS/dpx * dpx/dx1, dS/dpy * dpy/dy1)
+//   with grid_sample's own derivative (zeros padding: only in-range taps contribute); block reduction in fixed order.
+// ================================================================================================
+namespace {
+
+__global__ void __launch_bounds__(256) layout_objmap_kernel(const float* __restrict__ gout, const float* __restrict__ vecs,
+                                                           const int64_t* __restrict__ o2i, const int32_t* __restrict__ seg,
+                                                           float* __restrict__ T, int D, int HW, int avg) {
+  const int o = blockIdx.y;
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  if (px >= HW) return;
+  const int n = (int)o2i[o];
+  const float* g = gout + (size_t)n * D * HW + px;
+  const float* v = vecs + (size_t)o * D;
+  float s = 0.f;
+  for (int d = 0; d < D; ++d) s += g[(size_t)d * HW] * v[d];
+  if (avg) { const int cnt = seg[n + 1] - seg[n]; s = s / (float)(cnt > 1 ? cnt : 1); }
+  T[(size_t)o * HW + px] = s;
+}
+
+// candidate pixel range [lo, hi] whose bilinear footprint can touch mask index y along one axis
+__device__ __forceinline__ void layout_axis_range(float b0, float b1, int n_pix, int M, int y, int& lo, int& hi, int ac) {
+  const float p0 = tap_coord(box_coord(0.f, b0, b1), M, ac), p1 = tap_coord(box_coord(1.f, b0, b1), M, ac);
+  lo = 0; hi = n_pix - 1;
+  if (n_pix == 1 || !(fabsf(p0) < 1e8f) || !(fabsf(p1) < 1e8f)) return;
+  const float s = (p1 - p0) / (float)(n_pix - 1);
+  if (fabsf(s) < 1e-6f) return;
+  float a = ((float)(y - 1) - p0) / s, b = ((float)(y + 1) - p0) / s;
+  if (a > b) { const float t = a; a = b; b = t; }
+  const float fl = floorf(a) - 1.f, fh = ceilf(b) + 1.f;
+  lo = fl < 0.f ? 0 : (fl > (float)(n_pix - 1) ? n_pix : (int)fl);
+  hi = fh > (float)(n_pix - 1) ? n_pix - 1 : (fh < 0.f ? -1 : (int)fh);
+}
+
+__global__ void __launch_bounds__(256) layout_bwd_masks_kernel(const float* __restrict__ T, const float* __restrict__ boxes,
+                                                              float* __restrict__ gm, int M, int H, int W, int ac) {
+  const int o = blockIdx.y;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= M * M) return;
+  const int y = e / M, x = e - y * M;
+  const float x0 = boxes[o * 4 + 0], y0 = boxes[o * 4 + 1], x1 = boxes[o * 4 + 2], y1 = boxes[o * 4 + 3];
+  int hlo, hhi, wlo, whi;
+  layout_axis_range(y0, y1, H, M, y, hlo, hhi, ac);
+  layout_axis_range(x0, x1, W, M, x, wlo, whi, ac);
+  const float* t = T + (size_t)o * H * W;
+  float s = 0.f;
+  for (int h = hlo; h <= hhi; ++h) {
+    const Tap ty = make_tap(box_coord(lin01(h, H), y0, y1), M, ac);
+    const float wy = (ty.i0 == y ? ty.w0 : 0.f) + (ty.i1 == y ? ty.w1 : 0.f);
+    if (wy == 0.f) continue;
+    for (int w = wlo; w <= whi; ++w) {
+      const Tap tx = make_tap(box_coord(lin01(w, W), x0, x1), M, ac);
+      const float wx = (tx.i0 == x ? tx.w0 : 0.f) + (tx.i1 == x ? tx.w1 : 0.f);
+      if (wx != 0.f) s += t[h * W + w] * (wy * wx);
+    }
+  }
+  gm[(size_t)o * M * M + e] = s;
+}
+
+template <bool I64>
+__global__ void __launch_bounds__(256) layout_bwd_boxes_kernel(const float* __restrict__ T, const float* __restrict__ boxes,
+                                                              const void* __restrict__ masks, float* __restrict__ gb, int M, int H,
+                                                              int W, int ac) {
+  __shared__ float red[16];
+  const size_t o = blockIdx.x;
+  const float x0 = boxes[o * 4 + 0], y0 = boxes[o * 4 + 1], x1 = boxes[o * 4 + 2], y1 = boxes[o * 4 + 3];
+  const float dx = x1 - x0, dy = y1 - y0;
+  const float scale = ac ? 0.5f * (float)(M - 1) : 0.5f * (float)M;          // d(pixel coordinate) / d(normalised coordinate)
+  const float* t = T + o * H * W;
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+  for (int p = threadIdx.x; p < H * W; p += 256) {
+    const int h = p / W, w = p - h * W;
+    const float Y = lin01(h, H), X = lin01(w, W);
+    const Tap ty = make_tap(box_coord(Y, y0, y1), M, ac), tx = make_tap(box_coord(X, x0, x1), M, ac);
+    // taps with zero weight because they are outside the mask contribute nothing to the derivative either (zeros padding)
+    const float m00 = mask_at<I64>(masks, o, M, ty.i0, tx.i0), m01 = mask_at<I64>(masks, o, M, ty.i0, tx.i1);
+    const float m10 = mask_at<I64>(masks, o, M, ty.i1, tx.i0), m11 = mask_at<I64>(masks, o, M, ty.i1, tx.i1);
+    const float px = tap_coord(box_coord(X, x0, x1), M, ac), py = tap_coord(box_coord(Y, y0, y1), M, ac);
+    const bool fin = fabsf(px) < 1e8f && fabsf(py) < 1e8f;
+    const float flx = floorf(px), fly = floorf(py);
+    // in-range indicators of the four taps (grid_sample's zeros padding: an out-of-range corner contributes nothing)
+    const float ix0 = (flx >= 0.f && flx < (float)M) ? 1.f : 0.f, ix1 = (flx + 1.f >= 0.f && flx + 1.f < (float)M) ? 1.f : 0.f;
+    const float iy0 = (fly >= 0.f && fly < (float)M) ? 1.f : 0.f, iy1 = (fly + 1.f >= 0.f && fly + 1.f < (float)M) ? 1.f : 0.f;
+    const float dSdx = ((m01 * ix1 - m00 * ix0) * ty.w0 + (m11 * ix1 - m10 * ix0) * ty.w1);
+    const float dSdy = ((m10 * iy1 - m00 * iy0) * tx.w0 + (m11 * iy1 - m01 * iy0) * tx.w1);
+    const float tv = fin ? t[p] : 0.f;
+    const float cx = tv * dSdx * scale * 2.f / (dx * dx), cy = tv * dSdy * scale * 2.f / (dy * dy);
+    g0 += cx * (X - x1); g2 += -cx * (X - x0);
+    g1 += cy * (Y - y1); g3 += -cy * (Y - y0);
+  }
+  g0 = sg_block_sum(g0, red); g1 = sg_block_sum(g1, red); g2 = sg_block_sum(g2, red); g3 = sg_block_sum(g3, red);
+  if (threadIdx.x == 0) { gb[o * 4 + 0] = g0; gb[o * 4 + 1] = g1; gb[o * 4 + 2] = g2; gb[o * 4 + 3] = g3; }
+}
+
+}  // namespace
+
+extern "C" size_t sg_masks_to_layout_bwd_geom_ws_bytes(int O, int H, int W) { return (size_t)(O > 0 ? O : 1) * H * W * sizeof(float); }
+
+extern "C" int sg_masks_to_layout_bwd_geom(const float* gout, const float* vecs, const float* boxes, const void* masks, int masks_i64,
+                                           const int64_t* obj_to_img, const int32_t* seg_off, float* g_masks, float* g_boxes,
+                                           void* ws, size_t ws_bytes, int N, int O, int D, int M, int H, int W, int avg,
+                                           sgStream stream) {
+  SG_ARG_CHECK(gout && vecs && boxes && masks && obj_to_img && seg_off && ws && (g_masks || g_boxes) && N > 0 && O > 0 && D > 0,
+               "sg_masks_to_layout_bwd_geom: bad arguments");
+  SG_ARG_CHECK(ws_bytes >= sg_masks_to_layout_bwd_geom_ws_bytes(O, H, W), "sg_masks_to_layout_bwd_geom: workspace too small");
+  SG_ARG_CHECK(!(g_masks && masks_i64), "sg_masks_to_layout_bwd_geom: integer masks have no gradient");
+  hipStream_t s = (hipStream_t)stream;
+  float* T = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(layout_objmap_kernel, dim3(sg_cdiv(H * W, 256), O), dim3(256), 0, s, gout, vecs, obj_to_img, seg_off, T, D, H * W, avg);
+  if (g_masks)
+    hipLaunchKernelGGL(layout_bwd_masks_kernel, dim3(sg_cdiv(M * M, 256), O), dim3(256), 0, s, (const float*)T, boxes, g_masks, M, H, W,
+                       g_align_corners);
+  if (g_boxes) {
+    if (masks_i64) hipLaunchKernelGGL(layout_bwd_boxes_kernel<true>, dim3(O), dim3(256), 0, s, (const float*)T, boxes, masks, g_boxes, M, H, W, g_align_corners);
+    else hipLaunchKernelGGL(layout_bwd_boxes_kernel<false>, dim3(O), dim3(256), 0, s, (const float*)T, boxes, masks, g_boxes, M, H, W, g_align_corners);
+  }
+  SG_LAUNCH_CHECK("sg_masks_to_layout_bwd_geom");
+  return 0;
+}

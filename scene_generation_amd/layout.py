@@ -45,7 +45,7 @@ def masks_to_layout(vecs, boxes, masks, obj_to_img, H, W=None, pooling='sum', te
     if test_mode:      # layout.py:87-92,157-169: front-to-back compositing in ascending-mass order, on the device
         return ops.masks_to_layout_test(vecs, boxes, masks, seg, N, H, W, pooling == 'avg')
     out = ops.MasksToLayoutFn.apply(vecs, boxes, masks, seg, N, H, W, pooling == 'avg', int(grad_from_channel),
-                                    int(max_per_image))
+                                    int(max_per_image), obj_to_img)
     if grad_from_channel > 0:
         # backward only reads d out[:, grad_from_channel:]; consumers (the generator's first conv) may skip the rest
         ops.set_hints(out, grad_from=int(grad_from_channel))

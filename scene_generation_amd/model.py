@@ -115,7 +115,7 @@ class Model(nn.Module):
                 return masks_to_layout(vecs, boxes_gt, masks, obj_to_img, H, W, test_mode=False,
                                        grad_from_channel=self.num_objs, **kw)
         gt_layout = layout_of(scene_layout_vecs, masks_gt)
-        # pred_layout feeds no loss (train.py:203,219); back-propagating through its masks raises loudly
+        # pred_layout feeds no loss (train.py:203,219); it stays differentiable w.r.t. masks_pred like the reference's
         pred_layout = layout_of(scene_layout_vecs, masks_pred)
         wrong_layout = layout_of(wrong_layout_vecs, masks_gt)
         dev = gt_layout.device

@@ -997,10 +997,10 @@ def segment_offsets(obj_to_img, N):
 
 
 class MasksToLayoutFn(Function):
-    """masks_to_layout (layout.py:64-93) train branch; gradient w.r.t. vecs (columns >= grad_from)."""
+    """masks_to_layout (layout.py:64-93) train branch; gradients w.r.t. vecs (columns >= grad_from), float masks, boxes."""
 
     @staticmethod
-    def forward(ctx, vecs, boxes, masks, seg_off, N, H, W, avg, grad_from, max_per_image):
+    def forward(ctx, vecs, boxes, masks, seg_off, N, H, W, avg, grad_from, max_per_image, obj_to_img=None):
         vecs, boxes = _f32(vecs, 'vecs'), _f32(boxes, 'boxes')
         _dev(masks, 'masks')
         if masks.dtype == torch.int64:
@@ -1016,24 +1016,32 @@ class MasksToLayoutFn(Function):
         _call('sg_masks_to_layout_fwd', _p(vecs), _p(boxes), _p(masks), i64, _p(seg_off), _p(out), N, O, D, M, H, W,
               1 if avg else 0, max_per_image, _stream())
         ctx.cfg = (N, O, D, M, H, W, avg, grad_from, i64)
-        ctx.save_for_backward(boxes, masks, seg_off)
+        geom = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        ctx.save_for_backward(boxes, masks, seg_off, vecs if geom else None, obj_to_img if geom else None)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        boxes, masks, seg_off = ctx.saved_tensors
+        boxes, masks, seg_off, vecs, obj_to_img = ctx.saved_tensors
         N, O, D, M, H, W, avg, grad_from, i64 = ctx.cfg
-        gv = None
+        gv = gb = gm = None
+        gout = _f32(gout)
         if ctx.needs_input_grad[0]:
-            gout = _f32(gout)
             gv = torch.empty(O, D, dtype=torch.float32, device=gout.device)
             _call('sg_masks_to_layout_bwd_vecs', _p(gout), _p(boxes), _p(masks), i64, None, _p(seg_off), _p(gv), N, O, D, M,
                   H, W, 1 if avg else 0, grad_from, _stream())
-        if ctx.needs_input_grad[2]:
-            raise NotImplementedError(
-                'masks_to_layout: gradient w.r.t. masks is not implemented (no loss of the training step consumes '
-                'pred_layout: model.py:120, train.py:203,219); detach the masks or do not backprop through this layout')
-        return gv, None, None, None, None, None, None, None, None, None
+        want_b, want_m = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if want_b or want_m:
+            if obj_to_img is None:
+                raise RuntimeError('masks_to_layout: gradients w.r.t. boxes / masks need obj_to_img (pass it to the Function)')
+            if want_m and i64:
+                raise RuntimeError('masks_to_layout: integer masks have no gradient')
+            gm = torch.empty(O, M, M, dtype=torch.float32, device=gout.device) if want_m else None
+            gb = torch.empty(O, 4, dtype=torch.float32, device=gout.device) if want_b else None
+            wsb = _L().sg_masks_to_layout_bwd_geom_ws_bytes(O, H, W)
+            _call('sg_masks_to_layout_bwd_geom', _p(gout), _p(vecs), _p(boxes), _p(masks), i64, _p(_i64(obj_to_img)), _p(seg_off),
+                  _p(gm), _p(gb), _p(workspace(wsb, gout.device)), wsb, N, O, D, M, H, W, 1 if avg else 0, _stream())
+        return gv, gb, gm, None, None, None, None, None, None, None, None
 
 
 def masks_to_layout_deferred(vecs, boxes, masks, seg_off, N, H, W, avg, max_per_image, differentiable=False):
@@ -1085,7 +1093,7 @@ def layout_planes(boxes, masks, seg_off, plane_idx, N, J, H, W):
     masks_to_layout with the vectors one_hot(plane index of o): the same fused kernel, D = J channels."""
     with torch.no_grad():
         sel = one_hot(plane_idx, J)
-        return MasksToLayoutFn.apply(sel, boxes.detach(), masks.detach(), seg_off, N, H, W, False, 0, J)
+        return MasksToLayoutFn.apply(sel, boxes.detach(), masks.detach(), seg_off, N, H, W, False, 0, J, None)
 
 
 class FactoredLayout(object):

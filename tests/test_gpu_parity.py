@@ -1372,3 +1372,32 @@ def test_legacy_align_corners_switch(hip, golden):
         scene_generation_amd.set_legacy_align_corners(False)
     out = masks_to_layout(d('vecs'), d('boxes'), d('masks'), d('obj_to_img'), 16)
     assert float((out.cpu() - torch.from_numpy(g['out'])).abs().max()) > 1e-3      # the default geometry is back
+
+
+@pytest.mark.parametrize('pooling', ['sum', 'avg'])
+def test_masks_to_layout_gradients_wrt_masks_and_boxes(hip, pooling):
+    """layout.py:85-86 is differentiable in vecs, masks AND boxes: all three gradients vs the oracle's autograd (float masks,
+    boxes partly outside the image, a box that up-samples its mask strongly)."""
+    from scene_generation_amd.layout import masks_to_layout
+    g = torch.Generator().manual_seed(17)
+    counts = [3, 1, 4]
+    Oc = sum(counts)
+    o2i = torch.cat([torch.full((c,), i, dtype=torch.long) for i, c in enumerate(counts)])
+    vecs = det((Oc, 9), 401)
+    x0, y0 = torch.rand(Oc, generator=g) * 0.5, torch.rand(Oc, generator=g) * 0.5
+    boxes = torch.stack([x0, y0, x0 + 0.12 + 0.4 * torch.rand(Oc, generator=g), y0 + 0.12 + 0.4 * torch.rand(Oc, generator=g)], 1)
+    boxes[1] = torch.tensor([-0.15, 0.3, 0.45, 1.2])
+    boxes[2] = torch.tensor([0.05, 0.05, 0.95, 0.9])
+    masks = torch.rand(Oc, 16, 16, generator=g)
+    H, W = 24, 28
+    vr, br, mr = [t.clone().requires_grad_() for t in (vecs, boxes, masks)]
+    ref = O.masks_to_layout(vr, br, mr, o2i, H, W, pooling=pooling)
+    wgt = det(tuple(ref.shape), 402)
+    (ref * wgt).sum().backward()
+    vg, bg, mg = [t.to(DEV).requires_grad_() for t in (vecs, boxes, masks)]
+    out = masks_to_layout(vg, bg, mg, o2i.to(DEV), H, W, pooling=pooling)
+    (out * wgt.to(DEV)).sum().backward()
+    close(out, ref, 1e-5, 'layout')
+    close(vg.grad, vr.grad, 2e-5, 'd/dvecs')
+    close(mg.grad, mr.grad, 2e-5, 'd/dmasks')
+    close(bg.grad, br.grad, 1e-4, 'd/dboxes')
