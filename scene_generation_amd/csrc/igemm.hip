@@ -2085,6 +2085,59 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
   }
 }
 
+// LDS-staged form for R, Cc multiples of 32: a workgroup owns a 32x32 block of (r, c), reads its 32 source rows of 32*9
+// contiguous floats coalesced (for the transposed modes those rows are w[c][r0..r0+31]: the per-thread form above reads them
+// with a lane stride of R*36 bytes) and writes U with c contiguous.  Same arithmetic, same results.
+constexpr int WW_PITCH = 32 * 9 + 1;
+__global__ void __launch_bounds__(256) wino_weight_lds_kernel(const float* __restrict__ w, float* __restrict__ U, int R, int Cc,
+                                                              int flip) {
+  __shared__ float S[32 * WW_PITCH];
+  const int cb = blockIdx.x % (Cc / 32), rb = blockIdx.x / (Cc / 32);
+  const int r0 = rb * 32, c0 = cb * 32, t = threadIdx.x;
+  // source row j: flip == 0 -> (r0 + j, c0 ..), else (c0 + j, r0 ..) of the [Cc][R] tensor
+  // (rows start at multiples of 288 floats: 16-byte aligned whenever w is)
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int idx = i * 256 + t, j = idx / 72, o = (idx - j * 72) * 4;
+    const size_t src = flip ? ((size_t)(c0 + j) * R + r0) * 9 + o : ((size_t)(r0 + j) * Cc + c0) * 9 + o;
+    const float4 v = *reinterpret_cast<const float4*>(w + src);
+    float* d = S + j * WW_PITCH + o;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  const size_t RC = (size_t)R * Cc;
+  const int cl = t & 31;
+  const bool rot = flip == 1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rl = (t >> 5) + 8 * q;
+    const float* g = flip ? S + cl * WW_PITCH + rl * 9 : S + rl * WW_PITCH + cl * 9;
+    float tt[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float g0 = rot ? g[8 - j] : g[j], g1 = rot ? g[5 - j] : g[3 + j], g2 = rot ? g[2 - j] : g[6 + j];
+      tt[0][j] = g0; tt[1][j] = 0.5f * (g0 + g1 + g2); tt[2][j] = 0.5f * (g0 - g1 + g2); tt[3][j] = g2;
+    }
+    const size_t i = (size_t)(r0 + rl) * Cc + c0 + cl;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float u[4] = {tt[a][0], 0.5f * (tt[a][0] + tt[a][1] + tt[a][2]), 0.5f * (tt[a][0] - tt[a][1] + tt[a][2]), tt[a][2]};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) U[(size_t)(a * 4 + b) * RC + i] = u[b];
+    }
+  }
+}
+
+// one entry for the three call sites (SG_WINO_WT=0 keeps the per-thread kernel)
+inline void wino_weight(const float* w, float* U, int R, int Cc, int flip, hipStream_t s) {
+  static int lds = -1;
+  if (lds < 0) { const char* e = getenv("SG_WINO_WT"); lds = e ? atoi(e) : 1; }
+  if (lds && R % 32 == 0 && Cc % 32 == 0 && aligned16(w))
+    hipLaunchKernelGGL(wino_weight_lds_kernel, dim3((R / 32) * (Cc / 32)), dim3(256), 0, s, w, U, R, Cc, flip);
+  else
+    hipLaunchKernelGGL(wino_weight_kernel, dim3(sg_cdiv((size_t)R * Cc, 256)), dim3(256), 0, s, w, U, R, Cc, flip);
+}
+
 // y[n][m][2ti+a][2tj+b] = act((A^T Mx A)[a][b] + bias[m]),  Mx[m][xi*Pstride + p]
 __global__ void wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias, float* __restrict__ y, int N,
                                    int M, int H, int W, size_t Pstride, int act, float slope) {
@@ -2352,7 +2405,7 @@ extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const 
     float* Ytp = UT + 16 * (size_t)M * K;           // [16][P][Cout]
     float* G = Ytp + 16 * P * K;                    // [P][16][C1]
     { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0);
-      hipLaunchKernelGGL(wino_weight_kernel, dim3(sg_cdiv((size_t)M * K, 256)), dim3(256), 0, s, w, UT, M, K, 2); }
+      wino_weight(w, UT, M, K, 2, s); }
     { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0);
       const size_t lds = (size_t)64 * (HW + 1) * sizeof(float);
       if (lds > 48 * 1024)
@@ -2374,7 +2427,7 @@ extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const 
   float* V = U + 16 * (size_t)M * K;                // [16][Pd][Cout]
   float* Mx = V + 16 * Pd * K;                      // [C1][16][Pd]
   float* gpad = Mx + 16 * Pd * M;                   // [N][C1][LH+2][LW+2] (reflect) / [N][C1][LH][LW] (upsample)
-  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_weight_kernel, dim3(sg_cdiv((size_t)M * K, 256)), dim3(256), 0, s, w, U, M, K, 1); }
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); wino_weight(w, U, M, K, 1, s); }
   wino_input_pc(gy, V, d->N, K, LH, LW, TH, TW, refl ? -2 : -1, 1, Pd, 0, s);
   wino_bgemm(U, V, Mx, M, (int)Pd, K, 2.0 * M * (double)K * 16.0 * ((double)d->N * TH * TW), s);   // flops of the real tiles
   const bool direct = !refl && d->upsample == 1;
@@ -2396,7 +2449,7 @@ extern "C" int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const flo
   float* U = reinterpret_cast<float*>(ws);
   float* V = U + 16 * (size_t)M * C;
   float* Mx = V + 16 * P * C;
-  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_weight_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, w, U, M, C, 0); }
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); wino_weight(w, U, M, C, 0, s); }
   wino_input_pc(x, V, d->N, C, LH, LW, LH / 2, LW / 2, -1, d->pad_reflect ? 0 : 1, P, d->upsample == 2 ? 1 : 0, s);
   wino_bgemm(U, V, Mx, M, (int)P, C, 2.0 * M * (double)C * 16.0 * P, s);
   { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_output_kernel, dim3(sg_cdiv(P * M, 256)), dim3(256), 0, s, (const float*)Mx, bias, y, d->N, M, LH, LW, P,
@@ -2442,6 +2495,14 @@ namespace {
 template <class A64, class B64, class A32, class B128>
 int run_dense(const A64& a64, const B64& b64, const A32& a32, const B128& b128, const EpRowMajor& ep, int M, int N,
               int K, hipStream_t s) {
+  // these GEMMs are a chain of K/16 dependent load -> LDS -> MFMA rounds on a grid that does not even fill the chip
+  // (graph-conv MLPs: ~150 workgroups): 32-deep k-tiles halve the number of rounds.  SG_LINEAR_NSUB=1 restores depth 16.
+  static int deep = -1;
+  if (deep < 0) { const char* e = getenv("SG_LINEAR_NSUB"); deep = e ? atoi(e) : 2; }
+  if (deep == 2 && K >= 64) {
+    if (M <= 32) return launch_cfg<TileCfg<32, 128, 1, 2>>(a32, b128, ep, M, N, K, 1, s);
+    return launch_cfg<TileCfg<64, 64, 2, 2>>(a64, b64, ep, M, N, K, 1, s);
+  }
   if (M <= 32) return launch_cfg<Cfg32>(a32, b128, ep, M, N, K, 1, s);
   return launch_cfg<Cfg64>(a64, b64, ep, M, N, K, 1, s);
 }

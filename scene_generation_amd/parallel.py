@@ -9,6 +9,10 @@ are "the reference run independently on each shard, gradients averaged" (SURVEY 
 decides which parameters receive gradients, so it is drawn once per step on rank 0 and broadcast (Trainer.draw_use_gt);
 as a second line of defence the reducer ORs the optimisers' "received a gradient" flags across ranks.
 
+Two planes: gradients travel over RCCL on the device; the tiny per-step AGREEMENT values (the coin, the flags) travel over
+a gloo control group on the host (``control_group()``), so that agreeing never drains the GPU queue -- the host runs
+~40 ms ahead of the device on this step and a blocking host-side exchange costs nothing, a ``.item()`` would cost a bubble.
+
 xGMI note: collectives are per-link bound (7 links x ~153 GB/s), so buckets are LARGE (default 64 MB): a few big
 reduce-scatter/all-gather rings amortise the per-collective latency; the 764.7 MB generator gradient is ~12 buckets.
 """
@@ -16,6 +20,49 @@ import os
 
 import torch
 import torch.distributed as dist
+
+
+_CTRL = {'group': None, 'tried': False}
+
+
+def control_group():
+    """Host-side (gloo) group for the per-step agreement values, or None (then they go through the default group on the
+    device and cost one synchronisation each).  Collective: the first call must happen on every rank (init_distributed)."""
+    if not _CTRL['tried']:
+        _CTRL['tried'] = True
+        if dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() != 'gloo' \
+                and os.environ.get('SG_CTRL_GLOO', '1') != '0':
+            try:
+                _CTRL['group'] = dist.new_group(backend='gloo')
+            except Exception as e:                       # no usable interface: fall back to the device path
+                print('scene_generation_amd.parallel: no gloo control group (%s); agreement values use the device group' % e)
+                _CTRL['group'] = None
+    return _CTRL['group']
+
+
+def agree(values, op, device):
+    """All-reduce a short list of numbers across ranks (op: dist.ReduceOp.MAX / SUM) and return them as Python floats.
+    Host-side over the control group when there is one (no GPU synchronisation), else over the default group."""
+    g = control_group()
+    if g is not None or dist.get_backend() == 'gloo':
+        t = torch.tensor(values, dtype=torch.float32)
+        dist.all_reduce(t, op=op, group=g)
+        return t.tolist()
+    t = torch.tensor(values, dtype=torch.float32, device=device)
+    dist.all_reduce(t, op=op)
+    return t.tolist()
+
+
+def broadcast_int(value, device, src=0):
+    """rank ``src``'s integer on every rank (host-side when the control group exists)"""
+    g = control_group()
+    if g is not None or dist.get_backend() == 'gloo':
+        t = torch.tensor([int(value)], dtype=torch.int64)
+        dist.broadcast(t, src=src, group=g)
+        return int(t.item())
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.broadcast(t, src=src)
+    return int(t.item())
 
 
 def init_distributed(backend=None):
@@ -31,6 +78,7 @@ def init_distributed(backend=None):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    control_group()
     return rank, world
 
 
@@ -41,9 +89,11 @@ class GradReducer:
     last-layer-first).  The reducer is ARMED by the owning optimiser's ``zero_grad()`` (``begin_step``) and disarmed by
     ``wait()``: gradient hooks that fire outside that window -- e.g. a discriminator parameter touched by the
     generator's backward -- are ignored, and a parameter counts once per step no matter how often its hook fires
-    (per-parameter ready flags, not a counter).  When the last parameter of a bucket has reported, the bucket's async
-    all-reduce is issued immediately; ``wait()`` (called before optimizer.step) launches the remaining buckets IN
-    BUCKET ORDER (identical on every rank, whatever subset of parameters each rank touched), waits, and scales by
+    (per-parameter ready flags, not a counter).  Buckets are launched strictly IN BUCKET ORDER: bucket b's async
+    all-reduce is issued as soon as every parameter of buckets 0..b has reported, so the sequence of collectives is the
+    same on every rank whatever order (or subset) the hooks fire in.  ``flush()`` issues the rest without waiting (the
+    Trainer calls it after the generator's backward and lets the reduce run under the discriminator steps);
+    ``wait()`` (called before optimizer.step) flushes, makes the current stream wait for the collectives, and scales by
     1/world.  Parameters that received no gradient this step still hold zeros, which is what the all-reduce must see.
 
     ``touched`` (optional, a callable returning / accepting the optimiser's per-parameter "received a gradient" flags):
@@ -86,6 +136,7 @@ class GradReducer:
         self._ready = [False] * len(self.fp.params)
         self._pending = [len(idxs) for _, _, idxs in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._next = 0               # buckets [0, _next) have been launched
         self._works = []
 
     def begin_step(self):
@@ -103,33 +154,43 @@ class GradReducer:
         if not (self.active and self.armed and self.world > 1 and self.overlap) or self._ready[i]:
             return
         self._ready[i] = True
-        b = self.bucket_of[i]
-        self._pending[b] -= 1
-        if self._pending[b] == 0 and not self._launched[b]:
-            self._launch(b)
+        self._pending[self.bucket_of[i]] -= 1
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch(self._next)
 
     def _launch(self, b):
+        assert b == self._next
         s, e, _ = self.buckets[b]
         self._launched[b] = True
+        self._next = b + 1
         self._works.append(dist.all_reduce(self.fp.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def flush(self):
+        """Issue the all-reduce of every bucket not launched yet (the backward is over); does not wait."""
+        if self.world > 1 and self.active and self.armed:
+            while self._next < len(self.buckets):
+                self._launch(self._next)
 
     def wait(self):
         """Complete the mean all-reduce of every bucket; disarms the reducer until the next begin_step()."""
         if self.world > 1 and self.active:
-            for b in range(len(self.buckets)):          # fixed order: the same sequence of collectives on every rank
-                if not self._launched[b]:
-                    self._launch(b)
+            while self._next < len(self.buckets):        # (also when nobody armed the reducer: hooks were ignored)
+                self._launch(self._next)
             for w in self._works:
                 w.wait()
             self.fp.grad.mul_(1.0 / self.world)
             opt = self.optimizer
             if opt is not None:                          # every rank must update the same parameters
-                flags = torch.tensor([1.0 if t else 0.0 for t in opt._touched], dtype=torch.float32,
-                                     device=self.fp.grad.device)
-                dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
-                opt._touched = [bool(v) for v in flags.tolist()]
+                flags = agree([1.0 if t else 0.0 for t in opt._touched], dist.ReduceOp.MAX, self.fp.grad.device) \
+                    if self.group is None else self._agree_in_group(opt._touched)
+                opt._touched = [bool(v) for v in flags]
         self.armed = False
         self._reset()
+
+    def _agree_in_group(self, touched):
+        flags = torch.tensor([1.0 if t else 0.0 for t in touched], dtype=torch.float32, device=self.fp.grad.device)
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+        return flags.tolist()
 
 
 def broadcast_params(flat_params, src=0, group=None):

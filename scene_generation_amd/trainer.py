@@ -306,7 +306,14 @@ class Trainer:
             L.set_value('total_loss', L.total_loss)
             self.optimizer.zero_grad()
             L.total_loss.backward(retain_graph=bool(shared))
-        self.optimizer.step()
+        if getattr(self, '_defer_g_step', False):
+            # data parallel, inside Trainer.step: start the all-reduce of the generator gradients now and take the Adam step
+            # after the discriminator steps (which read no generator parameter): the collective runs under them
+            for r in self.reducers:
+                if r.optimizer is self.optimizer:
+                    r.flush()
+        else:
+            self.optimizer.step()
 
     def train_obj_discriminator(self, imgs, imgs_pred, objs, boxes, boxes_pred, obj_to_img):
         if self.obj_discriminator is not None:
@@ -377,9 +384,8 @@ class Trainer:
         import random as _random
         coin = (rng or _random).randint(0, 1)
         if self.distributed and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            t = torch.tensor([coin], dtype=torch.int64, device=self.device)
-            torch.distributed.broadcast(t, src=0)
-            coin = int(t.item())
+            from .parallel import broadcast_int
+            coin = broadcast_int(coin, self.device)      # host-side (gloo control group): no GPU synchronisation
         return coin != 0
 
     def step(self, batch, use_gt=True):
@@ -396,10 +402,19 @@ class Trainer:
         finally:
             self.model.lazy_layouts = False
         imgs_pred, boxes_pred, masks_pred, layout, layout_pred, layout_wrong = model_out
-        self.train_generator(imgs, imgs_pred, masks, masks_pred, layout, objs, boxes, boxes_pred, obj_to_img, use_gt)
-        self.train_mask_discriminator(masks, masks_pred.detach(), objs)
-        self.train_obj_discriminator(imgs, imgs_pred.detach(), objs, boxes, boxes.detach(), obj_to_img)
-        self.train_image_discriminator(imgs, imgs_pred.detach(), layout.detach(), layout_wrong.detach())
+        # Under data parallelism the generator's Adam step moves behind the discriminator steps (they consume only tensors
+        # computed above and no generator parameter, so the result is the same): its 765 MB gradient all-reduce then overlaps
+        # their compute instead of stalling the stream.  (train.py's own loop calls the four functions itself: unchanged.)
+        self._defer_g_step = bool(self.reducers) and getattr(self, 'overlap_g_reduce', True)
+        try:
+            self.train_generator(imgs, imgs_pred, masks, masks_pred, layout, objs, boxes, boxes_pred, obj_to_img, use_gt)
+            self.train_mask_discriminator(masks, masks_pred.detach(), objs)
+            self.train_obj_discriminator(imgs, imgs_pred.detach(), objs, boxes, boxes.detach(), obj_to_img)
+            self.train_image_discriminator(imgs, imgs_pred.detach(), layout.detach(), layout_wrong.detach())
+            if self._defer_g_step:
+                self.optimizer.step()
+        finally:
+            self._defer_g_step = False
         if getattr(self, 'dense_layout_outputs', True):
             for lay in (layout, layout_pred, layout_wrong):
                 ops.ensure_dense(lay)

@@ -111,3 +111,65 @@ def test_two_rank_gradient_mean_equals_sequential_shards(bucket_bytes):
         assert torch.equal(flat, flat0), 'rank %d: parameters were not broadcast from rank 0' % rank
         assert nb >= (2 if bucket_bytes == 4096 else 1)
     assert torch.equal(res[0][1], res[1][1]), 'ranks must hold identical averaged gradients'
+
+
+def _order_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from scene_generation_amd.optim import FlatParams
+    from scene_generation_amd.parallel import GradReducer, init_distributed, agree, broadcast_int, control_group
+    init_distributed('gloo')
+    assert control_group() is None                     # the default group already lives on the host
+    params = [torch.nn.Parameter(torch.zeros(300 + 17 * i)) for i in range(9)]
+    fp = FlatParams(params)
+    red = GradReducer(fp, bucket_bytes=2048)           # several parameters per bucket, several buckets
+    launched = []
+    orig = red._launch
+    red._launch = lambda b: (launched.append(b), orig(b))[1]
+    g = torch.Generator().manual_seed(11 + rank)
+    for step in range(2):
+        fp.grad.zero_()
+        red.begin_step()
+        del launched[:]
+        order = list(range(len(params))) if rank == 0 else torch.randperm(len(params), generator=g).tolist()
+        skipped = 4 if rank == 1 else None             # rank 1 never reports parameter 4 (it holds zeros there)
+        for i in order:
+            if i == skipped:
+                continue
+            fp.grad_view(i).copy_(torch.full_like(params[i], float(rank + 1) * (i + 1)))
+            red.param_ready(i)
+            assert launched == sorted(launched) == list(range(len(launched))), 'buckets must be launched in bucket order'
+        red.flush()
+        assert launched == list(range(len(red.buckets)))
+        red.flush()                                     # idempotent
+        assert launched == list(range(len(red.buckets)))
+        red.wait()
+        assert not red.armed
+    coin = broadcast_int(7 if rank == 0 else 3, 'cpu')
+    flags = agree([float(rank == 0), 0.0, float(rank == 1)], dist.ReduceOp.MAX, 'cpu')
+    q.put((rank, fp.packed(fp.grad).detach().numpy().copy(), coin, flags, len(red.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_launch_order_is_rank_independent():
+    """Hooks fire in a different order on each rank and one rank never reports a parameter: the sequence of collectives
+    (bucket 0, 1, 2, ...) must still be the same everywhere, flush() must issue the rest without waiting, and the mean
+    must come out right.  Also the host-side agreement helpers (coin broadcast, flag OR)."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_order_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sizes = [300 + 17 * i for i in range(9)]
+    want = torch.cat([torch.full((n,), ((1.0 * (i + 1)) + (0.0 if i == 4 else 2.0 * (i + 1))) / 2) for i, n in enumerate(sizes)])
+    for rank, g, coin, flags, nb in res:
+        assert nb >= 3
+        assert torch.equal(torch.from_numpy(g), want), 'rank %d' % rank
+        assert coin == 7 and flags == [1.0, 0.0, 1.0]
