@@ -22,7 +22,7 @@ from .discriminators import AcCropDiscriminator, define_mask_D, define_D
 from .losses import get_gan_losses, GANLoss, VGGLoss
 from .model import Model
 from .optim import FusedAdam
-from .parallel import GradReducer, broadcast_params
+from .parallel import GradReducer, broadcast_params, broadcast_int, control_group
 from .utils import LossManager, weighted_sum
 
 
@@ -104,6 +104,7 @@ class Trainer:
         self.share_d_forward = True
         self.reducers = []
         if distributed:
+            control_group()                      # collective: create the host-side agreement group on every rank now
             for opt in (self.optimizer, self.optimizer_d_img, self.optimizer_d_obj, self.optimizer_d_mask):
                 if opt is not None:
                     broadcast_params(opt.fp)
@@ -384,7 +385,6 @@ class Trainer:
         import random as _random
         coin = (rng or _random).randint(0, 1)
         if self.distributed and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            from .parallel import broadcast_int
             coin = broadcast_int(coin, self.device)      # host-side (gloo control group): no GPU synchronisation
         return coin != 0
 
