@@ -29,9 +29,9 @@ constexpr int BK = 16;     // sub-tile depth: the unit one loader call stages (1
 // A workgroup k-tile is NSUB sub-tiles deep (BKT = 16*NSUB): all 2*NSUB loader calls of the next tile are issued
 // before the MFMAs of the current one, so NSUB*~8 global loads per thread stay in flight across 8*NSUB*TM*TN
 // MFMAs (the f32 MFMA is 64 cycles: one sub-tile of work per load round trip left the kernel latency-bound).
-template <int BM_, int BN_, int WGM_, int NSUB_>
+template <int BM_, int BN_, int WGM_, int NSUB_, int PIPE_ = 0>
 struct TileCfg {
-  static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = 4 / WGM_, NSUB = NSUB_, BKT = BK * NSUB_;
+  static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = 4 / WGM_, NSUB = NSUB_, BKT = BK * NSUB_, PIPE = PIPE_;
   static constexpr int WM = BM / WGM, WN = BN / WGN;
   static constexpr int TM = WM / 32, TN = WN / 32;
   static constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -99,7 +99,7 @@ struct LoadKContig {
     for (int p = 0; p < PASSES; ++p) {
       const int xl = xr_ + p * 64;
       const int x = x0_ + xl, k = k0 + kq_;
-      const bool xok = xl < BX && x < X;
+      const bool xok = (BX % 64 == 0 || xl < BX) && x < X;     // (xr_ < 64: whole passes need no row check)
       const unsigned row = (unsigned)(xok ? x : 0) * (unsigned)ld;
       if (VEC && !MASK) {                         // full tiles only (X % BX == 0, K % 16 == 0): no validity at all
         const float4 v = *reinterpret_cast<const float4*>(base + (unsigned)x * (unsigned)ld + k);
@@ -131,9 +131,10 @@ struct LoadKContig {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int xl = xr_ + p * 64;
-      if (xl < BX && (SG_BUFLOAD || (VEC && !MASK))) {      // (buffer loads already returned zeros for the masked elements)
+      const bool in_tile = BX % 64 == 0 || xl < BX;          // compile-time true for the 64 / 128-row tiles: no exec-mask branch
+      if (in_tile && (SG_BUFLOAD || (VEC && !MASK))) {      // (buffer loads already returned zeros for the masked elements)
         *reinterpret_cast<float4*>(T + xl * LDK + kq_) = make_float4(st.r[p * 4], st.r[p * 4 + 1], st.r[p * 4 + 2], st.r[p * 4 + 3]);
-      } else if (xl < BX) {
+      } else if (in_tile) {
         float4 v;
         v.x = ((st.ok >> (p * 4 + 0)) & 1u) ? st.r[p * 4 + 0] : 0.f;
         v.y = ((st.ok >> (p * 4 + 1)) & 1u) ? st.r[p * 4 + 1] : 0.f;
@@ -682,6 +683,25 @@ struct LoadTapNK {
 // ------------------------------------------------------------------------------------------------
 // Epilogues.  Accumulator register r of a 32x32 tile <-> row (r&3)+8*(r>>2)+4*(lane>>5), col lane&31.
 // ------------------------------------------------------------------------------------------------
+// Epilogues.  The activation switch and the bounds checks are hoisted OUT of the 16*TM*TN-element store loops: a wave whose
+// 32TM x 32TN block lies inside the matrix (the common case) runs a loop specialised for its activation with unconditional
+// stores; edge blocks and the rare tanh / sigmoid take the general loop.  (With the switch -- tanhf / expf inlined -- and an
+// m < M test per element the epilogue was 40 KB of code per kernel and cost the dense Winograd GEMM 9 % of its run time.)
+template <int ACT> __device__ __forceinline__ float act_fixed(float v, int act, float slope) {
+  if constexpr (ACT == SG_ACT_NONE) return v;
+  else if constexpr (ACT == SG_ACT_RELU) return v > 0.f ? v : 0.f;
+  else if constexpr (ACT == SG_ACT_LEAKY) return v > 0.f ? v : v * slope;
+  else return sg_apply_act(v, act, slope);
+}
+template <int A> struct ActTag { static constexpr int value = A; };
+// f(ActTag<A>) with A = the activation when it is one of the cheap ones and the block is full, else -1 (general loop)
+template <class F> __device__ __forceinline__ void ep_dispatch(bool full, int act, F&& f) {
+  if (full && act == SG_ACT_NONE) f(ActTag<SG_ACT_NONE>{});
+  else if (full && act == SG_ACT_LEAKY) f(ActTag<SG_ACT_LEAKY>{});
+  else if (full && act == SG_ACT_RELU) f(ActTag<SG_ACT_RELU>{});
+  else f(ActTag<-1>{});
+}
+
 struct EpNCHW {     // out[z][img][m][pix], n = img*PHW + pix ; bias per row m (z = split-K slab, raw partials)
   float* out; const float* bias; int PHW, Mtot, M, Npix, act; float slope; size_t zstride;
   // optional scatter of a pixel sub-lattice into the full grid (parity-decomposed strided transposed gathers)
@@ -689,31 +709,48 @@ struct EpNCHW {     // out[z][img][m][pix], n = img*PHW + pix ; bias per row m (
   __device__ __forceinline__ void set_limit(int n) { Npix = n; }
   template <int TM, int TN>
   __device__ __forceinline__ void store(f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int z) const {
+    const bool full = mbase + 32 * TM <= M && nbase + 32 * TN <= Npix;
+    const int mrow = mbase + 4 * (lane >> 5);
+    ep_dispatch(full, act, [&](auto tag) {
+      constexpr int A = decltype(tag)::value;
+      constexpr bool FULL = A >= 0;
+      float bv[TM][16];
+      if (bias) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = nbase + j * 32 + (lane & 31);
-      if (n >= Npix) continue;
-      const int img = n / PHW;
-      int pix = n - img * PHW, plane = PHW;
-      if (step > 1) {
-        const int i = pix / PWs;
-        pix = (i * step + h0) * PWf + (pix - i * PWs) * step + w0;
-        plane = PHWf;
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mrow + i * 32 + (r & 3) + 8 * (r >> 2);
+            bv[i][r] = (FULL || m < M) ? bias[m] : 0.f;
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) bv[i][r] = 0.f;
       }
-      float* o = out + (size_t)z * zstride + (size_t)img * Mtot * plane + pix;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+      for (int j = 0; j < TN; ++j) {
+        const int n = nbase + j * 32 + (lane & 31);
+        if (!FULL && n >= Npix) continue;
+        const int img = n / PHW;
+        int pix = n - img * PHW, plane = PHW;
+        if (step > 1) {
+          const int i = pix / PWs;
+          pix = (i * step + h0) * PWf + (pix - i * PWs) * step + w0;
+          plane = PHWf;
+        }
+        float* o = out + (size_t)z * zstride + ((size_t)img * Mtot + mrow) * plane + pix;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (m < M) {
-            float v = acc[i][j][r];
-            if (bias) v += bias[m];
-            o[(size_t)m * plane] = sg_apply_act(v, act, slope);
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
+            if (FULL || mrow + dm < M) o[(size_t)dm * plane] = act_fixed<A>(acc[i][j][r] + bv[i][r], act, slope);
           }
         }
       }
-    }
+    });
   }
 };
 
@@ -722,21 +759,41 @@ struct EpRowMajor {  // out[z][m*ldc + n] ; bias per column n
   __device__ __forceinline__ void set_limit(int) {}
   template <int TM, int TN>
   __device__ __forceinline__ void store(f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int z) const {
-    float* o = out + (size_t)z * zstride;
+    const bool full = mbase + 32 * TM <= M && nbase + 32 * TN <= N;
+    const int mrow = mbase + 4 * (lane >> 5), n0 = nbase + (lane & 31);
+    float* o = out + (size_t)z * zstride + (size_t)mrow * ldc + n0;
+    ep_dispatch(full, act, [&](auto tag) {
+      constexpr int A = decltype(tag)::value;
+      constexpr bool FULL = A >= 0;
+      float b[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = nbase + j * 32 + (lane & 31);
-      if (n >= N) continue;
-      const float b = bias ? bias[n] : 0.f;
+      for (int j = 0; j < TN; ++j) b[j] = (bias && (FULL || n0 + j * 32 < N)) ? bias[n0 + j * 32] : 0.f;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (m < M) o[(size_t)m * ldc + n] = sg_apply_act(acc[i][j][r] + b, act, slope);
+          const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
+          if (!FULL && mrow + dm >= M) continue;
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            if (FULL || n0 + j * 32 < N) o[(size_t)dm * ldc + j * 32] = act_fixed<A>(acc[i][j][r] + b[j], act, slope);
         }
-      }
-    }
+    });
+  }
+};
+
+struct EpRowMajorPlain {  // out[m*ldc + n], full tiles, no bias / activation: 64 unconditional coalesced stores per lane
+  float* out; int ldc;
+  __device__ __forceinline__ void set_limit(int) {}
+  template <int TM, int TN>
+  __device__ __forceinline__ void store(f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int) const {
+    float* o = out + (size_t)(mbase + 4 * (lane >> 5)) * ldc + nbase + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) o[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc + j * 32] = acc[i][j][r];
   }
 };
 
@@ -747,17 +804,26 @@ struct EpWgrad {     // tap-major virtual column n = t*cpad + cj  ->  slab[z][m]
   __device__ __forceinline__ void store(f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int z) const {
     float* o0 = out + (size_t)z * zstride;
     const size_t ldm = (size_t)KS2 * cpad;
+    const int mrow = mbase + 4 * (lane >> 5), n0 = nbase + (lane & 31), Ncols = KS2 * cpad;
+    float* o = o0 + (size_t)mrow * ldm + n0;
+    if (mbase + 32 * TM <= M && nbase + 32 * TN <= Ncols) {          // whole block inside: unconditional stores
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) o[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldm + j * 32] = acc[i][j][r];
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = nbase + j * 32 + (lane & 31);
-      if (n >= KS2 * cpad) continue;
-      float* o = o0 + n;
+      if (n0 + j * 32 >= Ncols) continue;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          if (m < M) o[(size_t)m * ldm] = acc[i][j][r];
+          const int dm = i * 32 + (r & 3) + 8 * (r >> 2);
+          if (mrow + dm < M) o[(size_t)dm * ldm + j * 32] = acc[i][j][r];
         }
       }
     }
@@ -896,6 +962,68 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
 
   const int lr = lane & 31, lk = lane >> 5;
   int buf = 0;
+  if constexpr (CFG::PIPE != 0) {
+    // Software-pipelined form (dense Winograd GEMMs).  A k-tile is 2*NSUB PHASES of 4 MFMA k-steps (one ds_read_b128 per
+    // fragment row, 4*TM*TN MFMAs); the fragments of phase p+1 are read while the MFMAs of phase p issue, the next tile
+    // goes to LDS at the TOP of the iteration (its global loads were issued one iteration earlier) and the single barrier
+    // sits before the LAST phase, whose MFMAs cover the first fragment reads of the next tile.  No LDS read is waited for
+    // right behind a barrier (the plain loop exposes that latency once per sub-tile), the summation order is unchanged.
+    static_assert(AL::LDS_INTS == 0 && BL::LDS_INTS == 0, "PIPE: loaders without LDS tap tables only");
+    constexpr int P = 2 * NSUB;
+    float4 fa[2][TM], fb[2][TN];
+    auto read_frag = [&](int bsel, int p, float4 (&a)[TM], float4 (&b)[TN]) {
+      const int u = p >> 1, h = p & 1;
+      const float* A_ = As[bsel] + u * BM * LDK + (wm0 + lr) * LDK + lk * 8 + h * 4;
+      const float* B_ = Bs[bsel] + u * BN * LDK + (wn0 + lr) * LDK + lk * 8 + h * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const float4*>(A_ + i * 32 * LDK);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const float4*>(B_ + j * 32 * LDK);
+    };
+    auto mma = [&](const float4 (&a)[TM], const float4 (&b)[TN]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const float av = e == 0 ? a[i].x : (e == 1 ? a[i].y : (e == 2 ? a[i].z : a[i].w));
+            const float bv = e == 0 ? b[j].x : (e == 1 ? b[j].y : (e == 2 ? b[j].z : b[j].w));
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+    };
+    // the prologue above stored tile 0 and passed a barrier; stage tile 1 in registers, fetch the first fragments
+    if (kbeg + BKT < kend) {
+#pragma unroll
+      for (int u = 0; u < NSUB; ++u) { al.load(sa[u], kbeg + BKT + u * BK, kend); bl.load(sb[u], kbeg + BKT + u * BK, kend); }
+    }
+    read_frag(0, 0, fa[0], fb[0]);
+    for (int k0 = kbeg; k0 < kend; k0 += BKT) {
+      const bool more1 = k0 + BKT < kend, more2 = k0 + 2 * BKT < kend;
+      if (more1) {
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) { al.store(sa[u], As[buf ^ 1] + u * BM * LDK); bl.store(sb[u], Bs[buf ^ 1] + u * BN * LDK); }
+      }
+      if (more2) {
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) { al.load(sa[u], k0 + 2 * BKT + u * BK, kend); bl.load(sb[u], k0 + 2 * BKT + u * BK, kend); }
+      }
+#pragma unroll
+      for (int p = 0; p < P - 1; ++p) {
+        read_frag(buf, p + 1, fa[(p + 1) & 1], fb[(p + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);          // keep the reads IN FRONT of the MFMAs that cover their latency
+        mma(fa[p & 1], fb[p & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      if (more1) read_frag(buf ^ 1, 0, fa[0], fb[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(fa[(P - 1) & 1], fb[(P - 1) & 1]);
+      buf ^= 1;
+    }
+    ep.store(acc, m0 + wm0, n0 + wn0, lane, bi.xcd_splitk ? zblk : (int)blockIdx.z);
+    return;
+  }
   for (int k0 = kbeg; k0 < kend; k0 += BKT) {
     const bool more = k0 + BKT < kend;
     if (more) {
@@ -968,7 +1096,8 @@ constexpr int NSW = 1;
 using CfgW128 = TileCfg<128, 128, 2, NSW>;
 using CfgW64 = TileCfg<64, 64, 2, NSW>;
 using CfgW32 = TileCfg<32, 128, 1, NSW>;
-using CfgD128 = TileCfg<128, 128, 2, 2>;     // dense Winograd GEMMs
+using CfgD128 = TileCfg<128, 128, 2, 2>;     // dense Winograd GEMMs (plain loop: SG_WINO_TILE=3)
+using CfgDP128 = TileCfg<128, 128, 2, 2, 1>; // ... software-pipelined fragment reads, barrier before the last phase
 using CfgD128x64 = TileCfg<128, 64, 2, 1>;   // experiment (SG_WINO_TILE=1): half-width tiles, 4-5 workgroups per CU
 
 inline int pick_tile(int M, int N) {
@@ -2356,9 +2485,18 @@ void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, in
     else if (wt == 2)
       launch_cfg<Cfg128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M,
                          16 * cols, K, 1, s);
-    else
+    else if (wt == 3)       // the plain loop (before the software-pipelined form)
       launch_cfg<CfgD128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M,
                           16 * cols, K, 1, s);
+    else if (wt == 5)       // the plain loop with the unconditional epilogue
+      launch_cfg<CfgD128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols},
+                          EpRowMajorPlain{Cout, 16 * cols}, M, 16 * cols, K, 1, s);
+    else if (wt == 4)       // pipelined loop, general epilogue
+      launch_cfg<CfgDP128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M,
+                           16 * cols, K, 1, s);
+    else
+      launch_cfg<CfgDP128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols},
+                           EpRowMajorPlain{Cout, 16 * cols}, M, 16 * cols, K, 1, s);
   }
   t_batch = BatchInfo{};
 }
