@@ -29,7 +29,10 @@ constexpr int BK = 16;     // sub-tile depth: the unit one loader call stages (1
 // A workgroup k-tile is NSUB sub-tiles deep (BKT = 16*NSUB): all 2*NSUB loader calls of the next tile are issued
 // before the MFMAs of the current one, so NSUB*~8 global loads per thread stay in flight across 8*NSUB*TM*TN
 // MFMAs (the f32 MFMA is 64 cycles: one sub-tile of work per load round trip left the kernel latency-bound).
-template <int BM_, int BN_, int WGM_, int NSUB_, int PIPE_ = 0>
+#ifndef SG_PIPE_DEFAULT
+#define SG_PIPE_DEFAULT 1      // software-pipelined main loop for every instantiation (0: the plain loop; measured on MI355X:
+#endif                         // 648 -> 660 images/s, every kernel family +1..6 %)
+template <int BM_, int BN_, int WGM_, int NSUB_, int PIPE_ = SG_PIPE_DEFAULT>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = 4 / WGM_, NSUB = NSUB_, BKT = BK * NSUB_, PIPE = PIPE_;
   static constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -968,7 +971,6 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     // goes to LDS at the TOP of the iteration (its global loads were issued one iteration earlier) and the single barrier
     // sits before the LAST phase, whose MFMAs cover the first fragment reads of the next tile.  No LDS read is waited for
     // right behind a barrier (the plain loop exposes that latency once per sub-tile), the summation order is unchanged.
-    static_assert(AL::LDS_INTS == 0 && BL::LDS_INTS == 0, "PIPE: loaders without LDS tap tables only");
     constexpr int P = 2 * NSUB;
     float4 fa[2][TM], fb[2][TN];
     auto read_frag = [&](int bsel, int p, float4 (&a)[TM], float4 (&b)[TN]) {
@@ -992,12 +994,18 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
           }
     };
-    // the prologue above stored tile 0 and passed a barrier; stage tile 1 in registers, fetch the first fragments
+    // the prologue above stored tile 0, fetched the k-split entries of tile 1 (prefetch) and passed a barrier; stage tile 1
+    // in registers, fetch the entries of tile 2 and the first fragments
     if (kbeg + BKT < kend) {
 #pragma unroll
       for (int u = 0; u < NSUB; ++u) { al.load(sa[u], kbeg + BKT + u * BK, kend); bl.load(sb[u], kbeg + BKT + u * BK, kend); }
+#pragma unroll
+      for (int u = 0; u < NSUB; ++u) { al.prefetch(sa[u], kbeg + 2 * BKT + u * BK); bl.prefetch(sb[u], kbeg + 2 * BKT + u * BK); }
     }
     read_frag(0, 0, fa[0], fb[0]);
+    // loaders that keep per-tile tap tables in LDS: the entries prefetch() just wrote are read by load() at the top of the
+    // first iteration (later iterations have the mid-iteration barrier in between)
+    if (AL::LDS_INTS > 0 || BL::LDS_INTS > 0) __syncthreads();
     for (int k0 = kbeg; k0 < kend; k0 += BKT) {
       const bool more1 = k0 + BKT < kend, more2 = k0 + 2 * BKT < kend;
       if (more1) {
@@ -1007,6 +1015,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
       if (more2) {
 #pragma unroll
         for (int u = 0; u < NSUB; ++u) { al.load(sa[u], k0 + 2 * BKT + u * BK, kend); bl.load(sb[u], k0 + 2 * BKT + u * BK, kend); }
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) { al.prefetch(sa[u], k0 + 3 * BKT + u * BK); bl.prefetch(sb[u], k0 + 3 * BKT + u * BK); }
       }
 #pragma unroll
       for (int p = 0; p < P - 1; ++p) {
@@ -1096,7 +1106,7 @@ constexpr int NSW = 1;
 using CfgW128 = TileCfg<128, 128, 2, NSW>;
 using CfgW64 = TileCfg<64, 64, 2, NSW>;
 using CfgW32 = TileCfg<32, 128, 1, NSW>;
-using CfgD128 = TileCfg<128, 128, 2, 2>;     // dense Winograd GEMMs (plain loop: SG_WINO_TILE=3)
+using CfgD128 = TileCfg<128, 128, 2, 2, 0>;   // dense Winograd GEMMs (plain loop: SG_WINO_TILE=3)
 using CfgDP128 = TileCfg<128, 128, 2, 2, 1>; // ... software-pipelined fragment reads, barrier before the last phase
 using CfgD128x64 = TileCfg<128, 64, 2, 1>;   // experiment (SG_WINO_TILE=1): half-width tiles, 4-5 workgroups per CU
 
