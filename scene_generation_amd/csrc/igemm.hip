@@ -1120,10 +1120,13 @@ inline int pick_tile(int M, int N) {
   // workgroups per CU, else 64x64
   const long t128 = (long)sg_cdiv(M, 128) * sg_cdiv(N, 128);
   const bool low_waste = sg_cdiv(M, 128) * 128 * 20 <= M * 23 && N >= 512;
-  if (M >= 96 && low_waste && (M >= 512 || t128 >= 384)) return 0;
+  static int t128_min = -1, wide_min = -1;           // thresholds (tuning aids: SG_T128_MIN, SG_TILE3_MIN; SG_TILE3=0 disables 64x128)
+  if (t128_min < 0) { const char* e = getenv("SG_T128_MIN"); t128_min = e ? atoi(e) : 384; }
+  if (M >= 96 && low_waste && (M >= 512 || t128 >= t128_min)) return 0;
   static int wide = -1;
   if (wide < 0) { const char* e = getenv("SG_TILE3"); wide = e ? atoi(e) : 1; }
-  if (wide && (long)sg_cdiv(M, 64) * sg_cdiv(N, 128) >= 768) return 3;
+  if (wide_min < 0) { const char* e = getenv("SG_TILE3_MIN"); wide_min = e ? atoi(e) : 768; }
+  if (wide && (long)sg_cdiv(M, 64) * sg_cdiv(N, 128) >= wide_min) return 3;
   return 1;
 }
 
@@ -1172,7 +1175,7 @@ __global__ void slab_reduce_nchw_kernel(const float* ws, float* out, size_t n, i
   if (i >= n) return;
   float v = 0.f;
   for (int z = 0; z < S; ++z) v += ws[(size_t)z * n + i];
-  if (bias) v += bias[(i / PHW) % Mtot];
+  if (bias) v += bias[((unsigned)i / (unsigned)PHW) % (unsigned)Mtot];        // (n < 2^31: 32-bit divisions)
   out[i] = sg_apply_act(v, act, slope);
 }
 // float4 form (n % 4 == 0, PHW % 4 == 0: the four lanes of a vector share their channel)
@@ -1185,7 +1188,7 @@ __global__ void slab_reduce_nchw_vec_kernel(const float4* ws, float4* out, size_
     const float4 t = ws[(size_t)z * n4 + i];
     v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
   }
-  const float b = bias ? bias[(i / PHW4) % Mtot] : 0.f;
+  const float b = bias ? bias[((unsigned)i / (unsigned)PHW4) % (unsigned)Mtot] : 0.f;
   v.x = sg_apply_act(v.x + b, act, slope); v.y = sg_apply_act(v.y + b, act, slope);
   v.z = sg_apply_act(v.z + b, act, slope); v.w = sg_apply_act(v.w + b, act, slope);
   out[i] = v;
@@ -1598,17 +1601,31 @@ __global__ void sparse_wgrad_perimage_kernel(const float* slabs, const int* cnt,
 }
 // gw[m][c][t] = sum_z slab[z][m][t][c]: un-permutes the tap-major slabs of the weight-gradient GEMM (the GEMM epilogue
 // writes them coalesced; scattering 4-byte stores at stride KS2*4 from there cost 8x write amplification in HBM)
-__global__ void wgrad_unpermute_reduce_kernel(const float* slabs, float* gw, int M, int C, int KS2, int cpad, int S) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)M * C * KS2) return;
-  const int t = (int)(i % KS2);
-  const int c = (int)((i / KS2) % C);
-  const int m = (int)(i / ((size_t)KS2 * C));
+__global__ void __launch_bounds__(256) wgrad_unpermute_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ gw, int M,
+                                                                     int C, int KS2, int cpad, int S) {
+  // workgroup = (64 channels, one m): the slabs are read with c contiguous (coalesced), summed over z in ascending order,
+  // transposed through LDS and written with (c, t) contiguous.  (One thread per output element read the slabs at a lane stride
+  // of cpad floats and paid three 64-bit divisions per element.)
+  extern __shared__ float ur_lds[];
+  const int pitch = KS2 | 1;                                   // odd pitch: conflict-free transposed writes
+  const int m = blockIdx.y, c0 = blockIdx.x * 64;
+  const int cl = threadIdx.x & 63, tq = threadIdx.x >> 6;
   const size_t zs = (size_t)M * KS2 * cpad;
-  const float* p = slabs + ((size_t)m * KS2 + t) * cpad + c;
-  float v = 0.f;
-  for (int z = 0; z < S; ++z) v += p[(size_t)z * zs];
-  gw[i] = v;
+  if (c0 + cl < C) {
+    for (int t = tq; t < KS2; t += 4) {
+      const float* p = slabs + ((size_t)m * KS2 + t) * cpad + c0 + cl;
+      float v = 0.f;
+      for (int z = 0; z < S; ++z) v += p[(size_t)z * zs];
+      ur_lds[cl * pitch + t] = v;
+    }
+  }
+  __syncthreads();
+  const int nc = min(64, C - c0);
+  float* o = gw + ((size_t)m * C + c0) * KS2;
+  for (int k = threadIdx.x; k < nc * KS2; k += 256) {
+    const int c = k / KS2, t = k - c * KS2;
+    o[k] = ur_lds[c * pitch + t];
+  }
 }
 inline size_t sparse_wgrad_ws(int NB, int M, int C, int L, int KS2) {
   return (size_t)NB * M * (sg_cdiv(L, 128) * 128) * KS2 * sizeof(float) + (size_t)NB * C * sizeof(int);
@@ -1767,8 +1784,8 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
     return 0;
   }
   if (pl.tap)
-    hipLaunchKernelGGL(wgrad_unpermute_reduce_kernel, dim3(sg_cdiv(nout, 256)), dim3(256), 0, s, (const float*)ws, out, M, C,
-                       KS2, pl.cpad, splits);
+    hipLaunchKernelGGL(wgrad_unpermute_reduce_kernel, dim3(sg_cdiv(C, 64), M), dim3(256), (size_t)64 * (KS2 | 1) * sizeof(float), s,
+                       (const float*)ws, out, M, C, KS2, pl.cpad, splits);
   else if (splits > 1)
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(sg_cdiv(mn, 256)), dim3(256), 0, s, (const float*)ws, out, mn, splits);
   return 0;

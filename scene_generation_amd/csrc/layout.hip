@@ -623,6 +623,43 @@ __global__ void factored_weights_bwd_w_kernel(const float* __restrict__ gwimg, c
   gW[i] = s;
 }
 
+// Same sums, same order, with the per-object class id and gwimg slot staged in LDS once per workgroup (the kernel above
+// re-reads objs / img_idx / seg from global memory in a serial, branchy loop over all objects: ~100 us per call).
+__global__ void __launch_bounds__(256) factored_weights_bwd_w_lds_kernel(
+    const float* __restrict__ gwimg, const float* __restrict__ repr, const int64_t* __restrict__ objs,
+    const int32_t* __restrict__ seg, const int64_t* __restrict__ img_idx, float* __restrict__ gW, int N, int O, int M, int L,
+    int KS2, int C, int R, int C2) {
+  extern __shared__ int ws_lds[];
+  int* cls = ws_lds;            // [O] class of object o
+  int* base = ws_lds + O;       // [O] n_o*M*L + j_o
+  for (int o = threadIdx.x; o < O; o += 256) {
+    const int n = (int)img_idx[o];
+    cls[o] = (int)objs[o];
+    base[o] = n * M * L + (o - seg[n]);
+  }
+  __syncthreads();
+  const int Ct = C + R + C2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * Ct * KS2) return;
+  const int t = (int)(i % KS2);
+  const int c = (int)((i / KS2) % Ct);
+  const int m = (int)(i / ((size_t)KS2 * Ct));
+  const int mL = m * L;
+  float s = 0.f;
+  if (c < C) {
+    for (int o = 0; o < O; ++o)
+      if (cls[o] == c) s += gwimg[(size_t)(base[o] + mL) * KS2 + t];
+  } else if (c < C + R) {
+    const float* rp = repr + (c - C);
+#pragma unroll 4
+    for (int o = 0; o < O; ++o) s += rp[(size_t)o * R] * gwimg[(size_t)(base[o] + mL) * KS2 + t];
+  } else {
+    const int e = c - C - R;
+    for (int n = 0; n < N; ++n) s += gwimg[(((size_t)n * M + m) * L + (seg[n + 1] - seg[n]) + e) * KS2 + t];
+  }
+  gW[i] = s;
+}
+
 // grepr[o][d] = sum_{m,t} gwimg[n_o][m][j_o][t] * W[m][C + d][t]: one wave per (o, d)
 __global__ void __launch_bounds__(256) factored_weights_bwd_repr_kernel(const float* __restrict__ gwimg, const float* __restrict__ W,
                                                                        const int32_t* __restrict__ seg,
@@ -664,8 +701,12 @@ extern "C" int sg_factored_weights_bwd(const float* gwimg, const float* w, const
   hipStream_t s = (hipStream_t)stream;
   if (gw) {
     const size_t n = (size_t)M * (C + R + C2) * KS2;
-    hipLaunchKernelGGL(factored_weights_bwd_w_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, s, gwimg, repr, objs, seg_off, img_idx, gw,
-                       N, O, M, L, KS2, C, R, C2);
+    if (O <= 4096 && (size_t)N * M * L < (1u << 30))
+      hipLaunchKernelGGL(factored_weights_bwd_w_lds_kernel, dim3(sg_cdiv(n, 256)), dim3(256), (size_t)O * 2 * sizeof(int), s, gwimg,
+                         repr, objs, seg_off, img_idx, gw, N, O, M, L, KS2, C, R, C2);
+    else
+      hipLaunchKernelGGL(factored_weights_bwd_w_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, s, gwimg, repr, objs, seg_off, img_idx,
+                         gw, N, O, M, L, KS2, C, R, C2);
   }
   if (grepr && R > 0)
     hipLaunchKernelGGL(factored_weights_bwd_repr_kernel, dim3(sg_cdiv((size_t)O * R, 4)), dim3(256), 0, s, gwimg, w, seg_off, img_idx,
