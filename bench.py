@@ -91,9 +91,9 @@ def cpu_baseline(image_size, n_images, n_steps):
 
 # what the profiler kinds are, as template instantiations (include/sg2im_hip.h, csrc/igemm.hip)
 KERNEL_INSTANTIATIONS = {
-    'wino_bgemm_t128': 'igemm_kernel<TileCfg<128,128,2,1>, LoadKContig<128,true,false>, LoadKContig<128,true,false>, EpRowMajor>: '
+    'wino_bgemm_t128': 'igemm_kernel<TileCfg<128,128,2,2,1>, LoadKContig<128,true,false>, LoadKContig<128,true,false>, EpRowMajorPlain>: '
                        'the 16 batched dense GEMMs of a Winograd F(2x2,3x3) conv (ResnetBlock / VGG19 convs), batch-major '
-                       'tile order',
+                       'tile order, 32-deep k-tiles, software-pipelined fragment reads',
     'wino_bgemm_t64': 'igemm_kernel<TileCfg<64,64,2,1>, LoadKContig<64,true,false>, LoadKContig<64,true,false>, EpRowMajor>: '
                       'Winograd GEMMs of the 192-channel mask_net convs',
 }

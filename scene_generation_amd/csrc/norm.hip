@@ -268,9 +268,14 @@ __global__ void __launch_bounds__(256) channel_sum_partial_kernel(const float* _
   const long chunk = (cnt + S - 1) / S;
   const long beg = z * chunk, end = beg + chunk < cnt ? beg + chunk : cnt;
   float s = 0.f;
-  {
+  if (HW >= 256) {
     BnIter it(beg + threadIdx.x, HW);          // (a 64-bit division per element made this kernel compute-bound)
     for (long i = beg + threadIdx.x; i < end; i += 256, it.step(256)) s += g[((size_t)it.n * C + c) * HW + it.p];
+  } else {
+    for (long i = beg + threadIdx.x; i < end; i += 256) {      // cnt < 2^31: 32-bit division
+      const unsigned n = (unsigned)i / (unsigned)HW, p = (unsigned)i - n * (unsigned)HW;
+      s += g[((size_t)n * C + c) * HW + p];
+    }
   }
   s = sg_block_sum(s, red);
   if (threadIdx.x == 0) part[(size_t)c * S + z] = s;
@@ -289,9 +294,9 @@ __global__ void channel_sum_kernel(const float* __restrict__ g, float* __restric
   const int c = blockIdx.x;
   const int cnt = N * HW;
   float s = 0.f;
-  {
-    BnIter it(threadIdx.x, HW);
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x, it.step(blockDim.x)) s += g[((size_t)it.n * C + c) * HW + it.p];
+  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {       // (small tensors: HW is often 1..64, where stepping an (n, p)
+    const int n = i / HW, p = i - n * HW;                      //  pair by 256 costs more than this 32-bit division -- measured)
+    s += g[((size_t)n * C + c) * HW + p];
   }
   s = sg_block_sum(s, red);
   if (threadIdx.x == 0) out[c] = s;

@@ -15,7 +15,7 @@ def short(n):
     n = n.replace('(anonymous namespace)::', '')
     m = re.match(r'void igemm_kernel<(.*)>\(', n)
     if m:
-        return 'igemm<' + re.sub(r'TileCfg<(\d+), (\d+), \d+, \d+>', r'T\1x\2', m.group(1))[:104] + '>'
+        return 'igemm<' + re.sub(r'TileCfg<(\d+), (\d+), \d+, \d+(?:, \d+)?>', r'T\1x\2', m.group(1))[:104] + '>'
     return re.sub(r'\(.*', '', n).replace('void ', '')[:80]
 
 
@@ -54,7 +54,7 @@ def main():
         if a[1] * 2 > 0.005 * sum(x[1] * 2 for x in f.values()):
             print('| %s | %d | %d | %.1f | %.1f | %.1f | %.0f |' % (k[0], k[1], a[0], fe / 1e6, wr / 1e6, us, (fe + wr) / us / 1e3))
     if '--json' in sys.argv:
-        names = {'igemm<T128x128, LoadKContig<128, true, false>, LoadKContig<128, true, false>, EpRowMajor>': 'wino_bgemm_t128'}
+        names = {'igemm<T128x128, LoadKContig<128, true, false>, LoadKContig<128, true, false>, EpRowMajorPlain>': 'wino_bgemm_t128'}
         for kname, kind in names.items():
             if kname in tot:
                 t = tot[kname]
