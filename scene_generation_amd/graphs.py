@@ -21,6 +21,10 @@ from . import ops
 
 ENABLED = os.environ.get('SG_GRAPHS', '1') != '0'
 REPLAYS = [0]                    # hipGraph launches issued by this process
+# Only the capturing thread is policed: a training process has other threads that legitimately touch the runtime while a
+# segment is being captured (the DataLoader's pin-memory thread, RCCL's watchdog), and under the default 'global' mode any of
+# their calls would invalidate the capture.
+CAPTURE_MODE = os.environ.get('SG_GRAPH_CAPTURE_MODE', 'thread_local')
 
 
 def _flat(out):
@@ -124,7 +128,7 @@ class GraphedSegment(object):
         e.static_in = x.detach().clone().requires_grad_(x_grad)
         torch.cuda.synchronize()
         e.fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(e.fwd):
+        with torch.cuda.graph(e.fwd, capture_error_mode=CAPTURE_MODE):
             out = self.fn(e.static_in)
         e.static_out, e.n_out = _flat(out)
         e.static_gin, e.static_gout, e.deliveries, e.bwd = None, [], [], None
@@ -134,7 +138,7 @@ class GraphedSegment(object):
             torch.cuda.synchronize()
             e.bwd = torch.cuda.CUDAGraph()
             with ops.capture_deliveries(1 if self.accumulate else 0) as deliveries:
-                with torch.cuda.graph(e.bwd, pool=e.fwd.pool()):
+                with torch.cuda.graph(e.bwd, pool=e.fwd.pool(), capture_error_mode=CAPTURE_MODE):
                     grads = torch.autograd.grad(e.static_out, inputs, e.static_gout, allow_unused=True, retain_graph=True)
             e.deliveries = list(deliveries)
             e.static_gin = grads[0] if x_grad else None

@@ -28,6 +28,9 @@ _CTRL = {'group': None, 'tried': False}
 def control_group():
     """Host-side (gloo) group for the per-step agreement values, or None (then they go through the default group on the
     device and cost one synchronisation each).  Collective: the first call must happen on every rank (init_distributed)."""
+    if not dist.is_initialized():
+        _CTRL['group'], _CTRL['tried'] = None, False     # (a later init_process_group starts over)
+        return None
     if not _CTRL['tried']:
         _CTRL['tried'] = True
         if dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() != 'gloo' \
