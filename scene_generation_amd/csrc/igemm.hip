@@ -1106,6 +1106,7 @@ constexpr int NSW = 1;
 using CfgW128 = TileCfg<128, 128, 2, NSW>;
 using CfgW64 = TileCfg<64, 64, 2, NSW>;
 using CfgW32 = TileCfg<32, 128, 1, NSW>;
+using CfgW64W = TileCfg<64, 128, 2, NSW>;
 using CfgD128 = TileCfg<128, 128, 2, 2, 0>;   // dense Winograd GEMMs (plain loop: SG_WINO_TILE=3)
 using CfgDP128 = TileCfg<128, 128, 2, 2, 1>; // ... software-pipelined fragment reads, barrier before the last phase
 using CfgD128x64 = TileCfg<128, 64, 2, 1>;   // experiment (SG_WINO_TILE=1): half-width tiles, 4-5 workgroups per CU
@@ -1631,7 +1632,13 @@ inline NkPlan nk_plan(int M, int C, int KS2, int Kpix, bool two) {
     const double w64 = (double)sg_cdiv(M, 64) * 64 * sg_cdiv(C, 64) * 64;
     if (w128 * 0.7 < w64) p.tile = 0;
   }
-  const int BMt = p.tile == 0 ? 128 : (p.tile == 1 ? 64 : 32), BNt = p.tile == 1 ? 64 : 128;
+  // opt-in (SG_NK_TILE3=1): 64 rows x 128 columns where the 64x64 tile was chosen and 128-wide channel tiles pad no further
+  // (each wave owns 32x64: two accumulators per fragment read).  Parity-tested; none of the benchmark's 64x64 weight-gradient
+  // launches qualifies (their inputs have 64 channels), so it is not the default.
+  static int nk3 = -1;
+  if (nk3 < 0) { const char* e = getenv("SG_NK_TILE3"); nk3 = e ? atoi(e) : 0; }
+  if (nk3 && p.tile == 1 && p.tap && sg_cdiv(C, 128) * 128 == sg_cdiv(C, 64) * 64) p.tile = 3;
+  const int BMt = p.tile == 0 ? 128 : ((p.tile == 1 || p.tile == 3) ? 64 : 32), BNt = p.tile == 1 ? 64 : 128;
   p.cpad = p.tap ? sg_cdiv(C, BNt) * BNt : 0;
   const long tiles = (long)sg_cdiv(M, BMt) * (p.tap ? (long)KS2 * (p.cpad / BNt) : (long)sg_cdiv((long)C * KS2, BNt));
   const int target = p.tile == 0 ? 768 : 1024;       // resident workgroups on 256 CUs
@@ -1744,6 +1751,7 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
       switch (pl.tile) {
         case 0: launch_nk_tap<CfgW128, 128, 128>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
         case 1: launch_nk_tap<CfgW64, 64, 64>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
+        case 3: launch_nk_tap<CfgW64W, 64, 128>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
         default: launch_nk_tap<CfgW32, 32, 128>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
       }
     } else {
