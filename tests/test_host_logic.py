@@ -232,3 +232,37 @@ def test_checkpoint_round_trip_and_torch_adam_compatibility(tmp_path):
     st = ref.optimizer.state[p0]
     assert float(st['step']) == 3.0
     assert torch.equal(st['exp_avg'], tr.optimizer.exp_avg[:p0.numel()].view(p0.shape))
+
+
+def test_collate_adapter_contract_and_host_summaries():
+    """pipeline.py: the collate contract of data/coco.py:517-534 is checked on the host, the host lists the step needs are
+    derived without touching the device, and on a CPU device the prefetcher is a pass-through iterator."""
+    import pytest as _pt
+    from scene_generation_amd.pipeline import DeviceBatchPrefetcher, validate_collated, segment_offsets
+    from scene_generation_amd.synthetic import make_batch, Batch
+    hb = make_batch(N=5, min_objs=2, max_objs=6, size=16, mask_size=8, seed=3)
+    o2i = validate_collated(hb)
+    assert o2i == hb.obj_to_img.tolist()
+    seg = segment_offsets(o2i, 5)
+    assert seg[0] == 0 and seg[-1] == hb.objs.numel() and all(b > a for a, b in zip(seg, seg[1:]))
+    for n in range(5):
+        assert all(i == n for i in o2i[seg[n]:seg[n + 1]])
+    out = list(DeviceBatchPrefetcher([hb, hb], 'cpu'))
+    assert len(out) == 2
+    db = out[0]
+    assert db.num_images == 5 and db.objs_host == hb.objs.tolist() and db.obj_to_img_host == o2i
+    assert db.seg_offsets_host == seg and all(torch.equal(a, b) for a, b in zip(db.batch, hb))
+    # violations of the contract fail on the host, before anything is launched
+    bad = hb._replace(obj_to_img=hb.obj_to_img.flip(0))
+    with _pt.raises(ValueError):
+        validate_collated(bad)
+    hole = hb.obj_to_img.clone()
+    hole[hole == 2] = 3                                   # image 2 owns no object
+    with _pt.raises(ValueError):
+        validate_collated(hb._replace(obj_to_img=hole))
+    tri = hb.triples.clone()
+    tri[0, 2] = hb.objs.numel()                            # object id outside the batch
+    with _pt.raises(ValueError):
+        validate_collated(hb._replace(triples=tri))
+    with _pt.raises(ValueError):
+        validate_collated(hb._replace(boxes=hb.boxes[:-1]))
