@@ -33,12 +33,18 @@ def control_group():
         return None
     if not _CTRL['tried']:
         _CTRL['tried'] = True
-        if dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() != 'gloo' \
-                and os.environ.get('SG_CTRL_GLOO', '1') != '0':
+        want = os.environ.get('SG_CTRL_GLOO', '1')       # '0': never; 'force': even when the default group is gloo (tests)
+        if dist.get_world_size() > 1 and want != '0' and (dist.get_backend() != 'gloo' or want == 'force'):
             try:
                 _CTRL['group'] = dist.new_group(backend='gloo')
             except Exception as e:                       # no usable interface: fall back to the device path
                 print('scene_generation_amd.parallel: no gloo control group (%s); agreement values use the device group' % e)
+                _CTRL['group'] = None
+            # every rank must take the same route from here on: use the host group only if ALL ranks have one
+            ok = torch.tensor([1.0 if _CTRL['group'] is not None else 0.0],
+                              device='cuda' if torch.cuda.is_available() else 'cpu')
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:
                 _CTRL['group'] = None
     return _CTRL['group']
 

@@ -173,3 +173,37 @@ def test_bucket_launch_order_is_rank_independent():
         assert nb >= 3
         assert torch.equal(torch.from_numpy(g), want), 'rank %d' % rank
         assert coin == 7 and flags == [1.0, 0.0, 1.0]
+
+
+def _ctrl_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      SG_CTRL_GLOO='force')
+    torch.set_num_threads(1)
+    from scene_generation_amd.parallel import init_distributed, agree, broadcast_int, control_group
+    init_distributed('gloo')
+    g = control_group()
+    assert g is not None and g is control_group()       # created once, on every rank, and agreed upon
+    coin = broadcast_int(11 if rank == 0 else 5, 'cpu')
+    flags = agree([float(rank), 1.0 - rank], dist.ReduceOp.MAX, 'cpu')
+    q.put((rank, coin, flags))
+    dist.barrier()
+    dist.destroy_process_group()
+    assert control_group() is None                      # a destroyed process group takes the control group with it
+
+
+def test_host_side_control_group():
+    """the separate gloo group the RCCL runs use for the per-step agreement values (created here next to a gloo default
+    group: SG_CTRL_GLOO=force), its all-ranks availability check and the two helpers that travel over it"""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ctrl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, coin, flags in res:
+        assert coin == 11 and flags == [1.0, 1.0]
