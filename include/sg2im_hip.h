@@ -134,6 +134,15 @@ int sg_convT2d_dgrad(const sgConvDesc* d, const float* gy, const float* w, float
                      sgStream stream);
 int sg_convT2d_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, float* gb,
                      void* ws, size_t ws_bytes, sgStream stream);
+/* Interpolate(x2, nearest) + Conv2d(C, Cout, 3, padding=1) (mask_net, reference generators.py:20-21, layers.py:304-314) as a
+ * SUB-PIXEL transposed convolution: every output pixel (2i+a, 2j+b) only sees a 2x2 neighbourhood of the stored input, with
+ * the 3x3 taps that land on the same source pixel summed -- conv3x3(up2(x); w) == convT(k4, s2, p1)(x; wt) with
+ *   wt[ci][co][kh][kw] = sum_{i in R(kh)} sum_{j in R(kw)} w[co][ci][i][j],  R(0)={2} R(1)={1,2} R(2)={0,1} R(3)={0}
+ * i.e. 16 instead of 36 multiply-adds per (input pixel, channel pair).  sg_upconv3_fold_weights builds wt; forward, data and
+ * weight gradient are sg_convT2d_{fwd,dgrad,wgrad} on a (KS=4, stride 2, pad 1) desc; sg_upconv3_unfold_wgrad is the adjoint
+ * of the fold: gw[co][ci][i][j] = sum_{kh: i in R(kh)} sum_{kw: j in R(kw)} gwt[ci][co][kh][kw]. */
+int sg_upconv3_fold_weights(const float* w, float* wt, int Cout, int Cin, sgStream stream);
+int sg_upconv3_unfold_wgrad(const float* gwt, float* gw, int Cout, int Cin, sgStream stream);
 /* fold a dgrad taken w.r.t. the reflect-padded and/or x2-upsampled logical input back onto the stored
  * input: gx[NC,H,W] = sum of gp[NC, H*up+2p, W*up+2p] over reflected / replicated positions */
 int sg_pad_upsample_bwd(const float* gp, float* gx, int NC, int H, int W, int pad, int upsample, sgStream stream);

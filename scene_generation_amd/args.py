@@ -98,6 +98,9 @@ def _build():
     A('--output_dir', default=os.path.join(os.getcwd(), 'output', stamp + '_' + socket.gethostname()))
     A('--checkpoint_name', default='checkpoint')
     A('--restore_from_checkpoint', default=False, type=bool_flag)
+    # extension (not a reference flag): torchvision vgg19 state_dict with the ImageNet weights the reference's VGGLoss
+    # downloads (losses.py:183); without it a --vgg_features_weight > 0 run trains against RANDOM VGG19 features and says so
+    A('--vgg_weights', default=None, type=str)
     return p
 
 

@@ -83,6 +83,10 @@ __device__ __forceinline__ float4 sg_bufload4(__amdgpu_buffer_rsrc_t r, unsigned
 }
 #endif
 constexpr unsigned ELEM_INVALID = 1u << 29;      // element offset that the range check of a buffer load rejects
+// Largest tensor (in elements) an operand loader may address.  Buffer loads carry a BYTE offset in 32 bits against
+// num_records = 2^31 bytes, so element indices must stay below 2^29 (an index in [2^29, 2^31) would be range-rejected and
+// silently read as 0); the plain-load build addresses 2^31 elements.  Every entry point checks its operands against this.
+constexpr double SG_MAX_ELEMS = SG_BUFLOAD ? 536870912.0 : 2147483647.0;
 
 
 // rows of length K contiguous in memory: elem(x, k) = base[x*ld + k].  VEC: ld%4==0 and 16-B aligned base.
@@ -1797,11 +1801,13 @@ int check_desc(const sgConvDesc* d, const char* who) {
   SG_ARG_CHECK(d->N > 0 && d->C1 > 0 && d->C2 >= 0 && d->Cout > 0 && d->H > 0 && d->W > 0 && d->OH > 0 && d->OW > 0,
                "%s: non-positive dimension", who);
   SG_ARG_CHECK(!d->pad_reflect || d->pad < d->H * d->upsample, "%s: reflect pad too large", who);
-  const double lim = 2147483647.0;     // kernels use 32-bit element offsets
-  SG_ARG_CHECK((double)d->N * (d->C1 + d->C2) * d->H * d->W < lim && (double)d->N * d->Cout * d->OH * d->OW < lim &&
+  const double lim = SG_MAX_ELEMS;     // 32-bit offsets; 2^29 elements with buffer-load masking (see SG_MAX_ELEMS)
+  SG_ARG_CHECK((double)d->N * (d->C1 + d->C2) * d->H * d->W <= lim && (double)d->N * d->Cout * d->OH * d->OW <= lim &&
                    (double)d->N * (d->C1 + d->C2) * (d->H * d->upsample + 2.0 * d->pad) *
-                           (d->W * d->upsample + 2.0 * d->pad) < lim,
-               "%s: tensor has >= 2^31 elements", who);
+                           (d->W * d->upsample + 2.0 * d->pad) <= lim &&
+                   (double)d->Cout * (d->C1 + d->C2) * d->KS * d->KS <= lim,
+               "%s: a tensor has more than %.0f elements (32-bit offsets%s)", who, lim,
+               SG_BUFLOAD ? ", buffer-load range masking" : "");
   return 0;
 }
 
@@ -1892,7 +1898,7 @@ extern "C" int sg_conv2d_dgrad(const sgConvDesc* d, const float* gy, const float
 static bool dgrad_folded_ok(const sgConvDesc* d) {
   return d && d->pad_reflect && d->pad == 1 && d->KS == 3 && d->stride == 1 && d->upsample == 1 && d->C2 == 0 &&
          d->H >= 3 && d->W >= 3 && d->OH == d->H && d->OW == d->W &&
-         9.0 * d->N * d->Cout * d->OH * d->OW < 2147483647.0;
+         9.0 * d->N * d->Cout * d->OH * d->OW <= SG_MAX_ELEMS;     // the nine pre-folded copies of gy are ONE gathered source
 }
 extern "C" int sg_conv2d_dgrad_folded_supported(const sgConvDesc* d) { return dgrad_folded_ok(d) ? 1 : 0; }
 extern "C" size_t sg_conv2d_dgrad_folded_ws_bytes(const sgConvDesc* d) {
@@ -2643,6 +2649,56 @@ extern "C" int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const 
   return 0;
 }
 
+// ---- Interpolate(x2 nearest) + conv3x3(pad 1) as a sub-pixel transposed conv (see the header) ---------------------------
+namespace {
+// taps of the 3x3 filter that land on transposed-conv tap k (per axis): [first, last]
+__device__ __forceinline__ void upconv_range(int k, int& lo, int& hi) {
+  lo = k == 0 ? 2 : (k == 1 ? 1 : 0);
+  hi = k == 0 ? 2 : (k == 1 ? 2 : (k == 2 ? 1 : 0));
+}
+__global__ void upconv3_fold_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int Cin) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;        // over wt [Cin][Cout][4][4]
+  if (idx >= (size_t)Cin * Cout * 16) return;
+  const int kw = idx & 3, kh = (idx >> 2) & 3;
+  const size_t cc = idx >> 4;
+  const int co = (int)(cc % Cout), ci = (int)(cc / Cout);
+  const float* g = w + ((size_t)co * Cin + ci) * 9;
+  int i0, i1, j0, j1;
+  upconv_range(kh, i0, i1);
+  upconv_range(kw, j0, j1);
+  float v = 0.f;
+  for (int i = i0; i <= i1; ++i)
+    for (int j = j0; j <= j1; ++j) v += g[i * 3 + j];
+  wt[idx] = v;
+}
+__global__ void upconv3_unfold_kernel(const float* __restrict__ gwt, float* __restrict__ gw, int Cout, int Cin) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;        // over gw [Cout][Cin][3][3]
+  if (idx >= (size_t)Cout * Cin * 9) return;
+  const int t = (int)(idx % 9), i = t / 3, j = t - i * 3;
+  const size_t cc = idx / 9;
+  const int ci = (int)(cc % Cin), co = (int)(cc / Cin);
+  const float* g = gwt + ((size_t)ci * Cout + co) * 16;
+  // tap i of the 3x3 filter contributes to transposed-conv taps {2,3} (i=0), {1,2} (i=1), {0,1} (i=2)
+  const int kh0 = 2 - i, kw0 = 2 - j;
+  gw[idx] = (g[kh0 * 4 + kw0] + g[kh0 * 4 + kw0 + 1]) + (g[(kh0 + 1) * 4 + kw0] + g[(kh0 + 1) * 4 + kw0 + 1]);
+}
+}  // namespace
+
+extern "C" int sg_upconv3_fold_weights(const float* w, float* wt, int Cout, int Cin, sgStream stream) {
+  SG_ARG_CHECK(w && wt && Cout > 0 && Cin > 0, "sg_upconv3_fold_weights: bad arguments");
+  const size_t n = (size_t)Cin * Cout * 16;
+  hipLaunchKernelGGL(upconv3_fold_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, w, wt, Cout, Cin);
+  SG_LAUNCH_CHECK("sg_upconv3_fold_weights");
+  return 0;
+}
+extern "C" int sg_upconv3_unfold_wgrad(const float* gwt, float* gw, int Cout, int Cin, sgStream stream) {
+  SG_ARG_CHECK(gwt && gw && Cout > 0 && Cin > 0, "sg_upconv3_unfold_wgrad: bad arguments");
+  const size_t n = (size_t)Cout * Cin * 9;
+  hipLaunchKernelGGL(upconv3_unfold_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, gwt, gw, Cout, Cin);
+  SG_LAUNCH_CHECK("sg_upconv3_unfold_wgrad");
+  return 0;
+}
+
 extern "C" size_t sg_plan_cache_bytes(void) {
   std::lock_guard<std::mutex> lk(g_tab_mu);
   return g_tab_bytes;
@@ -2657,6 +2713,9 @@ extern "C" int sg_plan_cache_clear(void) {
 
 // ---- dense layers --------------------------------------------------------------------------------
 namespace {
+inline bool dense_sizes_ok(int rows, int in_f, int out_f) {
+  return (double)rows * in_f <= SG_MAX_ELEMS && (double)rows * out_f <= SG_MAX_ELEMS && (double)in_f * out_f <= SG_MAX_ELEMS;
+}
 template <class A64, class B64, class A32, class B128>
 int run_dense(const A64& a64, const B64& b64, const A32& a32, const B128& b128, const EpRowMajor& ep, int M, int N,
               int K, hipStream_t s) {
@@ -2676,6 +2735,7 @@ int run_dense(const A64& a64, const B64& b64, const A32& a32, const B128& b128, 
 extern "C" int sg_linear_fwd(const float* x, const float* w, const float* b, float* y, int rows, int in_f, int out_f,
                              int act, float slope, sgStream stream) {
   SG_ARG_CHECK(x && w && y && rows > 0 && in_f > 0 && out_f > 0, "sg_linear_fwd: bad arguments");
+  SG_ARG_CHECK(dense_sizes_ok(rows, in_f, out_f), "sg_linear_fwd: operand exceeds %.0f elements", SG_MAX_ELEMS);
   hipStream_t s = (hipStream_t)stream;
   EpRowMajor ep{y, b, rows, out_f, out_f, act, slope, 0};
   const bool vec = (in_f % 4 == 0) && aligned16(x) && aligned16(w);
@@ -2693,6 +2753,7 @@ extern "C" int sg_linear_fwd(const float* x, const float* w, const float* b, flo
 extern "C" int sg_linear_bwd_data(const float* gy, const float* w, float* gx, int rows, int in_f, int out_f,
                                   sgStream stream) {
   SG_ARG_CHECK(gy && w && gx && rows > 0 && in_f > 0 && out_f > 0, "sg_linear_bwd_data: bad arguments");
+  SG_ARG_CHECK(dense_sizes_ok(rows, in_f, out_f), "sg_linear_bwd_data: operand exceeds %.0f elements", SG_MAX_ELEMS);
   hipStream_t s = (hipStream_t)stream;
   EpRowMajor ep{gx, nullptr, rows, in_f, in_f, SG_ACT_NONE, 0.f, 0};
   const bool vec = (out_f % 4 == 0) && aligned16(gy);
@@ -2710,6 +2771,7 @@ extern "C" int sg_linear_bwd_data(const float* gy, const float* w, float* gx, in
 extern "C" int sg_linear_bwd_weight(const float* gy, const float* x, float* gw, float* gb, int rows, int in_f,
                                     int out_f, sgStream stream) {
   SG_ARG_CHECK(gy && x && gw && rows > 0 && in_f > 0 && out_f > 0, "sg_linear_bwd_weight: bad arguments");
+  SG_ARG_CHECK(dense_sizes_ok(rows, in_f, out_f), "sg_linear_bwd_weight: operand exceeds %.0f elements", SG_MAX_ELEMS);
   hipStream_t s = (hipStream_t)stream;
   EpRowMajor ep{gw, nullptr, out_f, in_f, in_f, SG_ACT_NONE, 0.f, 0};
   {

@@ -13,6 +13,7 @@ capture time and re-issued after every replay.  Object-level sub-networks (mask_
 discriminators) see a different number of objects every iteration and stay eager.
 """
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -39,6 +40,11 @@ class _Entry(object):
     pass
 
 
+class _Token(object):
+    """lives as long as the autograd node of one grad-mode replay: an entry whose token is alive has a backward pending"""
+    __slots__ = ('__weakref__',)
+
+
 class _GraphedFn(Function):
     @staticmethod
     def forward(ctx, entry, x):
@@ -46,6 +52,10 @@ class _GraphedFn(Function):
         entry.fwd.replay()
         REPLAYS[0] += 1
         ctx.entry = entry
+        # the activations this replay saved live in the graph's private pool until the matching backward has run (or the
+        # autograd node is dropped): GraphedSegment.__call__ refuses a second grad-mode replay of the entry until then
+        ctx.token = _Token()
+        entry.pending = weakref.ref(ctx.token)
         outs = [o.detach() for o in entry.static_out]
         if entry.clone_outputs:
             outs = [o.clone() for o in outs]
@@ -59,10 +69,23 @@ class _GraphedFn(Function):
                 ops.fill_(buf, 0.0)
             else:
                 buf.copy_(g)
+        # A captured backward OVERWRITES the gradient slices of its parameters (sink mode 0: every parameter used once per
+        # step, after zero_grad()).  If a slice already holds a contribution (gradient accumulation: a second backward
+        # without zero_grad()), keep it and add it back after the replay -- the eager path would have accumulated.
+        carried = []
+        if not e.accumulate:
+            for opt, i in e.deliveries:
+                if opt._touched[i]:
+                    view = opt.fp.grad_view(i)
+                    carried.append((view, view.clone()))
         e.bwd.replay()
         REPLAYS[0] += 1
+        for view, old in carried:
+            view.add_(old)
         for opt, i in e.deliveries:           # what ops.GradOut.finish() tells the optimiser on the eager path
             opt._on_grad(i)
+        e.pending = None
+        ctx.token = None
         return None, (e.static_gin.detach() if e.static_gin is not None else None)
 
 
@@ -74,15 +97,16 @@ class GraphedSegment(object):
     after zero_grad()) it overwrites.  ``clone_outputs``: hand out copies instead of views of the static output buffers
     (for outputs that callers keep across iterations)."""
 
-    def __init__(self, fn, params=(), accumulate=False, warmup=2, clone_outputs=False, name='segment'):
+    def __init__(self, fn, params=(), accumulate=False, warmup=2, clone_outputs=False, name='segment', modules=()):
         self.fn, self.params = fn, list(params)
         self.accumulate, self.warmup, self.clone_outputs, self.name = accumulate, warmup, clone_outputs, name
+        self.modules = list(modules)           # their train / eval flags are part of the graph key (BatchNorm, dropout)
         self.entries, self.seen = {}, {}
 
     def __deepcopy__(self, memo):
         import copy
         return GraphedSegment(copy.deepcopy(self.fn, memo), copy.deepcopy(self.params, memo), self.accumulate, self.warmup,
-                              self.clone_outputs, self.name)          # graphs are never copied: the copy re-captures
+                              self.clone_outputs, self.name, copy.deepcopy(self.modules, memo))   # the copy re-captures
 
     def __call__(self, x):
         if not (ENABLED and x.is_cuda) or ops.prof_is_enabled():
@@ -90,7 +114,7 @@ class GraphedSegment(object):
         grad = torch.is_grad_enabled()
         need_grad = grad and (x.requires_grad or any(p.requires_grad for p in self.params))
         key = (tuple(x.shape), x.dtype, need_grad, grad and x.requires_grad, tuple(p.requires_grad for p in self.params),
-               ops.WINOGRAD, ops.FACTORED_LAYOUT, ops.skip_state_key())
+               ops.WINOGRAD, ops.FACTORED_LAYOUT, ops.skip_state_key(), tuple(m.training for m in self.modules))
         e = self.entries.get(key)
         if e is None:
             n = self.seen.get(key, 0)
@@ -110,6 +134,10 @@ class GraphedSegment(object):
                 self.entries[key] = e
         if e is False:
             return self.fn(x)
+        if need_grad and e.pending is not None and e.pending() is not None:
+            # a second grad-mode call before the first one's backward: a replay would overwrite the activations that
+            # backward still needs (they live in the graph's pool) -- this call runs eager
+            return self.fn(x)
         if need_grad:
             outs = _GraphedFn.apply(e, x)
         else:
@@ -124,6 +152,8 @@ class GraphedSegment(object):
     def _capture(self, x, need_grad):
         e = _Entry()
         e.clone_outputs = self.clone_outputs
+        e.accumulate = self.accumulate
+        e.pending = None
         x_grad = torch.is_grad_enabled() and x.requires_grad
         e.static_in = x.detach().clone().requires_grad_(x_grad)
         torch.cuda.synchronize()

@@ -131,9 +131,12 @@ class Vgg19(nn.Module):
         if not requires_grad:
             for p in self.parameters():
                 p.requires_grad = False
-        # static shapes, frozen parameters: one hipGraph for the forward and one for the data gradient (graphs.py)
+        # static shapes, frozen parameters: one hipGraph for the forward and one for the data gradient (graphs.py).  The five
+        # feature maps are handed out as COPIES: VGGLoss calls the extractor twice per step (x, then y) and under no_grad /
+        # with a detached x both calls replay the same graph, whose static output buffers the second call would overwrite
         from .graphs import GraphedSegment
-        self._graphed = GraphedSegment(self._features, params=list(self.parameters()), name='Vgg19')
+        self._graphed = GraphedSegment(self._features, params=list(self.parameters()), name='Vgg19', clone_outputs=True,
+                                       modules=[self])
 
     def load_torchvision_state_dict(self, sd):
         """``sd``: torchvision vgg19 state_dict (keys ``features.<i>.weight|bias``) or a path to one"""

@@ -439,12 +439,24 @@ def ensure_dense(t):
     return t
 
 
+def _upconv_prefers_winograd(x, weight):
+    """the folded-upsample Winograd path (>= 128 channels in multiples of 128) keeps its convs"""
+    if not WINOGRAD:
+        return False
+    N, C, H, W = x.shape
+    d = _conv_desc(N, C, 0, H, W, weight.size(0), 3, 1, 1, False, 2, 2 * H, 2 * W, 0, 0)
+    return bool(_q(d, 'sg_conv2d_wino_supported'))
+
+
 def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, upsample=1, act=ACT_NONE, slope=0.0, x2=None):
     """Layout hints (see the table above): 'grad_from' = c promises that nobody needs d/dx[:, :c] (the data gradient is
     then only computed for channels >= c, the rest is returned as zeros); 'sparse' = (chan_list, chan_cnt) promises that,
     per image, every channel outside the list is all-zero (forward and weight gradient then only visit the listed
     channels, sg_conv2d_*_sparse); 'factored' = the layout as planes x per-object vectors (factored_layout_conv)."""
     h = hints_of(x)
+    if (UPCONV and upsample == 2 and stride == 1 and pad == 1 and not reflect and x2 is None and h is None
+            and act == ACT_NONE and weight.size(2) == 3 and weight.size(3) == 3 and not _upconv_prefers_winograd(x, weight)):
+        return UpConv3Fn.apply(x, weight, bias)
     if h is None:
         return Conv2dFn.apply(x, x2, weight, bias, stride, pad, reflect, upsample, act, float(slope), 0, None)
     f = h.get('factored') if FACTORED_LAYOUT else None
@@ -524,6 +536,67 @@ class ConvTranspose2dFn(Function):
 
 def conv_transpose2d(x, weight, bias=None, stride=2, pad=1, out_pad=1):
     return ConvTranspose2dFn.apply(x, weight, bias, stride, pad, out_pad)
+
+
+# Interpolate(x2, nearest) + Conv2d(3, padding=1) as a sub-pixel transposed convolution (SG_UPCONV=0: 3x3 gather over the
+# folded upsample instead): 16 instead of 36 multiply-adds per input pixel and channel pair (mask_net, generators.py:20-21)
+UPCONV = os.environ.get('SG_UPCONV', '1') != '0'
+
+
+class UpConv3Fn(Function):
+    """conv3x3(pad 1)(nearest_up2(x)) == convT(k4, s2, p1)(x; wt), wt = the 3x3 taps summed per source pixel
+    (sg_upconv3_fold_weights); backward = the transposed conv's data / weight gradients + the adjoint of the fold."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = _f32(x, 'conv input')
+        weight = _f32(weight, 'conv weight')
+        N, Cin, H, W = x.shape
+        Cout = weight.size(0)
+        assert tuple(weight.shape) == (Cout, Cin, 3, 3)
+        s = _stream()
+        d = _conv_desc(N, Cin, 0, H, W, Cout, 4, 2, 1, False, 1, 2 * H, 2 * W, 0)
+        wt = torch.empty(Cin, Cout, 4, 4, dtype=torch.float32, device=x.device)
+        _call('sg_upconv3_fold_weights', _p(weight), _p(wt), Cout, Cin, s)
+        y = torch.empty(N, Cout, 2 * H, 2 * W, dtype=torch.float32, device=x.device)
+        wsb = _q(d, 'sg_conv2d_ws_bytes', 0)
+        _call('sg_convT2d_fwd', d._ref, _p(x), _p(wt), _p(bias), _p(y), _p(workspace(wsb, x.device)), wsb, s)
+        ctx.desc = d
+        ctx.bias_ref = bias
+        ctx.weight_ref = weight
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, wt)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if gy is None:
+            return None, None, None
+        x, wt = ctx.saved_tensors
+        d, weight = ctx.desc, ctx.weight_ref
+        gy = _f32(gy)
+        s, dev = _stream(), gy.device
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            wsb = _q(d, 'sg_conv2d_ws_bytes', 1)
+            _call('sg_convT2d_dgrad', d._ref, _p(gy), _p(wt), _p(gx), _p(workspace(wsb, dev)), wsb, s)
+        need_w = ctx.needs_input_grad[1] and _wants_grad(weight)
+        need_b = ctx.bias_ref is not None and ctx.needs_input_grad[2] and _wants_grad(ctx.bias_ref)
+        ow = GradOut(weight) if need_w else None
+        ob = GradOut(ctx.bias_ref) if need_b else None
+        if need_w:
+            gwt = torch.empty_like(wt)
+            wsb = _q(d, 'sg_conv2d_ws_bytes', 2)
+            _call('sg_convT2d_wgrad', d._ref, _p(gy), _p(x), _p(gwt), _p(ob.buf) if need_b else None,
+                  _p(workspace(wsb, dev)), wsb, s)
+            _call('sg_upconv3_unfold_wgrad', _p(gwt), _p(ow.buf), d.Cout, d.C1, s)
+        elif need_b:
+            wsb = _L().sg_channel_sum_ws_bytes(d.Cout)
+            _call('sg_channel_sum', _p(gy), _p(ob.buf), d.N, d.Cout, d.OH * d.OW, _p(workspace(wsb, dev)), wsb, s)
+        gw = ow.finish() if need_w else None
+        gb = ob.finish() if need_b else None
+        return gx, gw, gb
 
 
 # =============================================================================================

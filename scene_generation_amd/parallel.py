@@ -22,15 +22,20 @@ import torch
 import torch.distributed as dist
 
 
-_CTRL = {'group': None, 'tried': False}
+_CTRL = {'group': None, 'tried': False, 'default_pg': None}
 
 
 def control_group():
     """Host-side (gloo) group for the per-step agreement values, or None (then they go through the default group on the
     device and cost one synchronisation each).  Collective: the first call must happen on every rank (init_distributed)."""
     if not dist.is_initialized():
-        _CTRL['group'], _CTRL['tried'] = None, False     # (a later init_process_group starts over)
+        _CTRL['group'], _CTRL['tried'], _CTRL['default_pg'] = None, False, None     # (a later init_process_group starts over)
         return None
+    pg = dist.distributed_c10d._get_default_group()
+    if _CTRL['default_pg'] is not pg:
+        # the default process group was destroyed and re-created since the control group was made: a group built on the
+        # old one is stale (its ranks / store are gone) -- start over for THIS process group
+        _CTRL['group'], _CTRL['tried'], _CTRL['default_pg'] = None, False, pg
     if not _CTRL['tried']:
         _CTRL['tried'] = True
         want = os.environ.get('SG_CTRL_GLOO', '1')       # '0': never; 'force': even when the default group is gloo (tests)
@@ -160,7 +165,16 @@ class GradReducer:
 
     def param_ready(self, i):
         """parameter ``i`` has its final gradient for this step (autograd hook, or ops.deliver_param_grad)"""
-        if not (self.active and self.armed and self.world > 1 and self.overlap) or self._ready[i]:
+        if not (self.active and self.armed and self.world > 1 and self.overlap):
+            return
+        if self._ready[i]:
+            # "final on first delivery" is an assumption about the owner (every parameter used once per step).  A second
+            # contribution is harmless while the bucket is still local, but once its all-reduce is in flight the late
+            # contribution would be added to a slice that is being -- or has been -- reduced: the ranks would diverge silently
+            if self._launched[self.bucket_of[i]]:
+                raise RuntimeError('GradReducer(overlap=True): parameter %d received another gradient contribution after its '
+                                   'bucket was sent to the all-reduce (tied / re-used parameter?): build the reducer with '
+                                   'overlap=False for this optimiser' % i)
             return
         self._ready[i] = True
         self._pending[self.bucket_of[i]] -= 1

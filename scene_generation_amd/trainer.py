@@ -138,7 +138,15 @@ class Trainer:
         self.model = Model(**model_kwargs).to(self.device)
         self.criterionVGG = None
         if args.vgg_features_weight > 0:             # trainer.py:57; ImageNet weights via --vgg_weights <state_dict path>
-            self.criterionVGG = VGGLoss(weights=getattr(args, 'vgg_weights', None) or None).to(self.device)
+            vgg_weights = getattr(args, 'vgg_weights', None) or None
+            if vgg_weights is None:
+                import sys
+                print('scene_generation_amd.Trainer: WARNING -- --vgg_features_weight %g without --vgg_weights: the perceptual '
+                      'loss runs on a RANDOM-INIT VGG19 (torchvision ImageNet weights cannot be downloaded here).  Same '
+                      'arithmetic and cost as the reference objective, NOT its perceptual meaning; pass --vgg_weights '
+                      '<torchvision vgg19 state_dict> for real training or --vgg_features_weight 0 to drop the term.'
+                      % args.vgg_features_weight, file=sys.stderr)
+            self.criterionVGG = VGGLoss(weights=vgg_weights).to(self.device)
         self.criterionGAN = GANLoss(use_lsgan=not args.no_lsgan)
         self.optimizer = self._adam(self.model, args.learning_rate)
 

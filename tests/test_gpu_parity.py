@@ -93,6 +93,9 @@ CONV_CASES = [
     (2, 3, 0, 32, 32, 64, 3, 1, 1, False, 1, 1),       # VGG conv1_1
     (2, 16, 0, 15, 17, 8, 3, 2, 1, False, 1, 0),       # stride-2 dgrad: four parity classes of different sizes in one launch
     (2, 8, 0, 12, 12, 24, 4, 2, 1, False, 1, 0),       # k4 s2 p1: equal classes
+    (7, 24, 0, 1, 1, 24, 3, 1, 1, False, 2, 0),        # mask_net first octave: 1x1 -> 2x2 (sub-pixel transposed conv)
+    (3, 16, 0, 5, 7, 12, 3, 1, 1, False, 2, 0),        # sub-pixel transposed conv, odd non-square plane, Cin != Cout
+    (9, 192, 0, 16, 16, 192, 3, 1, 1, False, 2, 0),    # mask_net last octave at full width (192 channels, 16 -> 32)
 ]
 
 
@@ -230,6 +233,26 @@ def test_conv2d_broadcast_second_source(hip):
     close(yg, yr, 3e-5)
     close(xg.grad, xr.grad, 5e-5)
     close(wg.grad, wr.grad, 5e-5)
+
+
+def test_upconv_subpixel_form_equals_folded_upsample_gather(hip):
+    """Interpolate(x2)+Conv3x3 (generators.py:20-21): the sub-pixel transposed-conv form (ops.UpConv3Fn, the default) against
+    the 3x3 gather over the folded upsample (SG_UPCONV=0) -- same results to fp32 round-off, forward and all gradients."""
+    x, w, b = det((6, 40, 8, 8), 41), det((24, 40, 3, 3), 42, 0.2), det((24,), 43, 0.2)
+    gy = det((6, 24, 16, 16), 44).to(DEV)
+    res = []
+    saved = hip.UPCONV
+    try:
+        for flag in (True, False):
+            hip.UPCONV = flag
+            xg, wg, bg = [t.to(DEV).requires_grad_() for t in (x, w, b)]
+            y = hip.conv2d(xg, wg, bg, stride=1, pad=1, upsample=2)
+            y.backward(gy)
+            res.append((y, xg.grad, wg.grad, bg.grad))
+    finally:
+        hip.UPCONV = saved
+    for a, c, name in zip(res[0], res[1], ('y', 'gx', 'gw', 'gb')):
+        close(a, c, 2e-5, name)
 
 
 @pytest.mark.parametrize('N,Cin,Cout,H', [(2, 16, 8, 8), (3, 32, 16, 5), (2, 128, 64, 16)])

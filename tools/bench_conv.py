@@ -20,6 +20,11 @@ SHAPES = [
 ]
 
 
+for spec in filter(None, os.environ.get('SG_BENCH_SHAPES', '').split(';')):
+    f = spec.split(':')
+    SHAPES.append((f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4]), int(f[5]), int(f[6]), int(f[7]), f[8] == '1', int(f[9])))
+
+
 def timeit(fn, n=5):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -361,6 +361,69 @@ def golden_step():
     npz('state_dict_keys_full', **inv)
 
 
+def _slices(t, n=64):
+    """a few small, fixed slices of a tensor: the first and last n entries and n entries on a stride"""
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return torch.cat([f[:n], f[-n:], f[::step][:n]])
+
+
+def golden_step_full():
+    """G7 at FULL default widths ("one full-size run storing only loss dicts + output checksums"): the reference
+    Trainer (trainer.py:205-325 driven as train.py:190-215) for two iterations at
+      * the BASELINE configs[1] shape: 128x128, <= 8 objects (+ __image__), default widths, N = 8 (= the per-kernel shapes
+        of the bench line: Winograd 128-tiles, factored layout convs, 128-wide GEMM tiles), and
+      * BASELINE configs[0]: 64x64, 4 objects, N = 4.
+    Stored: the 16 named losses, (sum, |sum|) of the three outputs / three layouts and of EVERY post-step parameter and
+    buffer, plus a few small slices of the outputs."""
+    from scene_generation.args import parser
+    from scene_generation.trainer import Trainer
+    vocab = make_vocab()
+    for tag, size, N, lo, hi in (('c2', 128, 8, 3, 8), ('c1', 64, 4, 4, 4)):
+        argv = ['--image_size', '%d,%d' % (size, size), '--batch_size', str(N), '--vgg_features_weight', '0',
+                '--output_dir', '/tmp/o']
+        args = parser.parse_args(argv)
+        with fake_cuda():
+            tr = Trainer(args, vocab, {'model_kwargs': {}, 'd_obj_kwargs': {}, 'd_mask_kwargs': {}, 'd_img_kwargs': {}})
+        for m in (tr.model, tr.netD, tr.obj_discriminator, tr.mask_discriminator):
+            fill_deterministic(m)
+        random.seed(4321)
+        arrs = {'argv': np.array(argv), 'N': N, 'min_objs': lo, 'max_objs': hi, 'size': size}
+        for it in range(2):
+            batch = make_batch(N=N, min_objs=lo, max_objs=hi, size=size, seed=200 + it)
+            imgs, objs, boxes, masks, triples, o2i, _, attributes = batch
+            use_gt = (it == 0)
+            if not use_gt:
+                attributes = torch.zeros_like(attributes)
+            torch.manual_seed(888 + it)
+            noise = torch.randn((1, args.mask_noise_dim))
+            torch.manual_seed(888 + it)
+            out = tr.model(imgs, objs, triples, o2i, boxes_gt=boxes, masks_gt=masks, attributes=attributes)
+            imgs_pred, boxes_pred, masks_pred, layout, layout_pred, layout_wrong = out
+            tr.train_generator(imgs, imgs_pred, masks, masks_pred, layout, objs, boxes, boxes_pred, o2i, use_gt)
+            tr.train_mask_discriminator(masks, masks_pred.detach(), objs)
+            tr.train_obj_discriminator(imgs, imgs_pred.detach(), objs, boxes, boxes.detach(), o2i)
+            tr.train_image_discriminator(imgs, imgs_pred.detach(), layout.detach(), layout_wrong.detach())
+            pre = 'it%d_' % it
+            arrs[pre + 'noise'] = noise
+            for n, t in zip(['imgs_pred', 'boxes_pred', 'masks_pred', 'layout', 'layout_pred', 'layout_wrong'], out):
+                arrs[pre + n + '_stats'] = np.array([float(t.double().sum()), float(t.double().abs().sum())])
+                arrs[pre + n + '_slices'] = _slices(t)
+            arrs[pre + 'boxes_pred'] = boxes_pred.detach()
+            for lname, L in [('g', tr.generator_losses), ('dmask', tr.d_mask_losses), ('dobj', tr.d_obj_losses),
+                             ('dimg', tr.d_img_losses)]:
+                for k, v in L.items():
+                    arrs[pre + 'loss_' + lname + '_' + k] = v
+            for mname, m in [('model', tr.model), ('netD', tr.netD), ('objD', tr.obj_discriminator),
+                             ('maskD', tr.mask_discriminator)]:
+                keys, st = tensor_stats(m.state_dict())
+                arrs[pre + 'keys_' + mname] = np.array(keys)
+                arrs[pre + 'stats_' + mname] = st
+            print(tag, 'iteration', it, 'done', flush=True)
+        npz('step_full_' + tag, **arrs)
+        del tr
+
+
 def golden_testmode():
     """masks_to_layout(test_mode=True) (layout.py:87-92,157-169) and Model.forward(test_mode=True,
     features=...) (model.py:111-117,158-163) of the reference, reduced widths."""
@@ -532,6 +595,6 @@ def golden_args():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     install_shims()
-    which = sys.argv[1:] or ['gconv', 'layout', 'crop', 'modules', 'losses', 'losses2', 'vgg', 'legacy', 'step', 'testmode', 'args']
+    which = sys.argv[1:] or ['gconv', 'layout', 'crop', 'modules', 'losses', 'losses2', 'vgg', 'legacy', 'step', 'step_full', 'testmode', 'args']
     for w in which:
         globals()['golden_' + w]()
