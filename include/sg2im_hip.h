@@ -127,6 +127,16 @@ int sg_conv2d_smallm_fwd(const sgConvDesc* d, const float* x, const float* w, co
                          float slope, sgStream stream);
 int sg_conv2d_smallm_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, void* ws, size_t ws_bytes,
                            sgStream stream);
+/* Direct (vector-ALU) kernels for SINGLE-output-channel convs with zero padding, stride 1, KS in {1,3,4}: the PatchGAN score
+   heads (reference discriminators.py:152-158,232-234) and the 1x1 head of mask_net (generators.py:27).  Memory-bound
+   reductions; channel chunks / images are combined in a fixed order.  ws: sg_conv2d_head_ws_bytes.  gb via sg_channel_sum. */
+int sg_conv2d_head_supported(const sgConvDesc* d);
+size_t sg_conv2d_head_ws_bytes(const sgConvDesc* d);
+int sg_conv2d_head_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                       float slope, void* ws, size_t ws_bytes, sgStream stream);
+int sg_conv2d_head_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, sgStream stream);
+int sg_conv2d_head_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, void* ws, size_t ws_bytes,
+                         sgStream stream);
 /* nn.ConvTranspose2d(k3,s2,p1,op1) : w [Cin, Cout, KS, KS]; desc.H,W = input size, OH,OW = output size */
 int sg_convT2d_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y,
                    void* ws, size_t ws_bytes, sgStream stream);

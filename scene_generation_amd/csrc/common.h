@@ -38,7 +38,9 @@ enum {
   SG_K_CROP, SG_K_OTHER,
   // the batched dense GEMMs of the Winograd convs, one kind per template instantiation (they used to be lumped into
   // igemm_kn0_k3_t128 together with the direct 3x3 convs) and the elementwise Winograd transforms
-  SG_K_WINO_GEMM_128, SG_K_WINO_GEMM_64, SG_K_WINO_XFORM, SG_K_COUNT
+  SG_K_WINO_GEMM_128, SG_K_WINO_GEMM_64, SG_K_WINO_XFORM,
+  SG_K_HEAD,          // single-output-channel convolutions on the vector ALUs (smallm.hip), HBM-bound
+  SG_K_COUNT
 };
 static inline int sg_igemm_kind(int family, int KS, int tile) {
   const int k = KS == 1 ? 0 : (KS == 3 ? 1 : (KS == 4 ? 2 : 3));
@@ -54,6 +56,21 @@ struct SgProfScope {
     if (on) sg_prof_begin(kind, s);
   }
   ~SgProfScope() { if (on) sg_prof_end(kind, s, flops, bytes); }
+};
+
+// n / d for 0 <= n < 2^31 as one v_mul_hi + shift (a hardware-less integer division costs ~25 VALU instructions)
+struct FastDiv {
+  unsigned m, s, d;
+  FastDiv() : m(0), s(0), d(1) {}
+  explicit FastDiv(unsigned dd) : m(0), s(0), d(dd) {
+    if (dd > 1) {
+      unsigned sh = 0;
+      while ((1u << sh) < dd) ++sh;
+      m = (unsigned)((((uint64_t)1) << (31 + sh)) / dd + 1);
+      s = sh - 1;
+    }
+  }
+  __device__ __forceinline__ unsigned div(unsigned n) const { return d == 1 ? n : (__umulhi(n, m) >> s); }
 };
 
 static inline int sg_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

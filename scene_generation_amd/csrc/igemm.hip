@@ -379,22 +379,6 @@ struct LoadGatherKN {
   }
 };
 
-// n / d for 0 <= n < 2^31 as one v_mul_hi + shift (the k-loop splits a pixel index every tile: a hardware-less
-// integer division costs ~25 VALU instructions, more than the rest of a loader's per-tile work)
-struct FastDiv {
-  unsigned m, s, d;
-  FastDiv() : m(0), s(0), d(1) {}
-  explicit FastDiv(unsigned dd) : m(0), s(0), d(dd) {
-    if (dd > 1) {
-      unsigned sh = 0;
-      while ((1u << sh) < dd) ++sh;
-      m = (unsigned)((((uint64_t)1) << (31 + sh)) / dd + 1);
-      s = sh - 1;
-    }
-  }
-  __device__ __forceinline__ unsigned div(unsigned n) const { return d == 1 ? n : (__umulhi(n, m) >> s); }
-};
-
 // A operand of wgrad, vector form (PQ % 4 == 0, 16-byte aligned base): each thread moves one float4 of four
 // consecutive pixels of one row: 1 global_load_dwordx4 + 1 ds_write_b128 per 4 elements
 template <int BM>

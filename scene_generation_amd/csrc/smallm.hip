@@ -209,3 +209,268 @@ extern "C" int sg_conv2d_smallm_wgrad(const sgConvDesc* d, const float* gy, cons
   SG_LAUNCH_CHECK("sg_conv2d_smallm_wgrad");
   return 0;
 }
+
+// ================================================================================================
+// Single-output-channel "head" convolutions (PatchGAN score maps: Conv2d(512, 1, 4, padding=2) of discriminators.py:232-234,
+// Conv2d(256, 1, 3, padding=1) of the mask / object discriminators, the 1x1 head of mask_net, generators.py:27).
+// As an implicit GEMM they have ONE row: the 32x128 MFMA tile ran at 1-2 TFLOP/s (0.27 ms per call for 0.19 GFLOP).  They are
+// memory-bound reductions; here the vector ALUs do them from LDS-staged, zero-padded input planes:
+//   forward : workgroup = (channel chunk, image) -> per-chunk partial maps, a second tiny launch adds them (+ bias, act)
+//   dgrad   : workgroup = (channel chunk, image), gy of the image in LDS (one launch)
+//   wgrad   : workgroup = (channel chunk, image), one THREAD per (channel, tap) sums over the pixels -> per-image partials,
+//             combined over the images in a fixed order (deterministic)
+// Global loads are issued in batches of eight before the first LDS store (a "load, store" loop waits for every load in turn:
+// the first version was latency-bound at ~40 dependent HBM round trips per workgroup).
+// ================================================================================================
+namespace {
+
+constexpr int HEAD_LDS_FLOATS = 12288;      // 48 KB per workgroup
+
+struct HeadGeom {
+  int C, H, W, OH, OW, KS, pad, PH, PW;
+  int CH, chunks;              // channels per workgroup
+  FastDiv dPW, dOW, dHW, dW, dGW, dKK, dPP;
+};
+
+HeadGeom head_geom(const sgConvDesc* d) {
+  HeadGeom g;
+  g.C = d->C1; g.H = d->H; g.W = d->W; g.OH = d->OH; g.OW = d->OW; g.KS = d->KS; g.pad = d->pad;
+  g.PH = d->H + 2 * d->pad; g.PW = d->W + 2 * d->pad;
+  const int PP = g.PH * g.PW, OP = g.OH * g.OW;
+  int ch = (HEAD_LDS_FLOATS - 4 * OP) / PP;        // planes + per-wave sums (forward) / gy + pixel-offset table (wgrad)
+  ch = ch > 16 ? 16 : ch;
+  g.CH = ch < 1 ? 1 : ch;
+  g.chunks = (g.C + g.CH - 1) / g.CH;
+  g.dPW = FastDiv((unsigned)g.PW); g.dOW = FastDiv((unsigned)g.OW); g.dHW = FastDiv((unsigned)(g.H * g.W));
+  g.dW = FastDiv((unsigned)g.W); g.dGW = FastDiv((unsigned)(g.OW + 2 * (g.KS - 1)));
+  g.dKK = FastDiv((unsigned)(g.KS * g.KS));
+  g.dPP = FastDiv((unsigned)PP);
+  return g;
+}
+
+bool head_ok(const sgConvDesc* d) {
+  if (!d || d->Cout != 1 || d->stride != 1 || d->upsample != 1 || d->C2 != 0 || d->pad_reflect) return false;
+  if (!(d->KS == 1 || d->KS == 3 || d->KS == 4)) return false;
+  if (d->OH != d->H + 2 * d->pad - d->KS + 1 || d->OW != d->W + 2 * d->pad - d->KS + 1 || d->OW > 256) return false;
+  const int PP = (d->H + 2 * d->pad) * (d->W + 2 * d->pad), OP = d->OH * d->OW;
+  return PP + 4 * OP <= HEAD_LDS_FLOATS && d->C1 >= 16 &&
+         (d->OH + 2 * (d->KS - 1)) * (d->OW + 2 * (d->KS - 1)) + 16 * d->KS * d->KS <= HEAD_LDS_FLOATS;
+}
+
+// rows [prow0, prow0 + nrows) of the zero-padded planes of channels [c0, c0+nc) of one image -> LDS [nc][nrows*PW]
+__device__ __forceinline__ void head_stage(const float* __restrict__ xn, float* __restrict__ pl, int c0, int nc, int prow0,
+                                           int nrows, const FastDiv& dplane, const HeadGeom& g) {
+  const int BP = nrows * g.PW, total = nc * BP;
+  constexpr int U = 8;
+  for (int i0 = threadIdx.x; i0 < total; i0 += U * 256) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * 256;
+      const int ii = i < total ? i : 0;
+      const int c = (int)dplane.div((unsigned)ii), r = ii - c * BP, ph = (int)g.dPW.div((unsigned)r), pw = r - ph * g.PW;
+      const int ih = prow0 + ph - g.pad, iw = pw - g.pad;
+      const bool in = i < total && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+      const float t = xn[in ? ((size_t)(c0 + c) * g.H + ih) * g.W + iw : (size_t)0];      // unconditional load, clamped address
+      v[u] = in ? t : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * 256;
+      if (i < total) pl[i] = v[u];
+    }
+  }
+}
+
+// part[n][chunk][OH*OW] = sum over the chunk's channels and taps.  Wave v takes channels v, v+4, ... of the chunk for ALL pixels
+// (lanes stride the pixels; weights are wave-uniform scalar loads), the four waves' sums are combined through LDS.
+// (A one-launch form -- workgroup = (row band, image) looping over the channel chunks -- was 3x SLOWER: every chunk is a
+// dependent stage -> barrier -> compute round trip; here the chunks run in parallel and a second tiny launch adds them up.)
+template <int KS>
+__global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      float* __restrict__ part, HeadGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float pl[];
+  const int PP = g.PH * g.PW, OP = g.OH * g.OW;
+  float* red = pl + g.CH * PP;                         // [4][OP]
+  const int chunk = blockIdx.x, n = blockIdx.y, c0 = chunk * g.CH, nc = min(g.CH, g.C - c0);
+  head_stage(x + (size_t)n * g.C * g.H * g.W, pl, c0, nc, 0, g.PH, g.dPP, g);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int p = lane; p < OP; p += 64) {
+    const int oh = (int)g.dOW.div((unsigned)p), ow = p - oh * g.OW;
+    const float* base = pl + oh * g.PW + ow;
+    float acc = 0.f;
+    for (int c = wid; c < nc; c += 4) {
+      const float* q = base + c * PP;
+      const float* wc = w + (size_t)(c0 + c) * KS * KS;            // wave-uniform: scalar loads
+#pragma unroll
+      for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) acc = fmaf(wc[kh * KS + kw], q[kh * g.PW + kw], acc);
+    }
+    red[wid * OP + p] = acc;
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < OP; p += blockDim.x)
+    part[((size_t)n * g.chunks + chunk) * OP + p] = (red[p] + red[OP + p]) + (red[2 * OP + p] + red[3 * OP + p]);
+}
+// y[n][p] = act(bias + sum_chunk part[n][chunk][p])
+__global__ void head_fwd_finish_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ y,
+                                       int NB, int chunks, int OP, int act, float slope) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NB * OP) return;
+  const int n = i / OP, p = i - n * OP;
+  float v = bias ? bias[0] : 0.f;
+  for (int k = 0; k < chunks; ++k) v += part[((size_t)n * chunks + k) * OP + p];
+  y[i] = sg_apply_act(v, act, slope);
+}
+
+// gx[n][c][h][w] = sum_{kh,kw} w[c][kh][kw] * gy[n][h + pad - kh][w + pad - kw]
+template <int KS>
+__global__ void __launch_bounds__(256) head_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                        float* __restrict__ gx, HeadGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  // gy of image n, zero-extended by KS-1 on every side: [(OH + 2(KS-1))][(OW + 2(KS-1))]
+  const int E = KS - 1, GW = g.OW + 2 * E, GH = g.OH + 2 * E;
+  float* gl = sm;
+  float* wl = sm + GH * GW;
+  const int chunk = blockIdx.x, n = blockIdx.y, c0 = chunk * g.CH, nc = min(g.CH, g.C - c0);
+  for (int i = threadIdx.x; i < GH * GW; i += blockDim.x) {
+    const int r = (int)g.dGW.div((unsigned)i), q = i - r * GW, oh = r - E, ow = q - E;
+    gl[i] = ((unsigned)oh < (unsigned)g.OH && (unsigned)ow < (unsigned)g.OW) ? gy[((size_t)n * g.OH + oh) * g.OW + ow] : 0.f;
+  }
+  for (int i = threadIdx.x; i < nc * KS * KS; i += blockDim.x) wl[i] = w[(size_t)c0 * KS * KS + i];
+  __syncthreads();
+  const int HW = g.H * g.W;
+  float* out = gx + ((size_t)n * g.C + c0) * HW;
+  for (int i = threadIdx.x; i < nc * HW; i += blockDim.x) {
+    const int c = (int)g.dHW.div((unsigned)i), r = i - c * HW, h = (int)g.dW.div((unsigned)r), wq = r - h * g.W;
+    // gy row index oh = h + pad - kh  ->  extended row (oh + E) = h + pad + E - kh
+    const float* base = gl + (h + g.pad + E) * GW + (wq + g.pad + E);
+    const float* wc = wl + c * KS * KS;
+    float acc = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < KS; ++kw) acc = fmaf(wc[kh * KS + kw], base[-kh * GW - kw], acc);
+    out[i] = acc;
+  }
+}
+
+// part[n][c][kh][kw] = sum_{oh,ow} gy[n][oh][ow] * xpad[n][c][oh+kh][ow+kw].  Thread j = (pixel part q, channel, tap): it walks
+// the pixels p = q, q + Q, ... serially (gy[p] and the plane offset of p are LDS broadcasts) -- no cross-lane reduction per
+// tap; the Q parts of a (channel, tap) are added through LDS at the end.
+template <int KS>
+__global__ void __launch_bounds__(256) head_wgrad_kernel(const float* __restrict__ gy, const float* __restrict__ x,
+                                                        float* __restrict__ part, HeadGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float pl[];
+  constexpr int KK = KS * KS;
+  const int PP = g.PH * g.PW, OP = g.OH * g.OW;
+  float* gl = pl + g.CH * PP;                          // gy of image n: [OP]
+  int* offt = reinterpret_cast<int*>(gl + OP);         // plane offset of output pixel p: oh*PW + ow
+  const int chunk = blockIdx.x, n = blockIdx.y, c0 = chunk * g.CH, nc = min(g.CH, g.C - c0);
+  head_stage(x + (size_t)n * g.C * g.H * g.W, pl, c0, nc, 0, g.PH, g.dPP, g);
+  for (int i = threadIdx.x; i < OP; i += blockDim.x) {
+    gl[i] = gy[(size_t)n * OP + i];
+    const int oh = (int)g.dOW.div((unsigned)i);
+    offt[i] = oh * g.PW + (i - oh * g.OW);
+  }
+  __syncthreads();
+  const int pairs = nc * KK;                           // <= 16 * 16 = 256
+  const int Q = pairs >= 128 ? 1 : (pairs >= 64 ? 2 : (pairs >= 32 ? 4 : (pairs >= 16 ? 8 : 16)));   // pixel parts
+  const int j = threadIdx.x % (256 / Q), q = threadIdx.x / (256 / Q);
+  float acc = 0.f;
+  if (j < pairs) {
+    const int c = (int)g.dKK.div((unsigned)j), t = j - c * KK, kh = t / KS, kw = t - kh * KS;
+    const float* b = pl + c * PP + kh * g.PW + kw;
+    // (unrolled: the LDS reads of eight pixels are issued together; one-at-a-time the loop is a chain of dependent LDS
+    //  round trips -- offset, then the plane element -- of ~150 cycles per pixel)
+#pragma unroll 8
+    for (int p = q; p < OP; p += Q) acc = fmaf(gl[p], b[offt[p]], acc);
+  }
+  __syncthreads();                                     // planes are dead: reuse their LDS for the parts
+  pl[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < pairs) {
+    float v = 0.f;
+    for (int k = 0; k < Q; ++k) v += pl[k * (256 / Q) + threadIdx.x];
+    part[((size_t)n * g.C + c0) * KK + threadIdx.x] = v;
+  }
+}
+
+template <class K> void head_set_lds(K kernel, size_t bytes) {
+  if (bytes > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace
+
+extern "C" int sg_conv2d_head_supported(const sgConvDesc* d) { return head_ok(d) ? 1 : 0; }
+
+extern "C" size_t sg_conv2d_head_ws_bytes(const sgConvDesc* d) {
+  if (!head_ok(d)) return 0;
+  const HeadGeom g = head_geom(d);
+  const size_t a = (size_t)d->N * g.chunks * d->OH * d->OW, b = (size_t)d->N * d->C1 * d->KS * d->KS;
+  return (a > b ? a : b) * sizeof(float);
+}
+
+#define SG_HEAD_DISPATCH(KERNEL, ...)                                                                             \
+  switch (d->KS) {                                                                                                \
+    case 1: head_set_lds(KERNEL<1>, lds); hipLaunchKernelGGL((KERNEL<1>), grid, dim3(256), lds, s, __VA_ARGS__); break; \
+    case 3: head_set_lds(KERNEL<3>, lds); hipLaunchKernelGGL((KERNEL<3>), grid, dim3(256), lds, s, __VA_ARGS__); break; \
+    default: head_set_lds(KERNEL<4>, lds); hipLaunchKernelGGL((KERNEL<4>), grid, dim3(256), lds, s, __VA_ARGS__); break; \
+  }
+
+static double head_bytes(const sgConvDesc* d) {
+  return 4.0 * ((double)d->N * d->C1 * d->H * d->W + (double)d->N * d->OH * d->OW);
+}
+
+extern "C" int sg_conv2d_head_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                                  float slope, void* ws, size_t ws_bytes, sgStream stream) {
+  SG_ARG_CHECK(head_ok(d), "sg_conv2d_head_fwd: unsupported desc (needs Cout == 1, stride 1, zero padding, KS in {1,3,4})");
+  SG_ARG_CHECK(x && w && y && ws && ws_bytes >= sg_conv2d_head_ws_bytes(d), "sg_conv2d_head_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const HeadGeom g = head_geom(d);
+  float* part = reinterpret_cast<float*>(ws);
+  const dim3 grid(g.chunks, d->N);
+  const size_t lds = ((size_t)g.CH * g.PH * g.PW + 4 * (size_t)d->OH * d->OW) * sizeof(float);
+  SgProfScope prof(SG_K_HEAD, s, 2.0 * d->C1 * d->KS * d->KS * (double)d->N * d->OH * d->OW, head_bytes(d));
+  SG_HEAD_DISPATCH(head_fwd_kernel, x, w, part, g)
+  const int tot = d->N * d->OH * d->OW;
+  hipLaunchKernelGGL(head_fwd_finish_kernel, dim3(sg_cdiv(tot, 256)), dim3(256), 0, s, (const float*)part, bias, y, d->N,
+                     g.chunks, d->OH * d->OW, act, slope);
+  SG_LAUNCH_CHECK("sg_conv2d_head_fwd");
+  return 0;
+}
+
+extern "C" int sg_conv2d_head_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, sgStream stream) {
+  SG_ARG_CHECK(head_ok(d), "sg_conv2d_head_dgrad: unsupported desc");
+  SG_ARG_CHECK(gy && w && gx, "sg_conv2d_head_dgrad: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const HeadGeom g = head_geom(d);
+  const dim3 grid(g.chunks, d->N);
+  const int E = d->KS - 1;
+  const size_t lds = ((size_t)(d->OH + 2 * E) * (d->OW + 2 * E) + (size_t)g.CH * d->KS * d->KS) * sizeof(float);
+  SgProfScope prof(SG_K_HEAD, s, 2.0 * d->C1 * d->KS * d->KS * (double)d->N * d->OH * d->OW, head_bytes(d));
+  SG_HEAD_DISPATCH(head_dgrad_kernel, gy, w, gx, g)
+  SG_LAUNCH_CHECK("sg_conv2d_head_dgrad");
+  return 0;
+}
+
+extern "C" int sg_conv2d_head_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, void* ws, size_t ws_bytes,
+                                    sgStream stream) {
+  SG_ARG_CHECK(head_ok(d), "sg_conv2d_head_wgrad: unsupported desc");
+  SG_ARG_CHECK(gy && x && gw && ws && ws_bytes >= sg_conv2d_head_ws_bytes(d), "sg_conv2d_head_wgrad: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const HeadGeom g = head_geom(d);
+  float* part = reinterpret_cast<float*>(ws);
+  const dim3 grid(g.chunks, d->N);
+  const size_t lds = ((size_t)g.CH * g.PH * g.PW + 2 * (size_t)d->OH * d->OW) * sizeof(float);
+  const size_t nw = (size_t)d->C1 * d->KS * d->KS;
+  {
+    SgProfScope prof(SG_K_HEAD, s, 2.0 * d->C1 * d->KS * d->KS * (double)d->N * d->OH * d->OW, head_bytes(d));
+    SG_HEAD_DISPATCH(head_wgrad_kernel, gy, x, part, g)
+  }
+  hipLaunchKernelGGL(smallm_reduce_kernel, dim3(sg_cdiv(nw, 256)), dim3(256), 0, s, (const float*)part, gw, nw, d->N);
+  SG_LAUNCH_CHECK("sg_conv2d_head_wgrad");
+  return 0;
+}

@@ -224,7 +224,13 @@ class Conv2dFn(Function):
         y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=x1.device)
         ctx.smallm = x2 is None and sparse is None and bool(_q(d, 'sg_conv2d_smallm_supported'))
         ctx.wino = (x2 is None and sparse is None and WINOGRAD and bool(_q(d, 'sg_conv2d_wino_supported')))
-        if ctx.wino:                # ResnetBlock convs: Winograd F(2x2,3x3), 16 batched dense GEMMs
+        ctx.head = (x2 is None and sparse is None and HEADCONV and not ctx.wino and not ctx.smallm
+                    and bool(_q(d, 'sg_conv2d_head_supported')))
+        if ctx.head:                # one output channel (PatchGAN score maps, mask_net's 1x1 head): vector-ALU reduction
+            wsb = _q(d, 'sg_conv2d_head_ws_bytes')
+            _call('sg_conv2d_head_fwd', d._ref, _p(x1), _p(weight), _p(bias), _p(y), act, slope,
+                  _p(workspace(wsb, x1.device)), wsb, _stream())
+        elif ctx.wino:              # ResnetBlock convs: Winograd F(2x2,3x3), 16 batched dense GEMMs
             wsb = _q(d, 'sg_conv2d_wino_ws_bytes')
             _call('sg_conv2d_wino_fwd', d._ref, _p(x1), _p(weight), _p(bias), _p(y), act, slope,
                   _p(workspace(wsb, x1.device)), wsb, _stream())
@@ -279,6 +285,10 @@ class Conv2dFn(Function):
             folded = x2 is None and _q(d, 'sg_conv2d_dgrad_folded_supported')
 
             def dgrad(c0, c1):
+                if ctx.head and c0 == 0 and c1 == d.C1:
+                    out = torch.empty(d.N, d.C1, d.H, d.W, dtype=torch.float32, device=dev)
+                    _call('sg_conv2d_head_dgrad', d._ref, _p(gy), _p(weight), _p(out), s)
+                    return out
                 if ctx.wino and c0 == 0 and c1 == d.C1:     # Winograd on the padded gradient grid + reflection fold
                     out = torch.empty(d.N, d.C1, d.H, d.W, dtype=torch.float32, device=dev)
                     fb = _q(d, 'sg_conv2d_wino_ws_bytes')
@@ -316,7 +326,13 @@ class Conv2dFn(Function):
             if need_w:
                 gw = ow.buf
                 gb = ob.buf if need_b else None
-                if ctx.wino:
+                if ctx.head:
+                    wsb = max(_q(d, 'sg_conv2d_head_ws_bytes'), _L().sg_channel_sum_ws_bytes(d.Cout))
+                    ws = workspace(wsb, dev)
+                    _call('sg_conv2d_head_wgrad', d._ref, _p(gy), _p(x1), _p(gw), _p(ws), wsb, s)
+                    if gb is not None:
+                        _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb, s)
+                elif ctx.wino:
                     wsb = max(_q(d, 'sg_conv2d_wino_ws_bytes'), _L().sg_channel_sum_ws_bytes(d.Cout))
                     ws = workspace(wsb, dev)
                     _call('sg_conv2d_wino_wgrad', d._ref, _p(gy), _p(x1), _p(gw), _p(ws), wsb, s)
@@ -349,6 +365,8 @@ class Conv2dFn(Function):
         return gx1, gx2, gw, gb, None, None, None, None, None, None, None, None
 
 
+# single-output-channel convs on the vector ALUs (SG_HEADCONV=0: the 32x128 MFMA tile with one live row)
+HEADCONV = os.environ.get('SG_HEADCONV', '1') != '0'
 # Winograd F(2x2,3x3) for the ResnetBlock convs (SG_WINOGRAD=0 keeps them on the direct implicit-GEMM kernels)
 WINOGRAD = os.environ.get('SG_WINOGRAD', '1') != '0'
 # convs over a masks_to_layout() layout computed from its factored form (SG_FACTORED_LAYOUT=0: channel-sparse path instead)

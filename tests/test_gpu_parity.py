@@ -93,6 +93,10 @@ CONV_CASES = [
     (2, 3, 0, 32, 32, 64, 3, 1, 1, False, 1, 1),       # VGG conv1_1
     (2, 16, 0, 15, 17, 8, 3, 2, 1, False, 1, 0),       # stride-2 dgrad: four parity classes of different sizes in one launch
     (2, 8, 0, 12, 12, 24, 4, 2, 1, False, 1, 0),       # k4 s2 p1: equal classes
+    (3, 512, 0, 18, 18, 1, 4, 1, 2, False, 1, 0),      # PatchGAN score head (vector-ALU head kernels), full width
+    (4, 40, 0, 9, 11, 1, 4, 1, 2, False, 1, 2),        # head kernels: ragged channel chunk, non-square, fused LeakyReLU
+    (5, 64, 0, 8, 8, 1, 3, 1, 1, False, 1, 0),         # mask / object discriminator head (k3 p1)
+    (6, 192, 0, 32, 32, 1, 1, 1, 0, False, 1, 0),      # mask_net 1x1 head at full size
     (7, 24, 0, 1, 1, 24, 3, 1, 1, False, 2, 0),        # mask_net first octave: 1x1 -> 2x2 (sub-pixel transposed conv)
     (3, 16, 0, 5, 7, 12, 3, 1, 1, False, 2, 0),        # sub-pixel transposed conv, odd non-square plane, Cin != Cout
     (9, 192, 0, 16, 16, 192, 3, 1, 1, False, 2, 0),    # mask_net last octave at full width (192 channels, 16 -> 32)
@@ -745,6 +749,31 @@ def test_full_step_vs_reference_golden(hip, golden):
             for k, (s, a) in zip(g[pre + 'keys_' + mname].tolist(), g[pre + 'stats_' + mname]):
                 got = sd[k].double().abs().sum().item()
                 assert abs(got - a) <= 1e-2 * max(1.0, a), (it, mname, k, got, a)
+
+
+@pytest.mark.parametrize('tag', ['c2', 'c1'])
+def test_full_width_step_vs_reference_golden(hip, golden, tag):
+    """The HIP Trainer against the reference Trainer's own two iterations at DEFAULT widths (tests/golden/step_full_*.npz,
+    captured from trainer.py:205-325 / train.py:190-215 by tools/make_golden.py): BASELINE configs[1] shape (128x128, N = 8:
+    Winograd 128-tiles, factored layout convs, sub-pixel mask_net, every kernel family of the bench line) and configs[0]
+    (64x64, N = 4).  Tolerances ~2x the measured deviations (see tests/test_oracle_golden.py: iteration 1 follows a
+    sign-descent Adam step).  The measured numbers are written to gpurun_out/parity_step_full_<tag>.json first."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from step_full_common import run_step_full
+    from scene_generation_amd.trainer import Trainer
+    from scene_generation_amd.synthetic import batch_to
+
+    def make(args, vocab):
+        return Trainer(args, vocab, device=DEV)
+    devs = run_step_full(golden('step_full_' + tag), make, to_device=lambda b: batch_to(b, DEV))
+    _dump('parity_step_full_%s.json' % tag, [{k: (float(v) if not isinstance(v, str) else v) for k, v in d.items()} for d in devs])
+    tols = [dict(loss=2e-6, out_abs=1e-4, out_stat=2e-6, param_stat=5e-4),
+            dict(loss=1.5e-3, out_abs=0.1, out_stat=1.5e-3, param_stat=6e-4)]
+    for it, (dev, tol) in enumerate(zip(devs, tols)):
+        for k, t in tol.items():
+            assert dev[k] <= t, (tag, it, k, dev[k], t, dev)
 
 
 def _grad_snapshots(ref, tr):
