@@ -1,0 +1,92 @@
+// conv-style gathers: conv forward, transposed-conv data gradient, channel-sparse / per-image forward (see igemm_core.h / igemm.hip)
+#include "igemm_core.h"
+
+namespace {
+// ---- channel-sparse conv forward ---------------------------------------------------------------------
+// A masks_to_layout() layout has, per image, only the one-hot channels of the classes present plus the dense
+// representation block non-zero (model.py:165-168 of the reference builds it that way): ~40 of 204 channels.
+// Per image b the builder below makes a compact weight matrix Wc[b][m][k'] (k' = j*KS2 + t over the image's
+// active channels list[b][j], zero padded to Kc), the matching k-table, and the K extent; the regular kernel then
+// runs in batched mode (tiles never straddle images).
+__global__ void build_sparse_fwd_kernel(const float* W, int M, int K, int KS2, int C1, int C2, unsigned shw, int bcast2,
+                                        const int* list, const int* cnt, int L, int Kc, int Kpad, float* Wc,
+                                        KEntry* ktab, int* kcnt, int tail_valid, const float* Wimg) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = cnt[b];
+  if (i < M * Kc) {
+    const int m = i / Kc, k = i - m * Kc;
+    const int j = k / KS2, t = k - j * KS2;
+    float v = 0.f;
+    if (j < n) v = Wimg ? Wimg[(((size_t)b * M + m) * L + j) * KS2 + t] : W[(size_t)m * K + list[b * L + j] * KS2 + t];
+    Wc[((size_t)b * M + m) * Kc + k] = v;
+  }
+  if (i < Kpad) {
+    const int j = i / KS2, t = i - j * KS2;
+    KEntry e;
+    if (j < n) {
+      const int c = list[b * L + j];
+      const bool second = C2 > 0 && c >= C1;
+      const unsigned cc = (unsigned)(second ? c - C1 : c);
+      e.choff = (second && bcast2) ? cc : cc * shw;
+      e.tapsel = (unsigned)t | (second ? 256u : 0u);
+    } else {
+      e.choff = 0u; e.tapsel = tail_valid ? 0u : (unsigned)KS2;     // Wc is zero there
+    }
+    ktab[(size_t)b * Kpad + i] = e;
+  }
+  if (i == 0) kcnt[b] = ((n * KS2 + BK - 1) / BK) * BK;
+}
+
+
+template <int KS>
+int run_kn_sparse(const float* W, int M, int K, const Gather& g, int NB, const float* bias, float* out, int act,
+                  float slope, const Sparse& sp, void* ws, hipStream_t s) {
+  constexpr int KS2 = KS * KS;
+  const int PHW = g.PH * g.PW, Npix = NB * PHW;
+  const int Kc = sparse_kc(sp.L, KS2), Kpad = sparse_kpad(sp.L, KS2);
+  KEntry* ktab = reinterpret_cast<KEntry*>(ws);
+  float* Wc = reinterpret_cast<float*>(ktab + (size_t)NB * Kpad);
+  int* kcnt = reinterpret_cast<int*>(Wc + (size_t)NB * M * Kc);
+  int tile = pick_tile(M, Npix);
+  const int tBM = tile == 0 ? 128 : (tile == 2 ? 32 : 64), tBN = tile == 1 ? 64 : 128;
+  const bool nomask = g.reflect && (PHW % tBN == 0) && (M % tBM == 0);
+  {
+    const int work = M * Kc > Kpad ? M * Kc : Kpad;
+    hipLaunchKernelGGL(build_sparse_fwd_kernel, dim3(sg_cdiv(work, 256), NB), dim3(256), 0, s, W, M, K, KS2, g.C1, g.C2,
+                       (unsigned)(g.SH * g.SW), g.bcast2, sp.list, sp.cnt, sp.L, Kc, Kpad, Wc, ktab, kcnt, nomask ? 1 : 0,
+                       sp.wimg);
+  }
+  EpNCHW ep{out, bias, PHW, M, M, Npix, act, slope, 0, 0, 1, 0, 0, 0, 0};
+  // flops actually issued: the padded compact K of every image (bench.py prices the dominant kernel with this)
+  const double flops = 2.0 * M * (double)Kc * Npix;
+  t_batch = BatchInfo{}; t_batch.cols_per_batch = PHW; t_batch.nbatch = NB; t_batch.kcnt = kcnt; t_batch.a_stride = M * Kc; t_batch.b_stride = Kpad;
+  {
+    SgProfScope prof(sg_igemm_kind(0, KS, tile), s, flops, 0);
+    switch (tile) {
+      case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, 0>(Wc, Kc, M, true, g, Npix, ktab, ep, 1, nomask, s); break;
+      case 1: launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, 0>(Wc, Kc, M, true, g, Npix, ktab, ep, 1, nomask, s); break;
+      case 3: launch_ab<typename CfgFor<KS>::C64W, 64, 128, KS, 0>(Wc, Kc, M, true, g, Npix, ktab, ep, 1, nomask, s); break;
+      default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, 0>(Wc, Kc, M, true, g, Npix, ktab, ep, 1, nomask, s); break;
+    }
+  }
+  t_batch = BatchInfo{};
+  return 0;
+}
+
+}  // namespace
+
+int sgk::kn0_run(int KS, const float* A, int M, int K, const Gather& g, int NB, const float* bias, float* out, int Mtot, int act,
+                 float slope, double flops, void* ktab_ws, size_t ws_avail, hipStream_t s) {
+  return run_kn_ks<0>(KS, A, M, K, g, NB, bias, out, Mtot, act, slope, flops, ktab_ws, ws_avail, s);
+}
+int sgk::kn_sparse_run(int KS, const float* W, int M, int K, const Gather& g, int NB, const float* bias, float* out, int act,
+                       float slope, const Sparse& sp, void* ws, hipStream_t s) {
+  switch (KS) {
+    case 1: return run_kn_sparse<1>(W, M, K, g, NB, bias, out, act, slope, sp, ws, s);
+    case 3: return run_kn_sparse<3>(W, M, K, g, NB, bias, out, act, slope, sp, ws, s);
+    case 4: return run_kn_sparse<4>(W, M, K, g, NB, bias, out, act, slope, sp, ws, s);
+    case 7: return run_kn_sparse<7>(W, M, K, g, NB, bias, out, act, slope, sp, ws, s);
+  }
+  return -1;
+}

@@ -163,6 +163,8 @@ class GradOut(object):
             return self.buf
         sk = self.sink
         if self.mode == 1:
+            for f in getattr(sk.opt(), 'late_listeners', ()):      # e.g. GradReducer.late_contribution: may refuse
+                f(sk.i)
             _call('sg_axpy', _p(sk.view), _p(self.buf), 1.0, self.buf.numel(), _stream())
         if _CAPTURE is not None:
             _CAPTURE[1].append((sk.opt(), sk.i))

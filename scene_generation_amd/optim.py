@@ -72,6 +72,7 @@ class FusedAdam:
         self.pre_step_hooks = []          # e.g. GradReducer.wait
         self.zero_grad_hooks = []         # e.g. GradReducer.begin_step
         self.grad_listeners = []          # callables(i): parameter i just received (a contribution to) its gradient
+        self.late_listeners = []          # callables(i): parameter i is ABOUT to receive a second contribution this step
         for i, p in enumerate(self.fp.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
         if direct_grads and self.fp.flat.is_cuda:

@@ -168,18 +168,21 @@ class GradReducer:
         if not (self.active and self.armed and self.world > 1 and self.overlap):
             return
         if self._ready[i]:
-            # "final on first delivery" is an assumption about the owner (every parameter used once per step).  A second
-            # contribution is harmless while the bucket is still local, but once its all-reduce is in flight the late
-            # contribution would be added to a slice that is being -- or has been -- reduced: the ranks would diverge silently
-            if self._launched[self.bucket_of[i]]:
-                raise RuntimeError('GradReducer(overlap=True): parameter %d received another gradient contribution after its '
-                                   'bucket was sent to the all-reduce (tied / re-used parameter?): build the reducer with '
-                                   'overlap=False for this optimiser' % i)
-            return
+            return                   # a repeated REPORT (hooks may fire more than once); real late contributions: see below
         self._ready[i] = True
         self._pending[self.bucket_of[i]] -= 1
         while self._next < len(self.buckets) and self._pending[self._next] == 0:
             self._launch(self._next)
+
+    def late_contribution(self, i):
+        """Called (ops.GradOut.finish, through FusedAdam.late_listeners) BEFORE a second contribution is added to the gradient
+        slice of parameter ``i``.  "Final on first delivery" is an assumption about the owner (every parameter used once per
+        step): while the bucket is still local a later contribution is harmless, but once its all-reduce is in flight it
+        would be added to a slice that is being -- or has been -- reduced and the ranks would diverge silently."""
+        if self.active and self.armed and self.world > 1 and self.overlap and self._launched[self.bucket_of[i]]:
+            raise RuntimeError('GradReducer(overlap=True): parameter %d receives another gradient contribution after its '
+                               'bucket was sent to the all-reduce (tied / re-used parameter?): build the reducer with '
+                               'overlap=False for this optimiser' % i)
 
     def _launch(self, b):
         assert b == self._next

@@ -113,6 +113,7 @@ class Trainer:
                     # contributions per step (fake / real / wrong passes) and are reduced in wait() (<= 24 MB each)
                     r = GradReducer(opt.fp, optimizer=opt, overlap=opt is self.optimizer)
                     opt.grad_listeners.append(r.param_ready)
+                    opt.late_listeners.append(r.late_contribution)
                     opt.zero_grad_hooks.append(r.begin_step)
                     opt.pre_step_hooks.append(r.wait)
                     self.reducers.append(r)

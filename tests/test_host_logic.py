@@ -40,6 +40,46 @@ def test_argument_errors_are_reported_not_thrown():
     assert rc < 0 and b'kernel size' in lib.sg_last_error_string()
 
 
+def test_tensor_size_limit_of_the_buffer_load_masking():
+    """The gather loaders mask with the range check of raw buffer loads: byte offsets are 32 bits against num_records = 2^31
+    bytes, so an operand may hold at most 2^29 elements (up to 2^31 used to pass validation and would have read
+    zeros beyond 2 GiB).  Checked before any launch, so it runs without a device."""
+    lib = _hip.lib()
+    p8 = ctypes.c_void_p(8)
+
+    def fwd(N, C, H):
+        d = _hip.sgConvDesc(N, C, 0, H, H, 64, 1, 1, 0, 0, 1, H, H, 0, 0)      # 1x1 conv: no padded grid
+        return lib.sg_conv2d_fwd(ctypes.byref(d), p8, None, p8, None, p8, 0, 0.0, None, 1 << 20, None)
+    # 128 x 64 x 256 x 256 = 2^29 elements: the largest legal input (fails LATER, on the null workspace, not on the size)
+    assert fwd(128, 64, 256) < 0 and b'elements' not in lib.sg_last_error_string()
+    # one more image: rejected for its size
+    assert fwd(129, 64, 256) < 0 and b'elements' in lib.sg_last_error_string()
+    # dense layers: rows x features
+    assert lib.sg_linear_fwd(p8, p8, None, p8, 1 << 20, 1 << 10, 8, 0, 0.0, None) < 0
+    assert b'exceeds' in lib.sg_last_error_string()
+
+
+def test_late_gradient_contribution_is_refused_once_the_bucket_is_reduced():
+    """GradReducer(overlap=True) treats a parameter as final on its first delivery; a second CONTRIBUTION (ops.GradOut mode 1)
+    after the bucket went to the all-reduce must raise instead of letting the ranks diverge.  A repeated REPORT
+    of the same delivery stays a no-op."""
+    from scene_generation_amd.optim import FlatParams
+    from scene_generation_amd.parallel import GradReducer
+    fp = FlatParams([torch.nn.Parameter(torch.zeros(8)), torch.nn.Parameter(torch.zeros(8))])
+    red = GradReducer(fp, bucket_bytes=16)
+    red.world, red.overlap = 2, True              # pretend: two ranks (no process group is touched below)
+    launched = []
+    red._launch = lambda b: (launched.append(b), red._launched.__setitem__(b, True), setattr(red, '_next', b + 1))
+    red.begin_step()
+    red.late_contribution(1)                       # nothing launched yet: fine
+    red.param_ready(1)                             # reverse parameter order: bucket 0 holds parameter 1
+    assert launched == [0]
+    red.param_ready(1)                             # repeated report: no-op
+    with pytest.raises(RuntimeError, match='another gradient contribution'):
+        red.late_contribution(1)
+    red.late_contribution(0)                       # its bucket is still local
+
+
 def test_cpu_tensors_fail_loudly():
     from scene_generation_amd import ops
     with pytest.raises(RuntimeError, match='no CPU fallback'):
