@@ -34,8 +34,9 @@ def parse():
     p.add_argument('--batch_per_gpu', type=int, default=32)
     p.add_argument('--image_size', type=int, default=128)
     p.add_argument('--cpu_baseline', default='auto', choices=['auto', 'off'])
-    p.add_argument('--cpu_images', type=int, default=8)
+    p.add_argument('--cpu_images', type=int, default=32, help='images per CPU-baseline step (SURVEY 8d: config 2 at N = 32)')
     p.add_argument('--cpu_steps', type=int, default=3)
+    p.add_argument('--no_legs', action='store_true', help='skip the secondary config legs (c4: 256x256, c5: dense graphs)')
     p.add_argument('--no_prof', action='store_true')
     p.add_argument('--no_secondary', action='store_true', help='skip the secondary passes (default-flags step with the VGG '
                    'loss on; the step with every fast path off)')
@@ -130,12 +131,13 @@ def main():
     S, B = a.image_size, a.batch_per_gpu
     vocab = make_vocab()
 
-    def make_trainer(vgg_weight):
-        args = parser.parse_args(['--image_size', '%d,%d' % (S, S), '--batch_size', str(B * world),
+    def make_trainer(vgg_weight, size=None, batch=None, max_objs=8):
+        size, batch = size or S, batch or B
+        args = parser.parse_args(['--image_size', '%d,%d' % (size, size), '--batch_size', str(batch * world),
                                   '--vgg_features_weight', str(vgg_weight), '--output_dir', '/tmp/o'])
         torch.manual_seed(1234)                   # same initial weights on every rank (also broadcast in Trainer)
         tr = Trainer(args, vocab, device=dev, distributed=world > 1)
-        tr.model.layout_objects_hint = 9
+        tr.model.layout_objects_hint = max_objs + 1
         tr.share_d_forward = not a.no_share_d_forward
         tr.dense_layout_outputs = False           # nobody reads the three dense layouts here (TensorBoard-only outputs)
         return tr
@@ -148,21 +150,21 @@ def main():
     random.seed(0)                                # the use_gt coin (train.py:195): drawn on rank 0, broadcast (Trainer)
     torch.manual_seed(100 + rank)
 
-    def one_step(trainer, i):
-        db = staged[i % 2]
+    def one_step(trainer, i, batches=None):
+        db = (batches or staged)[i % 2]
         trainer.model.objs_host, trainer.model.obj_to_img_host = db.objs_host, db.obj_to_img_host
         trainer.step(db.batch, use_gt=trainer.draw_use_gt())      # train.py:195
 
     issue = [0.0]
 
-    def timed(trainer, n_steps, first):
+    def timed(trainer, n_steps, first, batches=None):
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n_steps):
-            one_step(trainer, first + i)
+            one_step(trainer, first + i, batches)
         issue[0] = time.perf_counter() - t0          # host done issuing; the GPU may still be working
         torch.cuda.synchronize()
         if world > 1:
@@ -204,6 +206,34 @@ def main():
     total = dict(tr.generator_losses.items())['total_loss']
     assert total == total and abs(total) < 1e6, 'non-finite generator loss %r' % total
 
+    # DP observability: isolated all-reduce time per bucket and how long the step was exposed to the collectives
+    comm = None
+    if world > 1:
+        comm = {}
+        for r in tr.reducers:
+            r.profile = True
+        d_obs = timed(tr, 3, a.warmup + 2 * a.steps + 3)
+        names = {id(tr.optimizer): 'G', id(tr.optimizer_d_img): 'D_img', id(tr.optimizer_d_obj): 'D_obj',
+                 id(tr.optimizer_d_mask): 'D_mask'}
+        iso_total, exposed_total = 0.0, 0.0
+        for r in tr.reducers:
+            exp_ms, n = r.exposed_ms()
+            r.profile = False
+            buckets = r.time_buckets()
+            iso = sum(ms for _, ms in buckets)
+            iso_total += iso
+            exposed_total += exp_ms / 3
+            comm[names.get(id(r.optimizer), '?')] = {
+                'buckets': len(buckets), 'bytes': sum(b for b, _ in buckets), 'overlap_mode': bool(r.overlap),
+                'isolated_allreduce_ms': round(iso, 3),
+                'per_bucket_ms': [round(ms, 3) for _, ms in buckets],
+                'algbw_GBps': round(sum(b for b, _ in buckets) / (iso * 1e-3) / 1e9, 1) if iso > 0 else None,
+                'exposed_ms_per_step': round(exp_ms / 3, 3)}
+        comm['exposed_ms_per_step'] = round(exposed_total, 3)
+        comm['isolated_ms_per_step'] = round(iso_total, 3)
+        comm['overlap_fraction'] = round(1.0 - exposed_total / iso_total, 3) if iso_total > 0 else None
+        comm['ms_per_step_observed'] = 1e3 * d_obs / 3
+
     out = {
         'metric': 'images/sec G+D step, 128x128 <=8-obj scene graphs', 'value': B * world * a.steps / dt,
         'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
@@ -226,20 +256,24 @@ def main():
     if world > 1:
         out['rccl_ranks'] = dist.get_world_size()
         out['dist_backend'] = backend
+        out['allreduce'] = comm
     if rank == 0 and not a.no_prof:
         prof = ops.prof_read()
-        mm = {k: v for k, v in prof.items() if v['launches'] > 0 and v['flops'] > 0 and k != 'linear'}
+        mm = {k: v for k, v in prof.items() if v['launches'] > 0 and v['flops'] > 0 and k not in ('linear', 'head_conv')}
         all_ms = sum(v['ms'] for v in prof.values())
         out['launches_per_step'] = sum(v['launches'] for v in prof.values()) / a.steps
         if mm:
             name, v = max(mm.items(), key=lambda kv: kv[1]['ms'])
             ach = v['flops'] / (v['ms'] * 1e-3) / 1e12 if v['ms'] > 0 else 0.0
             traffic, tsrc = None, None
-            tpath = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
-            if os.path.isfile(tpath):
-                tab = json.load(open(tpath)).get(name)
-                if tab:
-                    traffic, tsrc = tab.get('bytes_per_launch'), tab.get('source')
+            for tname in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
+                tpath = os.path.join(ROOT, 'profiles', tname)
+                if os.path.isfile(tpath):
+                    tab = json.load(open(tpath)).get(name)
+                    if tab:
+                        traffic = tab.get('bytes_per_launch')
+                        tsrc = 'STATIC (not measured in this run): profiles/%s -- %s' % (tname, tab.get('source'))
+                        break
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': ach / F32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': tsrc,
                                'kernel': name, 'instantiation': KERNEL_INSTANTIATIONS.get(name, name),
@@ -252,13 +286,33 @@ def main():
                                               % (a.steps, 1e3 * dt_prof / a.steps)}
             igms = sum(x['ms'] for x in mm.values())
             igfl = sum(x['flops'] for x in mm.values())
+            lin = prof.get('linear', {'flops': 0.0})
+            step_flops = (igfl + lin['flops']) / a.steps
             out['kernels'] = {
-                'all_mfma_gemms': {'ms_per_step': igms / a.steps, 'tflops': igfl / (igms * 1e-3) / 1e12 if igms else 0.0},
+                # every MFMA GEMM of the step together, and the step as a whole: FLOPs the matrix pipe really issued (Winograd
+                # and sub-pixel forms count their own, reduced, MACs) over the time of the GEMMs / of the whole step
+                'all_mfma_gemms': {'ms_per_step': igms / a.steps, 'tflops': igfl / (igms * 1e-3) / 1e12 if igms else 0.0,
+                                   'frac': igfl / (igms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS if igms else 0.0},
+                'step_mfma_frac': step_flops / (dt / a.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                'step_mfma_tflop': step_flops / 1e12,
                 'timed_kernels_ms_per_step': all_ms / a.steps,
                 'top': {k: {'ms_per_step': round(x['ms'] / a.steps, 3), 'launches_per_step': x['launches'] / a.steps,
                             'tflops': round(x['flops'] / (x['ms'] * 1e-3) / 1e12, 2) if x['ms'] and x['flops'] else None,
                             'gbs': round(x['bytes'] / (x['ms'] * 1e-3) / 1e9, 1) if x['ms'] and x['bytes'] else None}
                         for k, x in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])[:14] if x['launches']}}
+        # HBM-bound kernel classes: ALGORITHMIC bytes (what the op must read + write once) over the measured time
+        hbm = {}
+        for k in ('instnorm', 'instnorm_bwd', 'batchnorm', 'adam', 'wino_transforms', 'head_conv', 'crop', 'layout_fwd',
+                  'layout_bwd'):
+            x = prof.get(k)
+            if x and x['launches'] and x['bytes'] and x['ms']:
+                gbs = x['bytes'] / (x['ms'] * 1e-3) / 1e9
+                hbm[k] = {'launches_per_step': x['launches'] / a.steps, 'ms_per_step': round(x['ms'] / a.steps, 3),
+                          'avg_us': round(1e3 * x['ms'] / x['launches'], 2),
+                          'alg_bytes_per_launch': round(x['bytes'] / x['launches']), 'GBps': round(gbs, 1),
+                          'frac': round(gbs / HBM_PEAK_GBS, 3)}
+        out['roofline_hbm'] = {'peak_GBps': HBM_PEAK_GBS, 'note': 'algorithmic bytes / HIP-event time per launch; a kernel that '
+                               're-reads its input through L2 shows less than its real traffic rate', 'kernels': hbm}
     if world == 1 and not a.no_secondary:
         sec = {}
         n2 = max(2, min(a.steps, 6))
@@ -271,11 +325,38 @@ def main():
             sec['default_flags_vgg_on'] = {'images_per_s': B * n2 / d2, 'ms_per_step': 1e3 * d2 / n2, 'steps': n2,
                                            'note': '--vgg_features_weight 10 (args.py:73), He-normal VGG19 weights'}
             del tr2
-        # (2) every fast path off: direct convs instead of Winograd, dense 204-channel layout convs (channel-sparse),
+        # (2) Trainer.step's own defaults: fast paths on AND the three dense (N,204,H,W) layouts of Model.forward written
+        tr.dense_layout_outputs = True
+        one_step(tr, 0)
+        d4 = timed(tr, n2, 1)
+        tr.dense_layout_outputs = False
+        sec['fast_paths_on_dense_layouts'] = {'images_per_s': B * n2 / d4, 'ms_per_step': 1e3 * d4 / n2, 'steps': n2,
+                                              'note': 'headline configuration + dense_layout_outputs=True (3 x 428 MB written)'}
+        # the masks_to_layout kernel on its own: algorithmic bytes = 4 N D H W written + inputs
+        ops.prof_reset()
+        ops.prof_enable(True)
+        for i in range(2):
+            one_step(tr, i)
+        tr.dense_layout_outputs = True
+        for i in range(2):
+            one_step(tr, i)
+        tr.dense_layout_outputs = False
+        torch.cuda.synchronize()
+        ops.prof_enable(False)
+        lf = ops.prof_read().get('layout_fwd')
+        if lf and lf['launches']:
+            per = sorted([(lf['bytes'] / lf['launches'])])[0]
+            gbs = lf['bytes'] / (lf['ms'] * 1e-3) / 1e9
+            sec['masks_to_layout_fwd'] = {'launches': lf['launches'], 'avg_us': round(1e3 * lf['ms'] / lf['launches'], 2),
+                                          'alg_bytes_per_launch_mean': round(per), 'GBps': round(gbs, 1),
+                                          'frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 3),
+                                          'note': 'all launches of the kind in 4 eager steps (dense (N,204,H,W) layouts of the '
+                                                  'last two steps + the plane builders of the factored convs)'}
+        # (3) every fast path off: direct convs instead of Winograd, dense 204-channel layout convs (channel-sparse),
         #     discriminator forwards re-run in the D steps like the reference, dense layouts materialised
-        saved = (ops.WINOGRAD, ops.FACTORED_LAYOUT)
+        saved = (ops.WINOGRAD, ops.FACTORED_LAYOUT, ops.UPCONV, ops.HEADCONV)
         try:
-            ops.WINOGRAD = ops.FACTORED_LAYOUT = False
+            ops.WINOGRAD = ops.FACTORED_LAYOUT = ops.UPCONV = ops.HEADCONV = False
             tr3 = make_trainer(a.vgg)
             tr3.share_d_forward = False
             tr3.dense_layout_outputs = True
@@ -283,11 +364,52 @@ def main():
                 one_step(tr3, i)
             d3 = timed(tr3, n2, 4)
             sec['fast_paths_off'] = {'images_per_s': B * n2 / d3, 'ms_per_step': 1e3 * d3 / n2, 'steps': n2,
-                                     'note': 'SG_WINOGRAD=0 SG_FACTORED_LAYOUT=0 --no_share_d_forward, dense layouts written'}
+                                     'note': 'SG_WINOGRAD=0 SG_FACTORED_LAYOUT=0 SG_UPCONV=0 SG_HEADCONV=0 '
+                                             '--no_share_d_forward, dense layouts written'}
             del tr3
         finally:
-            ops.WINOGRAD, ops.FACTORED_LAYOUT = saved
+            ops.WINOGRAD, ops.FACTORED_LAYOUT, ops.UPCONV, ops.HEADCONV = saved
         out['secondary'] = sec
+    if world == 1 and not a.no_legs:
+        # the other BASELINE configs as secondary legs (parity-tested shapes; not the headline): c4 = configs[3] per-GPU shape
+        # (256x256, <= 16 objects, 8 images per GPU), c5 = configs[4] (32 objects / 96 triples per image, 128x128, N = 32:
+        # the GraphTripleConv scatter stress) with the graph kernels' own rates
+        from scene_generation_amd.synthetic import make_config_batch, CONFIGS
+        legs = {}
+        del tr
+        torch.cuda.empty_cache()
+        for name in ('c5', 'c4'):
+            cfg = CONFIGS[name]
+            trl = make_trainer(a.vgg, size=cfg['size'], batch=cfg['N'], max_objs=cfg['max_objs'])
+            hb = [make_config_batch(name, seed=2000 + i) for i in range(2)]
+            st = list(DeviceBatchPrefetcher(hb, dev))
+            for i in range(4):
+                one_step(trl, i, st)
+            nl = max(2, min(a.steps, 5))
+            dl = timed(trl, nl, 4, st)
+            leg = {'images_per_s': cfg['N'] * nl / dl, 'ms_per_step': 1e3 * dl / nl, 'steps': nl,
+                   'shape': '%dx%d, %d images, %d..%d objects/img, O=%d T=%d' % (
+                       cfg['size'], cfg['size'], cfg['N'], cfg['min_objs'], cfg['max_objs'], hb[0].objs.numel(),
+                       hb[0].triples.size(0))}
+            if not a.no_prof:
+                ops.prof_reset()
+                ops.prof_enable(True)
+                dp = timed(trl, 2, 4 + nl, st)
+                ops.prof_enable(False)
+                pr = ops.prof_read()
+                for k in ('linear', 'segsum'):
+                    x = pr.get(k)
+                    if x and x['launches'] and x['ms']:
+                        leg[k] = {'ms_per_step': round(x['ms'] / 2, 3), 'launches_per_step': x['launches'] / 2,
+                                  'tflops': round(x['flops'] / (x['ms'] * 1e-3) / 1e12, 2) if x['flops'] else None,
+                                  'GBps': round(x['bytes'] / (x['ms'] * 1e-3) / 1e9, 1) if x['bytes'] else None}
+                mmL = {k: v for k, v in pr.items() if v['launches'] and v['flops'] and k not in ('linear', 'head_conv')}
+                tms = sum(v['ms'] for v in mmL.values())
+                leg['all_mfma_gemms_tflops'] = round(sum(v['flops'] for v in mmL.values()) / (tms * 1e-3) / 1e12, 1) if tms else None
+            legs[name] = leg
+            del trl, st
+            torch.cuda.empty_cache()
+        out['legs'] = legs
     if rank == 0:
         if world == 1 and a.cpu_baseline == 'auto':
             try:

@@ -40,6 +40,7 @@ enum {
   // igemm_kn0_k3_t128 together with the direct 3x3 convs) and the elementwise Winograd transforms
   SG_K_WINO_GEMM_128, SG_K_WINO_GEMM_64, SG_K_WINO_XFORM,
   SG_K_HEAD,          // single-output-channel convolutions on the vector ALUs (smallm.hip), HBM-bound
+  SG_K_INSTNORM_BWD,
   SG_K_COUNT
 };
 static inline int sg_igemm_kind(int family, int KS, int tile) {

@@ -681,7 +681,7 @@ __global__ void wino_wgrad_output_kernel(const float* __restrict__ T, float* __r
 void wino_input_pc(const float* x, float* V, int N, int C, int H, int W, int TH, int TW, int off, int zero_pad, size_t Pstride,
                    int ush, hipStream_t s) {
   const int HW = H * W;
-  SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0);
+  SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)N * C * (H >> ush) * (W >> ush) + 16.0 * (double)Pstride * C));
   if (ush == 0 && HW <= 256 && HW % 4 == 0 && C % 64 == 0 && aligned16(x)) {
     const size_t lds = (size_t)64 * (HW + 1) * sizeof(float);
     if (lds > 48 * 1024)
@@ -788,16 +788,16 @@ extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const 
     float* UT = reinterpret_cast<float*>(ws);       // [16][C1][Cout]
     float* Ytp = UT + 16 * (size_t)M * K;           // [16][P][Cout]
     float* G = Ytp + 16 * P * K;                    // [P][16][C1]
-    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0);
+    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 25.0 * (double)M * K);
       wino_weight(w, UT, M, K, 2, s); }
-    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0);
+    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * K * HW + 16.0 * (double)P * K));
       const size_t lds = (size_t)64 * (HW + 1) * sizeof(float);
       if (lds > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_gy_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(wino_gy_small_kernel, dim3(K / 64, d->N), dim3(256), lds, s, gy, Ytp, d->N, K, d->H, d->W); }
     // G[p][xi*C1 + ci] = sum_co Ytp[xi][p][co] * UT[xi][ci][co]
     wino_bgemm(Ytp, UT, G, (int)P, M, K, 2.0 * M * (double)K * 16.0 * P, s);
-    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0);
+    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * (16.0 * (double)P * M + (double)d->N * M * HW));
       const size_t lds = (size_t)64 * ((d->H + 2) * (d->W + 2) + 1 + HW + 1) * sizeof(float);
       if (lds > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_patch_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -811,11 +811,11 @@ extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const 
   float* V = U + 16 * (size_t)M * K;                // [16][Pd][Cout]
   float* Mx = V + 16 * Pd * K;                      // [C1][16][Pd]
   float* gpad = Mx + 16 * Pd * M;                   // [N][C1][LH+2][LW+2] (reflect) / [N][C1][LH][LW] (upsample)
-  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); wino_weight(w, U, M, K, 1, s); }
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 25.0 * (double)M * K); wino_weight(w, U, M, K, 1, s); }
   wino_input_pc(gy, V, d->N, K, LH, LW, TH, TW, refl ? -2 : -1, 1, Pd, 0, s);
   wino_bgemm(U, V, Mx, M, (int)Pd, K, 2.0 * M * (double)K * 16.0 * ((double)d->N * TH * TW), s);   // flops of the real tiles
   const bool direct = !refl && d->upsample == 1;
-  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_output_kernel, dim3(sg_cdiv((size_t)d->N * TH * TW * M, 256)), dim3(256), 0, s, (const float*)Mx,
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * (16.0 * (double)Pd * M + (double)d->N * M * 4.0 * TH * TW)); hipLaunchKernelGGL(wino_output_kernel, dim3(sg_cdiv((size_t)d->N * TH * TW * M, 256)), dim3(256), 0, s, (const float*)Mx,
                      (const float*)nullptr, direct ? gx : gpad, d->N, M, 2 * TH, 2 * TW, Pd, SG_ACT_NONE, 0.f); }
   SG_LAUNCH_CHECK("sg_conv2d_wino_dgrad");
   if (direct) return 0;
@@ -833,10 +833,10 @@ extern "C" int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const flo
   float* U = reinterpret_cast<float*>(ws);
   float* V = U + 16 * (size_t)M * C;
   float* Mx = V + 16 * P * C;
-  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); wino_weight(w, U, M, C, 0, s); }
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 25.0 * (double)M * C); wino_weight(w, U, M, C, 0, s); }
   wino_input_pc(x, V, d->N, C, LH, LW, LH / 2, LW / 2, -1, d->pad_reflect ? 0 : 1, P, d->upsample == 2 ? 1 : 0, s);
   wino_bgemm(U, V, Mx, M, (int)P, C, 2.0 * M * (double)C * 16.0 * P, s);
-  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_output_kernel, dim3(sg_cdiv(P * M, 256)), dim3(256), 0, s, (const float*)Mx, bias, y, d->N, M, LH, LW, P,
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * (16.0 * (double)P * M + (double)d->N * M * LH * LW)); hipLaunchKernelGGL(wino_output_kernel, dim3(sg_cdiv(P * M, 256)), dim3(256), 0, s, (const float*)Mx, bias, y, d->N, M, LH, LW, P,
                      act, slope); }
   SG_LAUNCH_CHECK("sg_conv2d_wino_fwd");
   return 0;
@@ -853,11 +853,11 @@ extern "C" int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const 
   float* T = reinterpret_cast<float*>(ws);          // [M][16][C]
   float* Vp = T + 16 * (size_t)M * C;               // [16][C][P]
   float* Yt = Vp + 16 * P * C;                      // [16][M][P]
-  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_input_kernel<1>, dim3(sg_cdiv(P * C, 256)), dim3(256), 0, s, x, Vp, d->N, C, LH, LW, LH / 2, LW / 2, -1,
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * C * d->H * d->W + 16.0 * (double)P * C)); hipLaunchKernelGGL(wino_input_kernel<1>, dim3(sg_cdiv(P * C, 256)), dim3(256), 0, s, x, Vp, d->N, C, LH, LW, LH / 2, LW / 2, -1,
                      d->pad_reflect ? 0 : 1, P, d->upsample == 2 ? 1 : 0); }
-  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_gy_kernel, dim3(sg_cdiv(P * M, 256)), dim3(256), 0, s, gy, Yt, d->N, M, LH, LW); }
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * M * LH * LW + 16.0 * (double)P * M)); hipLaunchKernelGGL(wino_gy_kernel, dim3(sg_cdiv(P * M, 256)), dim3(256), 0, s, gy, Yt, d->N, M, LH, LW); }
   wino_bgemm(Yt, Vp, T, M, C, (int)P, 2.0 * M * (double)C * 16.0 * P, s);
-  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 0); hipLaunchKernelGGL(wino_wgrad_output_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, (const float*)T, gw, M, C); }
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 25.0 * (double)M * C); hipLaunchKernelGGL(wino_wgrad_output_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, (const float*)T, gw, M, C); }
   SG_LAUNCH_CHECK("sg_conv2d_wino_wgrad");
   return 0;
 }

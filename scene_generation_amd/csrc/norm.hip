@@ -517,7 +517,7 @@ extern "C" int sg_instnorm_fwd(const float* x, const float* skip, float* y, floa
                                float eps, int act, float slope, sgStream stream) {
   SG_ARG_CHECK(x && y && mean && rstd && NC > 0 && HW > 0, "sg_instnorm_fwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  SgProfScope prof(SG_K_INSTNORM, s, 0, (double)NC * HW * 4.0 * (skip ? 5 : 4));
+  SgProfScope prof(SG_K_INSTNORM, s, 0, (double)NC * HW * 4.0 * (skip ? 3 : 2));      // algorithmic: x (+ skip) in, y out
   if (HW <= 1024) hipLaunchKernelGGL(instnorm_fwd_kernel<true>, dim3(sg_cdiv(NC, 4)), dim3(256), 0, s, x, skip, y, mean, rstd, NC, HW, eps, act, slope);
   else hipLaunchKernelGGL(instnorm_fwd_kernel<false>, dim3(NC), dim3(256), 0, s, x, skip, y, mean, rstd, NC, HW, eps, act, slope);
   SG_LAUNCH_CHECK("sg_instnorm_fwd");
@@ -528,7 +528,7 @@ extern "C" int sg_instnorm_bwd(const float* x, const float* gy, const float* mea
                                int HW, int act, float slope, sgStream stream) {
   SG_ARG_CHECK(x && gy && mean && rstd && gx && NC > 0 && HW > 0, "sg_instnorm_bwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  SgProfScope prof(SG_K_INSTNORM, s, 0, (double)NC * HW * 4.0 * 5);
+  SgProfScope prof(SG_K_INSTNORM_BWD, s, 0, (double)NC * HW * 4.0 * 3);      // algorithmic: x, gy in, gx out
   if (HW <= 1024) hipLaunchKernelGGL(instnorm_bwd_kernel<true>, dim3(sg_cdiv(NC, 4)), dim3(256), 0, s, x, gy, mean, rstd, gx, NC, HW, act, slope);
   else hipLaunchKernelGGL(instnorm_bwd_kernel<false>, dim3(NC), dim3(256), 0, s, x, gy, mean, rstd, gx, NC, HW, act, slope);
   SG_LAUNCH_CHECK("sg_instnorm_bwd");
@@ -547,7 +547,7 @@ extern "C" int sg_batchnorm_fwd(const float* x, const float* gamma, const float*
   SG_ARG_CHECK(training || (running_mean && running_var), "sg_batchnorm_fwd: eval mode needs running stats");
   SG_ARG_CHECK(!training || (ws && ws_bytes >= sg_batchnorm_ws_bytes(N, C, HW)), "sg_batchnorm_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  SgProfScope prof(SG_K_BATCHNORM, s, 0, (double)N * C * HW * 16.0);
+  SgProfScope prof(SG_K_BATCHNORM, s, 0, (double)N * C * HW * 8.0);       // algorithmic: x in, y out
   const int S = bn_slices(N, C, HW);
   float* part = reinterpret_cast<float*>(ws);
   if (training) hipLaunchKernelGGL(bn_stats_kernel, dim3(C, S), dim3(256), 0, s, x, part, N, C, HW, S);
@@ -570,7 +570,7 @@ extern "C" int sg_batchnorm_bwd(const float* x, const float* gy, const float* ga
   SG_ARG_CHECK(x && gy && save_mean && save_rstd && gx && N > 0 && C > 0 && HW > 0, "sg_batchnorm_bwd: bad arguments");
   SG_ARG_CHECK(ws && ws_bytes >= sg_batchnorm_ws_bytes(N, C, HW), "sg_batchnorm_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  SgProfScope prof(SG_K_BATCHNORM, s, 0, (double)N * C * HW * 20.0);
+  SgProfScope prof(SG_K_BATCHNORM, s, 0, (double)N * C * HW * 12.0);      // algorithmic: x, gy in, gx out
   const int S = bn_slices(N, C, HW);
   float* part = reinterpret_cast<float*>(ws);
   float* sums = part + (size_t)C * S * 3;

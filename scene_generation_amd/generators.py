@@ -75,16 +75,29 @@ class GlobalGenerator(nn.Module):
         seq += [ReflectionPad2d(3), Conv2d(widths[0], output_nc, kernel_size=7, padding=0), Tanh()]
         self.model = FusedSequential(*seq)
         # everything behind the first convolution has static shapes (N x ngf x H x W in, the image out) whatever the scene
-        # graphs look like: replayed as one hipGraph forward and one backward (graphs.py); the stem sees the per-batch
-        # object lists (factored layout conv) and stays eager.  Only the image is handed out as a copy: callers keep it
-        # across iterations (train.py:203,219)
+        # graphs look like: replayed as hipGraphs (graphs.py); the stem sees the per-batch object lists (factored layout
+        # conv) and stays eager.  The remainder is cut into up to three segments at residual-block boundaries, each with
+        # its own forward / backward graph: the backward then hands its parameter gradients to the optimiser -- and, under
+        # data parallelism, to the bucketed all-reduce -- segment by segment (last third of the network first) instead of
+        # all at once behind one monolithic replay.  Only the image is handed out as a copy: callers keep it across
+        # iterations (train.py:203,219)
         from .graphs import GraphedSegment
-        self._tail = GraphedSegment(self._run_tail, params=[p for m in list(self.model)[2:] for p in m.parameters()],
-                                    clone_outputs=True, name='GlobalGenerator[2:]')
+        mods = list(self.model)
+        blocks = [i for i, m in enumerate(mods) if isinstance(m, ResnetBlock)]
+        cuts = [2]
+        if len(blocks) >= 3:
+            cuts += [blocks[len(blocks) // 3], blocks[(2 * len(blocks)) // 3]]
+        cuts.append(len(mods))
+        self._tail_cuts = cuts
+        self._tail = [GraphedSegment(self._runner(a, b), params=[p for m in mods[a:b] for p in m.parameters()],
+                                     clone_outputs=(b == len(mods)), name='GlobalGenerator[%d:%d]' % (a, b), modules=mods[a:b])
+                      for a, b in zip(cuts[:-1], cuts[1:])]
 
-    def _run_tail(self, h):
-        return self.model(h, start=2)
+    def _runner(self, a, b):
+        return lambda h: self.model(h, start=a, end=b)
 
     def forward(self, input):
         h = self.model(input, end=2)          # ReflectionPad2d(3) + Conv7x7 over the layout
-        return self._tail(h)
+        for seg in self._tail:
+            h = seg(h)
+        return h

@@ -140,6 +140,10 @@ class GradReducer:
                 self.bucket_of[i] = b
         self.active = True
         self.armed = False
+        # observability (bench.py --gpus N): with ``profile`` on, wait() brackets its blocking part with an event pair on the
+        # compute stream -- the time the step is EXPOSED to the collectives (0 when they finished under other work)
+        self.profile = False
+        self._stall_events = []
         self._reset()
         if self.world > 1 and overlap:
             for i, p in enumerate(self.fp.params):
@@ -202,8 +206,15 @@ class GradReducer:
         if self.world > 1 and self.active:
             while self._next < len(self.buckets):        # (also when nobody armed the reducer: hooks were ignored)
                 self._launch(self._next)
+            timed = self.profile and self.fp.grad.is_cuda
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             for w in self._works:
                 w.wait()
+            if timed:
+                e1.record()
+                self._stall_events.append((e0, e1))
             self.fp.grad.mul_(1.0 / self.world)
             opt = self.optimizer
             if opt is not None:                          # every rank must update the same parameters
@@ -212,6 +223,43 @@ class GradReducer:
                 opt._touched = [bool(v) for v in flags]
         self.armed = False
         self._reset()
+
+    def exposed_ms(self, reset=True):
+        """(total, count): milliseconds the compute stream spent blocked on this reducer's collectives since the last call"""
+        tot = 0.0
+        for e0, e1 in self._stall_events:
+            e1.synchronize()
+            tot += e0.elapsed_time(e1)
+        n = len(self._stall_events)
+        if reset:
+            self._stall_events = []
+        return tot, n
+
+    def time_buckets(self, repeats=3):
+        """isolated duration of each bucket's all-reduce (nothing else on the GPU): [(bytes, ms)] in launch order.  Collective:
+        call on every rank.  The gradient buffer is scratch between steps (zero_grad() precedes every backward)."""
+        out = []
+        esz = self.fp.grad.element_size()
+        for s_, e_, _ in self.buckets:
+            buf = self.fp.grad[s_:e_]
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)      # warm-up (connection set-up on first use)
+            if buf.is_cuda:
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(repeats):
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1) / repeats
+            else:
+                import time
+                t0 = time.perf_counter()
+                for _ in range(repeats):
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+                ms = 1e3 * (time.perf_counter() - t0) / repeats
+            out.append(((e_ - s_) * esz, ms))
+        return out
 
     def _agree_in_group(self, touched):
         flags = torch.tensor([1.0 if t else 0.0 for t in touched], dtype=torch.float32, device=self.fp.grad.device)

@@ -1,5 +1,6 @@
-"""Data parallelism through the REAL HIP Trainer on one GPU: two ranks share cuda:0 (gloo moves the gradient slices), each
-trains on its shard of one batch.  Checks (SURVEY 8e semantics: "the reference run independently on each shard, gradients
+"""Data parallelism through the REAL HIP Trainer: two ranks, each trains on its shard of one batch.  backend 'gloo': both
+ranks share cuda:0 (gloo moves the gradient slices; runs on a 1-GPU box); backend 'nccl' (= RCCL over xGMI): one GPU per
+rank, auto-skipped when fewer than two devices are visible -- the first multi-GPU run of the suite exercises RCCL itself.  Checks (SURVEY 8e semantics: "the reference run independently on each shard, gradients
 averaged"): (1) the all-reduced generator / discriminator gradients of the first step equal the mean of the per-shard
 gradients of two single-process trainers; (2) after two full G+D steps (use_gt on, then off: box_net is skipped by Adam in
 the second one on EVERY rank) all four optimisers hold bit-identical parameters on both ranks."""
@@ -21,11 +22,11 @@ ARGV = ['--image_size', '32,32', '--batch_size', '4', '--vgg_features_weight', '
 OPTS = ('optimizer', 'optimizer_d_mask', 'optimizer_d_obj', 'optimizer_d_img')
 
 
-def _make(distributed):
+def _make(distributed, device='cuda:0'):
     from scene_generation_amd.args import parser
     from scene_generation_amd.synthetic import make_vocab, fill_deterministic
     from scene_generation_amd.trainer import Trainer
-    tr = Trainer(parser.parse_args(ARGV), make_vocab(12, 4, 35), device='cuda:0', distributed=distributed)
+    tr = Trainer(parser.parse_args(ARGV), make_vocab(12, 4, 35), device=device, distributed=distributed)
     for m in (tr.model, tr.netD, tr.obj_discriminator, tr.mask_discriminator):
         fill_deterministic(m)
     tr.model.noise_override = torch.linspace(-1, 1, 64).view(1, -1)
@@ -41,17 +42,18 @@ def _batch():
     return make_batch(N=4, min_objs=2, max_objs=4, size=32, mask_size=8, num_objs=12, num_preds=4, seed=7)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY='0')
     import torch.distributed as dist
     from scene_generation_amd.synthetic import shard_batch, batch_to
-    torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    tr, grads = _make(True)
+    dev = 'cuda:%d' % (rank if backend == 'nccl' else 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    tr, grads = _make(True, dev)
     if rank == 1:                                    # the broadcast at construction already happened: perturbing now would
         pass                                         # desynchronise on purpose; nothing to do
-    shard = batch_to(shard_batch(_batch(), rank, world), 'cuda:0')
+    shard = batch_to(shard_batch(_batch(), rank, world), dev)
     random.seed(100 + rank)                          # different local RNG streams: the coin must still agree
     coins = []
     for it in range(2):
@@ -74,15 +76,18 @@ def _free_port():
     return p
 
 
-def test_two_rank_hip_trainer_matches_sequential_shards():
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
+def test_two_rank_hip_trainer_matches_sequential_shards(backend):
     import numpy as np
     import torch.multiprocessing as mp
     from scene_generation_amd.synthetic import shard_batch, batch_to
+    if backend == 'nccl' and torch.cuda.device_count() < 2:
+        pytest.skip('RCCL needs one GPU per rank: %d visible' % torch.cuda.device_count())
     world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])

@@ -1382,7 +1382,9 @@ def test_graphed_segments_are_bit_identical_to_eager(hip):
                 hist.append((losses, out[0].detach().clone()))
             if enabled:
                 tail = tr.model.layout_to_image._tail
-                assert any(e not in (None, False) for e in tail.entries.values()), 'the generator tail was never captured'
+                assert len(tail) == 3, 'the generator tail is cut into three graphed segments at residual-block boundaries'
+                for seg in tail:
+                    assert any(e not in (None, False) for e in seg.entries.values()), '%s was never captured' % seg.name
                 assert any(e not in (None, False) for e in tr.criterionVGG.vgg._graphed.entries.values())
             flat = torch.cat([getattr(tr, n).fp.flat for n in ('optimizer', 'optimizer_d_mask', 'optimizer_d_obj',
                                                               'optimizer_d_img')]).clone()
