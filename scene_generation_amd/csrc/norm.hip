@@ -3,6 +3,7 @@
 // nn.AvgPool2d(3,2,1,count_include_pad=False) (discriminators.py:100,186), GlobalAvgPool (layers.py:82-85)
 // and the activation modules fused behind them.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -73,6 +74,135 @@ __global__ void __launch_bounds__(256) instnorm_bwd_kernel(const float* __restri
     op[i] = rstd * (g - m1 - z * m2);
   }
 }
+
+// ---------------- InstanceNorm, register-resident form --------------------------------------------------------------------
+// A group of G threads owns one plane and keeps ALL of it in registers (E = ceil(HW / G) <= 64 elements per thread): every load
+// of the plane is issued before the first use, the mean / variance are the same two passes as above but over registers, and
+// the plane is read from memory exactly once.  (The loops above read it three times, one dependent 4-byte load per lane at a
+// time: 0.26 / 0.31 of the HBM peak on the algorithmic bytes.)  G = 16 (planes <= 64 elements: 16 planes per workgroup),
+// 64 (one wave per plane), 256 / 1024 (one workgroup per plane).
+template <int G>
+__device__ __forceinline__ float group_sum(float v, float* red) {
+  if constexpr (G == 16) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  } else if constexpr (G == 64) {
+    return sg_wave_sum(v);
+  } else {
+    return sg_block_sum(v, red);
+  }
+}
+
+template <int G, int E>
+__global__ void __launch_bounds__(G > 256 ? G : 256) instnorm_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ skip,
+                                                                            float* __restrict__ y, float* __restrict__ mean_o,
+                                                                            float* __restrict__ rstd_o, int NC, int HW, float eps,
+                                                                            int act, float slope) {
+  __shared__ float red[16];
+  constexpr int PPB = G >= 256 ? 1 : 256 / G;          // planes per workgroup
+  const int tg = threadIdx.x % G;
+  const int plane = blockIdx.x * PPB + threadIdx.x / G;
+  const bool live = plane < NC;                        // (whole groups: no divergence inside a reduction)
+  const size_t base = (size_t)(live ? plane : 0) * HW;
+  float v[E];
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const int i = tg + G * j;
+    v[j] = (live && i < HW) ? x[base + i] : 0.f;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < E; ++j) s += v[j];
+  s = group_sum<G>(s, red);
+  const float mean = s / (float)HW;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const float d = v[j] - mean;
+    q += (tg + G * j < HW) ? d * d : 0.f;
+  }
+  q = group_sum<G>(q, red);
+  const float rstd = 1.f / sqrtf(q / (float)HW + eps);
+  if (!live) return;
+  if (tg == 0) { mean_o[plane] = mean; rstd_o[plane] = rstd; }
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const int i = tg + G * j;
+    if (i < HW) {
+      float o = sg_apply_act((v[j] - mean) * rstd, act, slope);
+      if (skip) o += skip[base + i];
+      y[base + i] = o;
+    }
+  }
+}
+
+template <int G, int E>
+__global__ void __launch_bounds__(G > 256 ? G : 256) instnorm_bwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                            const float* __restrict__ mean_i,
+                                                                            const float* __restrict__ rstd_i, float* __restrict__ gx,
+                                                                            int NC, int HW, int act, float slope) {
+  __shared__ float red[16];
+  constexpr int PPB = G >= 256 ? 1 : 256 / G;
+  const int tg = threadIdx.x % G;
+  const int plane = blockIdx.x * PPB + threadIdx.x / G;
+  const bool live = plane < NC;
+  const size_t base = (size_t)(live ? plane : 0) * HW;
+  const float mean = mean_i[live ? plane : 0], rstd = rstd_i[live ? plane : 0];
+  float z[E], g[E];
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const int i = tg + G * j;
+    const bool ok = live && i < HW;
+    z[j] = ok ? x[base + i] : mean;
+    g[j] = ok ? gy[base + i] : 0.f;
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    z[j] = (z[j] - mean) * rstd;
+    g[j] *= act_grad_from_pre(z[j], act, slope);
+    s1 += g[j]; s2 += g[j] * z[j];
+  }
+  s1 = group_sum<G>(s1, red);
+  s2 = group_sum<G>(s2, red);
+  if (!live) return;
+  const float inv = 1.f / (float)HW;
+  const float m1 = s1 * inv, m2 = s2 * inv;
+#pragma unroll
+  for (int j = 0; j < E; ++j) {
+    const int i = tg + G * j;
+    if (i < HW) gx[base + i] = rstd * (g[j] - m1 - z[j] * m2);
+  }
+}
+
+// (G, E) for a plane of HW elements, or G = 0 when it does not fit 64 registers per thread
+inline void instnorm_shape(int HW, int maxE, int& G, int& E) {
+  G = HW <= 64 ? 16 : (HW <= 1024 ? 64 : (HW <= 256 * maxE ? 256 : (HW <= 1024 * maxE ? 1024 : 0)));
+  if (G == 0) { E = 0; return; }
+  const int e = (HW + G - 1) / G;
+  E = e <= 1 ? 1 : (e <= 2 ? 2 : (e <= 4 ? 4 : (e <= 8 ? 8 : (e <= 16 ? 16 : (e <= 32 ? 32 : 64)))));
+}
+
+#define SG_IN_CASE(KERNEL, Gv, Ev, ...)                                                                              \
+  hipLaunchKernelGGL((KERNEL<Gv, Ev>), dim3(sg_cdiv(NC, Gv >= 256 ? 1 : 256 / Gv)), dim3(Gv > 256 ? Gv : 256), 0, s, __VA_ARGS__)
+#define SG_IN_DISPATCH_E(KERNEL, Gv, ...)                                \
+  switch (E) {                                                           \
+    case 1: SG_IN_CASE(KERNEL, Gv, 1, __VA_ARGS__); break;               \
+    case 2: SG_IN_CASE(KERNEL, Gv, 2, __VA_ARGS__); break;               \
+    case 4: SG_IN_CASE(KERNEL, Gv, 4, __VA_ARGS__); break;               \
+    case 8: SG_IN_CASE(KERNEL, Gv, 8, __VA_ARGS__); break;               \
+    case 16: SG_IN_CASE(KERNEL, Gv, 16, __VA_ARGS__); break;             \
+    case 32: SG_IN_CASE(KERNEL, Gv, 32, __VA_ARGS__); break;             \
+    default: SG_IN_CASE(KERNEL, Gv, 64, __VA_ARGS__); break;             \
+  }
+#define SG_IN_DISPATCH(KERNEL, ...)                                       \
+  switch (G) {                                                            \
+    case 16: SG_IN_DISPATCH_E(KERNEL, 16, __VA_ARGS__) break;             \
+    case 64: SG_IN_DISPATCH_E(KERNEL, 64, __VA_ARGS__) break;             \
+    case 256: SG_IN_DISPATCH_E(KERNEL, 256, __VA_ARGS__) break;           \
+    default: SG_IN_DISPATCH_E(KERNEL, 1024, __VA_ARGS__) break;           \
+  }
 
 // ---------------- BatchNorm2d: one block per channel ---------------------------------------------
 // ---- BatchNorm2d (+ fused activation), three stages so that a 64..256-channel layer fills the chip ---------------------
@@ -518,7 +648,13 @@ extern "C" int sg_instnorm_fwd(const float* x, const float* skip, float* y, floa
   SG_ARG_CHECK(x && y && mean && rstd && NC > 0 && HW > 0, "sg_instnorm_fwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   SgProfScope prof(SG_K_INSTNORM, s, 0, (double)NC * HW * 4.0 * (skip ? 3 : 2));      // algorithmic: x (+ skip) in, y out
-  if (HW <= 1024) hipLaunchKernelGGL(instnorm_fwd_kernel<true>, dim3(sg_cdiv(NC, 4)), dim3(256), 0, s, x, skip, y, mean, rstd, NC, HW, eps, act, slope);
+  static int reg = -1;
+  if (reg < 0) { const char* e = getenv("SG_INSTNORM_REG"); reg = e ? atoi(e) : 1; }      // 0: the three-pass kernels
+  int G = 0, E = 0;
+  instnorm_shape(HW, 64, G, E);
+  if (reg && G > 0) {
+    SG_IN_DISPATCH(instnorm_fwd_reg_kernel, x, skip, y, mean, rstd, NC, HW, eps, act, slope)
+  } else if (HW <= 1024) hipLaunchKernelGGL(instnorm_fwd_kernel<true>, dim3(sg_cdiv(NC, 4)), dim3(256), 0, s, x, skip, y, mean, rstd, NC, HW, eps, act, slope);
   else hipLaunchKernelGGL(instnorm_fwd_kernel<false>, dim3(NC), dim3(256), 0, s, x, skip, y, mean, rstd, NC, HW, eps, act, slope);
   SG_LAUNCH_CHECK("sg_instnorm_fwd");
   return 0;
@@ -529,7 +665,13 @@ extern "C" int sg_instnorm_bwd(const float* x, const float* gy, const float* mea
   SG_ARG_CHECK(x && gy && mean && rstd && gx && NC > 0 && HW > 0, "sg_instnorm_bwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   SgProfScope prof(SG_K_INSTNORM_BWD, s, 0, (double)NC * HW * 4.0 * 3);      // algorithmic: x, gy in, gx out
-  if (HW <= 1024) hipLaunchKernelGGL(instnorm_bwd_kernel<true>, dim3(sg_cdiv(NC, 4)), dim3(256), 0, s, x, gy, mean, rstd, gx, NC, HW, act, slope);
+  static int reg = -1;
+  if (reg < 0) { const char* e = getenv("SG_INSTNORM_REG"); reg = e ? atoi(e) : 1; }
+  int G = 0, E = 0;
+  instnorm_shape(HW, 32, G, E);                        // (two register arrays: 2 x 32 values per thread at most)
+  if (reg && G > 0) {
+    SG_IN_DISPATCH(instnorm_bwd_reg_kernel, x, gy, mean, rstd, gx, NC, HW, act, slope)
+  } else if (HW <= 1024) hipLaunchKernelGGL(instnorm_bwd_kernel<true>, dim3(sg_cdiv(NC, 4)), dim3(256), 0, s, x, gy, mean, rstd, gx, NC, HW, act, slope);
   else hipLaunchKernelGGL(instnorm_bwd_kernel<false>, dim3(NC), dim3(256), 0, s, x, gy, mean, rstd, gx, NC, HW, act, slope);
   SG_LAUNCH_CHECK("sg_instnorm_bwd");
   return 0;
