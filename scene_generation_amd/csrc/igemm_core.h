@@ -393,34 +393,54 @@ struct LoadGatherKN {
   }
 };
 
+// k -> (image, pixel) tables of the weight-gradient loaders.  k = img*PQ + pix walks every pixel of every image; splitting it
+// costs a division, and the gather side needs a 2-D decode plus padding / reflection on top (~50 VALU instructions).  Done
+// per 16-pixel k-tile by a few lanes it sat in EVERY wave's instruction stream (61 VALU per 8 MFMA in the 64x64 kernel: the
+// f32 MFMA does not overlap with VALU work, measured with tools/probe/mfma_valu_coexec.hip).  Instead all 256 threads decode
+// a BLOCK of 256 pixels at once into a double-buffered LDS table when the k-loop crosses a block boundary (prefetch() runs
+// >= 1 barrier ahead of the loads that read it): 1/16 of the instructions per k-tile, and a gathered element costs one
+// LDS read + one add.
+constexpr int KBLK = 256;
+
 // A operand of wgrad, vector form (PQ % 4 == 0, 16-byte aligned base): each thread moves one float4 of four
 // consecutive pixels of one row: 1 global_load_dwordx4 + 1 ds_write_b128 per 4 elements
 template <int BM>
 struct LoadPixKVec {
   const float* base; int M, Mtot, PQ; FastDiv dPQ;
-  static constexpr int LDS_INTS = 0;
+  static constexpr int LDS_INTS = 2 * KBLK;
   static constexpr int Q = (BM * 4 + 255) / 256;
   struct Stage { float4 r[Q]; unsigned ok; };
-  int m0_, row_, kq_;
-  __device__ __forceinline__ void init(int m0, int tid, int*, int, int) { m0_ = m0; row_ = tid >> 2; kq_ = (tid & 3) * 4; }
-  __device__ __forceinline__ void set_batch(int, int, int) {}
-  __device__ __forceinline__ void prefetch(Stage&, int) const {}
-  __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
-    const int k = k0 + kq_;
-    const bool kok = k < kend;
-    const unsigned kk = kok ? (unsigned)k : 0u;
-    const unsigned img = dPQ.div(kk), pix = kk - img * (unsigned)PQ;
-    const unsigned p0 = img * (unsigned)Mtot * (unsigned)PQ + pix;
-    st.ok = 0;
+  int row_, kq_, tid_, kbeg_, kend_;
+  unsigned rowoff_[Q];
+  int* lds_;
+  __device__ __forceinline__ void init(int m0, int tid, int* lds, int kbeg, int kend) {
+    row_ = tid >> 2; kq_ = (tid & 3) * 4; tid_ = tid; lds_ = lds; kbeg_ = kbeg; kend_ = kend;
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
-      const int m = m0_ + row_ + 64 * i;
-      const bool ok = kok && m < M && (row_ + 64 * i < BM);
+      // rows beyond M read the last valid row: their products land in accumulator rows the epilogue never stores
+      const int m = min(m0 + row_ + 64 * i, M - 1);
+      rowoff_[i] = (unsigned)m * (unsigned)PQ;
+    }
+  }
+  __device__ __forceinline__ void set_batch(int, int, int) {}
+  __device__ __forceinline__ void prefetch(Stage&, int k0) const {
+    const int rel = k0 - kbeg_;
+    if ((rel & (KBLK - 1)) != 0) return;
+    const int k = k0 + tid_;
+    const unsigned kk = k < kend_ ? (unsigned)k : 0u;
+    const unsigned img = dPQ.div(kk), pix = kk - img * (unsigned)PQ;
+    lds_[((rel / KBLK) & 1) * KBLK + tid_] = k < kend_ ? (int)(img * (unsigned)Mtot * (unsigned)PQ + pix) : (int)ELEM_INVALID;
+  }
+  __device__ __forceinline__ void load(Stage& st, int k0, int) const {
+    const int rel = k0 - kbeg_;
+    const unsigned p0 = (unsigned)lds_[((rel / KBLK) & 1) * KBLK + (rel & (KBLK - 1)) + kq_];     // ELEM_INVALID beyond kend
+    st.ok = p0 < ELEM_INVALID ? 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
 #if SG_BUFLOAD
-      st.r[i] = sg_bufload4(sg_rsrc(base), ok ? p0 + (unsigned)m * (unsigned)PQ : ELEM_INVALID);       // rejected => zeros
+      st.r[i] = sg_bufload4(sg_rsrc(base), p0 + rowoff_[i]);                  // rejected by the range check => zeros
 #else
-      st.r[i] = *reinterpret_cast<const float4*>(base + (ok ? p0 + (unsigned)m * (unsigned)PQ : 0u));
-      st.ok |= ok ? (1u << i) : 0u;
+      st.r[i] = *reinterpret_cast<const float4*>(base + (st.ok ? p0 + rowoff_[i] : 0u));
 #endif
     }
   }
@@ -430,8 +450,7 @@ struct LoadPixKVec {
       if (row_ + 64 * i < BM) {
         float4 v = st.r[i];
 #if !SG_BUFLOAD
-        const bool ok = (st.ok >> i) & 1u;
-        if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!st.ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
         *reinterpret_cast<float4*>(T + (row_ + 64 * i) * LDK + kq_) = v;
       }
@@ -597,8 +616,7 @@ struct LoadTapNK {
   Gather g; int KS, Ccols, cpad;
   const int* chan_list; const int* chan_cnt; int L;     // optional per-image active-channel lists (image = blockIdx.z)
   FastDiv dPQ, dPW;
-  static constexpr int BUF = 2 * BK;                    // off1[16], off2[16]
-  static constexpr int LDS_INTS = 2 * NS * BUF;
+  static constexpr int LDS_INTS = 2 * KBLK * (TWO ? 2 : 1);      // off1[2][256] (, off2[2][256]): see KBLK above
   static constexpr int COLS = BN / 16;
   struct Stage { float r[COLS]; unsigned ok; };
   int kl_, tid_, nr_, kbeg_, kend_, kh_, kw_;
@@ -624,31 +642,31 @@ struct LoadTapNK {
       secmask_ |= second ? (1u << j) : 0u;
     }
   }
-  __device__ __forceinline__ int* buf_of(int k0) const { return lds_ + (((k0 - kbeg_) / BK) % (2 * NS)) * BUF; }
   __device__ __forceinline__ void prefetch(Stage&, int k0) const {
-    if (tid_ < BK) {
-      int* buf = buf_of(k0);
-      const int k = k0 + tid_;
-      const bool kok = k < kend_;
-      const unsigned kk = kok ? (unsigned)k : 0u;
-      const unsigned img = dPQ.div(kk), pix = kk - img * (unsigned)(g.PH * g.PW);
-      const unsigned ph = dPW.div(pix), pw = pix - ph * (unsigned)g.PW;
-      const int ih = axis_offset((int)ph * g.stride - g.pad, kh_, g.LH, g.reflect, g.ushift);
-      const int iw = axis_offset((int)pw * g.stride - g.pad, kw_, g.LW, g.reflect, g.ushift);
-      const bool valid = kok && (ih | iw) >= 0;
-      const unsigned shw = (unsigned)(g.SH * g.SW);
-      const unsigned tp = (unsigned)(ih * g.SW + iw);
-      buf[tid_] = valid ? (int)(img * (unsigned)g.C1 * shw + tp) : ((SG_BUFLOAD && MASK) ? (int)ELEM_INVALID : -1);
-      if (TWO) buf[BK + tid_] = (SG_BUFLOAD && MASK && !valid) ? (int)ELEM_INVALID
-                                    : (int)(g.bcast2 ? img * (unsigned)g.C2 : img * (unsigned)g.C2 * shw + tp);
-    }
+    const int rel = k0 - kbeg_;
+    if ((rel & (KBLK - 1)) != 0) return;
+    int* buf = lds_ + ((rel / KBLK) & 1) * KBLK;
+    const int k = k0 + tid_;
+    const bool kok = k < kend_;
+    const unsigned kk = kok ? (unsigned)k : 0u;
+    const unsigned img = dPQ.div(kk), pix = kk - img * (unsigned)(g.PH * g.PW);
+    const unsigned ph = dPW.div(pix), pw = pix - ph * (unsigned)g.PW;
+    const int ih = axis_offset((int)ph * g.stride - g.pad, kh_, g.LH, g.reflect, g.ushift);
+    const int iw = axis_offset((int)pw * g.stride - g.pad, kw_, g.LW, g.reflect, g.ushift);
+    const bool valid = kok && (ih | iw) >= 0;
+    const unsigned shw = (unsigned)(g.SH * g.SW);
+    const unsigned tp = (unsigned)(ih * g.SW + iw);
+    buf[tid_] = valid ? (int)(img * (unsigned)g.C1 * shw + tp) : ((SG_BUFLOAD && MASK) ? (int)ELEM_INVALID : -1);
+    if (TWO) buf[2 * KBLK + tid_] = (SG_BUFLOAD && MASK && !valid) ? (int)ELEM_INVALID
+                                        : (int)(g.bcast2 ? img * (unsigned)g.C2 : img * (unsigned)g.C2 * shw + tp);
   }
   __device__ __forceinline__ void load(Stage& st, int k0, int) const {
-    const int* buf = buf_of(k0);
+    const int rel = k0 - kbeg_;
+    const int* buf = lds_ + ((rel / KBLK) & 1) * KBLK + (rel & (KBLK - 1));
     const int o1 = buf[kl_];
 #if SG_BUFLOAD
     if (MASK) {        // invalid pixels carry ELEM_INVALID: the buffer load's range check returns zeros, nothing to select
-      const unsigned u1 = (unsigned)o1, u2 = TWO ? (unsigned)buf[BK + kl_] : 0u;
+      const unsigned u1 = (unsigned)o1, u2 = TWO ? (unsigned)buf[2 * KBLK + kl_] : 0u;
       const __amdgpu_buffer_rsrc_t r1 = sg_rsrc(g.src1);
 #pragma unroll
       for (int j = 0; j < COLS; ++j) {
@@ -665,7 +683,7 @@ struct LoadTapNK {
 #endif
     const bool ok = !MASK || o1 >= 0;
     const unsigned b1 = ok ? (unsigned)o1 : 0u;         // invalid pixel: element 0 of the channel plane, zeroed in store()
-    const unsigned b2 = (TWO && ok) ? (unsigned)buf[BK + kl_] : 0u;
+    const unsigned b2 = (TWO && ok) ? (unsigned)buf[2 * KBLK + kl_] : 0u;
 #pragma unroll
     for (int j = 0; j < COLS; ++j) {
       if (TWO) {
