@@ -17,6 +17,7 @@ built=0
 for f in $UNITS; do
   want=$( (echo "$FLAGS"; cat $f.hip $HDRS) | sha256sum | cut -d' ' -f1)
   if [ ! -f $f.o ] || [ ! -f $f.stamp ] || [ "$(cat $f.stamp)" != "$want" ]; then
+    rm -f $f.stamp                                  # a failed compile must not leave a stale object looking current
     ( /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $f.o && echo "$want" > $f.stamp ) &
     built=$((built+1))
   fi

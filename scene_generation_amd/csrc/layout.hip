@@ -10,6 +10,7 @@
 // crop_bbox_batch (bilinear.py:67-130): one gather kernel indexed by box_to_feat -- no per-image
 // nonzero()/expand/cat/inverse-permutation.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -158,6 +159,77 @@ __global__ void __launch_bounds__(256) layout_fwd_kernel(const float* __restrict
       }
       if (VEC == 4) *reinterpret_cast<float4*>(op + (size_t)d * HW) = make_float4(acc[0], acc[1], acc[2], acc[3]);
       else op[(size_t)d * HW] = acc[0];
+    }
+  }
+}
+
+// Register-resident form for W % 4 == 0 (the training path): a thread owns 4 consecutive pixels and keeps the sampled masks of
+// up to CAP objects for them in REGISTERS; only the coefficients live in LDS, transposed to Vt[d][CAP] so that one channel costs
+// CAP/4 broadcast ds_read_b128 instead of 2 LDS reads per (object, channel) -- the kernel above spends ~3.7 k LDS
+// instructions per thread on a 1024-pixel tile and runs at 2.0 TB/s (0.25 of the HBM peak on its 428 MB of output).  Objects
+// beyond an image's count contribute exact zeros (0 * 0 added in the same ascending order).  Images with more than CAP
+// objects take further passes that read-modify-write the tile, like the chunks of the kernel above.
+template <bool I64, int CAP>
+__global__ void __launch_bounds__(256) layout_fwd_reg_kernel(const float* __restrict__ vecs, const float* __restrict__ boxes,
+                                                            const void* __restrict__ masks, const int32_t* __restrict__ seg,
+                                                            float* __restrict__ out, int D, int M, int H, int W, int avg, int ac,
+                                                            int dchunk) {
+  extern __shared__ __attribute__((aligned(16))) float Vt[];        // [dchunk][CAP]: this workgroup's channel range
+  static_assert(CAP % 4 == 0, "CAP is read as float4s");
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int o_beg = seg[n], cnt = seg[n + 1] - o_beg;
+  const int HW = H * W;
+  const int px0 = (blockIdx.x * 256 + tid) * 4;
+  const bool live = px0 < HW;
+  const int h = live ? px0 / W : 0, w0 = live ? px0 - h * W : 0;
+  const float Y = lin01(h, H);
+  const float denom = (float)(cnt > 1 ? cnt : 1);
+  // blockIdx.z splits the channels: the sampled masks are recomputed per chunk (cheap) so that a 32-image batch puts
+  // ~2000 workgroups of stores in flight instead of 512
+  const int d_lo = blockIdx.z * dchunk, d_n = min(dchunk, D - d_lo);
+  float* op = out + ((size_t)n * D + d_lo) * HW + (live ? px0 : 0);
+  for (int c0 = 0; c0 == 0 || c0 < cnt; c0 += CAP) {
+    const int nc = min(CAP, cnt - c0);                 // (<= 0 for an image without objects: an all-zero layout)
+    __syncthreads();
+    for (int i = tid; i < d_n * CAP; i += 256) {
+      const int d = i / CAP, j = i - d * CAP;
+      Vt[i] = j < nc ? vecs[(size_t)(o_beg + c0 + j) * D + d_lo + d] : 0.f;
+    }
+    float sv[CAP][4];
+#pragma unroll
+    for (int j = 0; j < CAP; ++j) {
+      const bool on = live && j < nc;
+      const size_t o = (size_t)(o_beg + c0 + (j < nc ? j : 0));
+      const float x0 = boxes[o * 4 + 0], y0 = boxes[o * 4 + 1], x1 = boxes[o * 4 + 2], y1 = boxes[o * 4 + 3];
+      const Tap ty = make_tap(box_coord(Y, y0, y1), M, ac);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const Tap tx = make_tap(box_coord(lin01(w0 + v, W), x0, x1), M, ac);
+        sv[j][v] = on ? sample_mask<I64>(masks, o, M, ty, tx) : 0.f;
+      }
+    }
+    __syncthreads();
+    if (!live) continue;
+    const bool first = c0 == 0, last = c0 + CAP >= cnt;
+    for (int d = 0; d < d_n; ++d) {
+      float4 acc = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(op + (size_t)d * HW);
+      const float4* cp = reinterpret_cast<const float4*>(Vt + d * CAP);
+#pragma unroll
+      for (int q = 0; q < CAP / 4; ++q) {
+        const float4 c4 = cp[q];
+        const float c[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = q * 4 + e;
+          acc.x += c[e] * sv[j][0]; acc.y += c[e] * sv[j][1]; acc.z += c[e] * sv[j][2]; acc.w += c[e] * sv[j][3];
+        }
+      }
+      if (avg && last) { acc.x /= denom; acc.y /= denom; acc.z /= denom; acc.w /= denom; }
+      typedef float nt_f4 __attribute__((ext_vector_type(4)));
+      nt_f4* dst = reinterpret_cast<nt_f4*>(op + (size_t)d * HW);
+      const nt_f4 val = {acc.x, acc.y, acc.z, acc.w};
+      if (last) __builtin_nontemporal_store(val, dst);           // 428 MB nobody re-reads soon: keep it out of the caches
+      else *dst = val;
     }
   }
 }
@@ -459,6 +531,25 @@ extern "C" int sg_masks_to_layout_fwd(const float* vecs, const float* boxes, con
   if (cap > max_fit) cap = max_fit;
   const size_t lds_bytes = (size_t)cap * per_obj;
   SgProfScope prof(SG_K_LAYOUT_FWD, s, 0, 4.0 * N * D * (double)H * W + 4.0 * O * D + (masks_i64 ? 8.0 : 4.0) * O * M * M);
+  static int regform = -1;
+  if (regform < 0) { const char* e = getenv("SG_LAYOUT_REG"); regform = e ? atoi(e) : 1; }      // 0: the LDS-staged kernel
+  if (regform && use_vec == 4 && (size_t)D * 12 * sizeof(float) <= 64 * 1024) {
+    const int tiles = sg_cdiv(H * W, 1024);
+    // channel chunks per tile (grid.z): measured SLOWER on MI355X (4 chunks: 78 vs 69 us averaged over the kind, the whole
+    // dense-layout step 47.5 vs 43.5 ms) -- interleaved store streams of different chunks -- so one workgroup writes all D
+    static int dsplit_env = -1;
+    if (dsplit_env < 0) { const char* e = getenv("SG_LAYOUT_DSPLIT"); dsplit_env = e ? atoi(e) : 1; }
+    int dsplit = dsplit_env;
+    dsplit = dsplit < 1 ? 1 : (dsplit > 8 ? 8 : dsplit);
+    if (dsplit > D / 16) dsplit = D / 16 > 0 ? D / 16 : 1;
+    const int dchunk = sg_cdiv(D, dsplit);
+    const dim3 g4(tiles, N, sg_cdiv(D, dchunk));
+    const size_t lds = (size_t)dchunk * 12 * sizeof(float);
+    if (masks_i64) hipLaunchKernelGGL((layout_fwd_reg_kernel<true, 12>), g4, dim3(256), lds, s, vecs, boxes, masks, seg_off, out, D, M, H, W, avg, g_align_corners, dchunk);
+    else hipLaunchKernelGGL((layout_fwd_reg_kernel<false, 12>), g4, dim3(256), lds, s, vecs, boxes, masks, seg_off, out, D, M, H, W, avg, g_align_corners, dchunk);
+    SG_LAUNCH_CHECK("sg_masks_to_layout_fwd");
+    return 0;
+  }
   const dim3 grid(sg_cdiv(H * W, 256 * use_vec), N);
 #define LAUNCH_LAYOUT(I64, VEC)                                                                                         \
   do {                                                                                                                 \
