@@ -112,13 +112,17 @@ int sg_conv2d_wgrad_sparse(const sgConvDesc* d, const float* gy, const float* x1
    sg_conv2d_fwd / _dgrad / _wgrad to fp32 rounding (gb via sg_channel_sum). */
 int sg_conv2d_wino_supported(const sgConvDesc* d);
 size_t sg_conv2d_wino_ws_bytes(const sgConvDesc* d);
+/* ut_save (optional, sg_conv2d_wino_ut_floats(d) floats): the forward also writes the filter transform with the channel
+   roles swapped -- what sg_conv2d_wino_dgrad of the SAME conv multiplies with (ut_saved): the weights are transformed once
+   per step instead of once per direction. */
+size_t sg_conv2d_wino_ut_floats(const sgConvDesc* d);
 int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                       float slope, void* ws, size_t ws_bytes, sgStream stream);
+                       float slope, float* ut_save, void* ws, size_t ws_bytes, sgStream stream);
 int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, void* ws, size_t ws_bytes,
                          sgStream stream);
 /* gx [N, C1, H, W] (all input channels): Winograd on the padded gradient grid + reflection fold */
-int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, void* ws, size_t ws_bytes,
-                         sgStream stream);
+int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, const float* ut_saved,
+                         void* ws, size_t ws_bytes, sgStream stream);
 /* Direct (vector-ALU) kernels for ReflectionPad2d(3) + Conv2d(C, Cout <= 4, 7) [+ act]: the generator's RGB head
    (reference generators.py:88-90).  Same results as sg_conv2d_fwd / sg_conv2d_wgrad (gb via sg_channel_sum). */
 int sg_conv2d_smallm_supported(const sgConvDesc* d);

@@ -461,8 +461,11 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
 // contiguous floats coalesced (for the transposed modes those rows are w[c][r0..r0+31]: the per-thread form above reads them
 // with a lane stride of R*36 bytes) and writes U with c contiguous.  Same arithmetic, same results.
 constexpr int WW_PITCH = 32 * 9 + 1;
+// UT (optional, flip == 0 only): the same transformed filters with the channel roles swapped, UT[xi][c][r] = U[xi][r][c] -- what
+// the adjoint data gradient of the SAME conv multiplies with later in the step (flip == 2 of a second call used to rebuild it
+// from the weights: one more pass over 38 MB per ResnetBlock conv).  Written from the same LDS tile with the lanes along r.
 __global__ void __launch_bounds__(256) wino_weight_lds_kernel(const float* __restrict__ w, float* __restrict__ U, int R, int Cc,
-                                                              int flip) {
+                                                              int flip, float* __restrict__ UT) {
   __shared__ float S[32 * WW_PITCH];
   const int cb = blockIdx.x % (Cc / 32), rb = blockIdx.x / (Cc / 32);
   const int r0 = rb * 32, c0 = cb * 32, t = threadIdx.x;
@@ -498,16 +501,40 @@ __global__ void __launch_bounds__(256) wino_weight_lds_kernel(const float* __res
       for (int b = 0; b < 4; ++b) U[(size_t)(a * 4 + b) * RC + i] = u[b];
     }
   }
+  if (UT == nullptr) return;
+  const int rl2 = t & 31;                      // lanes along r this time: UT rows are contiguous in r
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int cl2 = (t >> 5) + 8 * q;
+    const float* g = S + rl2 * WW_PITCH + cl2 * 9;
+    float tt[4][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float g0 = g[j], g1 = g[3 + j], g2 = g[6 + j];
+      tt[0][j] = g0; tt[1][j] = 0.5f * (g0 + g1 + g2); tt[2][j] = 0.5f * (g0 - g1 + g2); tt[3][j] = g2;
+    }
+    const size_t i = (size_t)(c0 + cl2) * R + r0 + rl2;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float u[4] = {tt[a][0], 0.5f * (tt[a][0] + tt[a][1] + tt[a][2]), 0.5f * (tt[a][0] - tt[a][1] + tt[a][2]), tt[a][2]};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) UT[(size_t)(a * 4 + b) * RC + i] = u[b];
+    }
+  }
 }
 
-// one entry for the three call sites (SG_WINO_WT=0 keeps the per-thread kernel)
-inline void wino_weight(const float* w, float* U, int R, int Cc, int flip, hipStream_t s) {
+// one entry for the three call sites (SG_WINO_WT=0 keeps the per-thread kernel).  ``UT``: see wino_weight_lds_kernel; returns
+// whether it was written
+inline bool wino_weight(const float* w, float* U, int R, int Cc, int flip, hipStream_t s, float* UT = nullptr) {
   static int lds = -1;
   if (lds < 0) { const char* e = getenv("SG_WINO_WT"); lds = e ? atoi(e) : 1; }
-  if (lds && R % 32 == 0 && Cc % 32 == 0 && aligned16(w))
-    hipLaunchKernelGGL(wino_weight_lds_kernel, dim3((R / 32) * (Cc / 32)), dim3(256), 0, s, w, U, R, Cc, flip);
-  else
-    hipLaunchKernelGGL(wino_weight_kernel, dim3(sg_cdiv((size_t)R * Cc, 256)), dim3(256), 0, s, w, U, R, Cc, flip);
+  if (lds && R % 32 == 0 && Cc % 32 == 0 && aligned16(w)) {
+    hipLaunchKernelGGL(wino_weight_lds_kernel, dim3((R / 32) * (Cc / 32)), dim3(256), 0, s, w, U, R, Cc, flip,
+                       flip == 0 ? UT : nullptr);
+    return flip == 0 && UT != nullptr;
+  }
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(sg_cdiv((size_t)R * Cc, 256)), dim3(256), 0, s, w, U, R, Cc, flip);
+  return false;
 }
 
 // y[n][m][2ti+a][2tj+b] = act((A^T Mx A)[a][b] + bias[m]),  Mx[m][xi*Pstride + p]
@@ -770,26 +797,39 @@ extern "C" size_t sg_conv2d_wino_ws_bytes(const sgConvDesc* d) {
 // the zero-extended gy with the rotated filter), then the reflection fold (sg_pad_upsample_bwd); 1.44x fewer MACs than the
 // direct folded form.  Zero padding: the same correlation straight on the H x W grid (2.25x fewer MACs); behind a folded x2
 // upsample the result is on the upsampled grid and is summed back 2x2.
-extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, void* ws, size_t ws_bytes,
-                                    sgStream stream) {
+static bool wino_adjoint_shape(const sgConvDesc* d) {
+  static int adj = -1;
+  if (adj < 0) { const char* e = getenv("SG_WINO_ADJOINT"); adj = e ? atoi(e) : 1; }
+  return adj && wino_ok(d) && d->pad_reflect && d->upsample == 1 && d->H * d->W <= 256 && (d->H * d->W) % 4 == 0 &&
+         d->C1 % 64 == 0 && d->Cout % 64 == 0;
+}
+// floats of the transposed filter transform sg_conv2d_wino_fwd can hand to sg_conv2d_wino_dgrad (0: that conv's data gradient
+// does not use it)
+extern "C" size_t sg_conv2d_wino_ut_floats(const sgConvDesc* d) {
+  return (wino_adjoint_shape(d) && d->C1 % 32 == 0 && d->Cout % 32 == 0) ? (size_t)16 * d->C1 * d->Cout : 0;
+}
+
+extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, const float* ut_saved,
+                                    void* ws, size_t ws_bytes, sgStream stream) {
   SG_ARG_CHECK(wino_ok(d), "sg_conv2d_wino_dgrad: unsupported desc");
   SG_ARG_CHECK(gy && w && gx && ws && ws_bytes >= sg_conv2d_wino_ws_bytes(d), "sg_conv2d_wino_dgrad: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const int M = d->C1, K = d->Cout;                 // rows = input channels, reduction over output channels
   const int LH = d->H * d->upsample, LW = d->W * d->upsample;
   const int refl = d->pad_reflect;
-  static int adj = -1;
-  if (adj < 0) { const char* e = getenv("SG_WINO_ADJOINT"); adj = e ? atoi(e) : 1; }
-  if (adj && refl && d->upsample == 1 && d->H * d->W <= 256 && (d->H * d->W) % 4 == 0 && M % 64 == 0 && K % 64 == 0 &&
-      aligned16(gy) && aligned16(gx)) {
+  if (wino_adjoint_shape(d) && aligned16(gy) && aligned16(gx)) {
     // adjoint Winograd over the output tiles (see wino_gy_small_kernel / wino_patch_fold_kernel)
     const int HW = d->H * d->W;
     const size_t P = (size_t)d->N * (d->H / 2) * (d->W / 2);
-    float* UT = reinterpret_cast<float*>(ws);       // [16][C1][Cout]
-    float* Ytp = UT + 16 * (size_t)M * K;           // [16][P][Cout]
+    float* UTw = reinterpret_cast<float*>(ws);      // [16][C1][Cout]
+    float* Ytp = UTw + 16 * (size_t)M * K;          // [16][P][Cout]
     float* G = Ytp + 16 * P * K;                    // [P][16][C1]
-    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 25.0 * (double)M * K);
-      wino_weight(w, UT, M, K, 2, s); }
+    const float* UT = ut_saved;                     // built by the forward pass of this step (same weights) when given
+    if (UT == nullptr) {
+      SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 25.0 * (double)M * K);
+      wino_weight(w, UTw, M, K, 2, s);
+      UT = UTw;
+    }
     { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * K * HW + 16.0 * (double)P * K));
       const size_t lds = (size_t)64 * (HW + 1) * sizeof(float);
       if (lds > 48 * 1024)
@@ -823,7 +863,7 @@ extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const 
 }
 
 extern "C" int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                                  float slope, void* ws, size_t ws_bytes, sgStream stream) {
+                                  float slope, float* ut_save, void* ws, size_t ws_bytes, sgStream stream) {
   SG_ARG_CHECK(wino_ok(d), "sg_conv2d_wino_fwd: unsupported desc");
   SG_ARG_CHECK(x && w && y && ws && ws_bytes >= sg_conv2d_wino_ws_bytes(d), "sg_conv2d_wino_fwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
@@ -833,7 +873,10 @@ extern "C" int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const flo
   float* U = reinterpret_cast<float*>(ws);
   float* V = U + 16 * (size_t)M * C;
   float* Mx = V + 16 * P * C;
-  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 25.0 * (double)M * C); wino_weight(w, U, M, C, 0, s); }
+  SG_ARG_CHECK(ut_save == nullptr || sg_conv2d_wino_ut_floats(d) > 0, "sg_conv2d_wino_fwd: ut_save given but unused by this desc");
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * (25.0 + (ut_save ? 16.0 : 0.0)) * (double)M * C);
+    const bool wrote = wino_weight(w, U, M, C, 0, s, ut_save);
+    SG_ARG_CHECK(ut_save == nullptr || wrote, "sg_conv2d_wino_fwd: the transposed filter transform needs the LDS weight kernel"); }
   wino_input_pc(x, V, d->N, C, LH, LW, LH / 2, LW / 2, -1, d->pad_reflect ? 0 : 1, P, d->upsample == 2 ? 1 : 0, s);
   wino_bgemm(U, V, Mx, M, (int)P, C, 2.0 * M * (double)C * 16.0 * P, s);
   { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * (16.0 * (double)P * M + (double)d->N * M * LH * LW)); hipLaunchKernelGGL(wino_output_kernel, dim3(sg_cdiv(P * M, 256)), dim3(256), 0, s, (const float*)Mx, bias, y, d->N, M, LH, LW, P,

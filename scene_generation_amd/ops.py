@@ -234,7 +234,11 @@ class Conv2dFn(Function):
                   _p(workspace(wsb, x1.device)), wsb, _stream())
         elif ctx.wino:              # ResnetBlock convs: Winograd F(2x2,3x3), 16 batched dense GEMMs
             wsb = _q(d, 'sg_conv2d_wino_ws_bytes')
-            _call('sg_conv2d_wino_fwd', d._ref, _p(x1), _p(weight), _p(bias), _p(y), act, slope,
+            # the data gradient of the same conv multiplies with the transposed filter transform: build it now, in the same
+            # pass over the weights (they do not change between this forward and its backward)
+            utn = _q(d, 'sg_conv2d_wino_ut_floats') if ctx.needs_input_grad[0] else 0
+            ctx.wino_ut = torch.empty(utn, dtype=torch.float32, device=x1.device) if utn else None
+            _call('sg_conv2d_wino_fwd', d._ref, _p(x1), _p(weight), _p(bias), _p(y), act, slope, _p(ctx.wino_ut),
                   _p(workspace(wsb, x1.device)), wsb, _stream())
         elif ctx.smallm:              # <= 4 output channels (the RGB head): direct vector-ALU kernel, no MFMA tile waste
             _call('sg_conv2d_smallm_fwd', d._ref, _p(x1), _p(weight), _p(bias), _p(y), act, slope, _stream())
@@ -294,7 +298,8 @@ class Conv2dFn(Function):
                 if ctx.wino and c0 == 0 and c1 == d.C1:     # Winograd on the padded gradient grid + reflection fold
                     out = torch.empty(d.N, d.C1, d.H, d.W, dtype=torch.float32, device=dev)
                     fb = _q(d, 'sg_conv2d_wino_ws_bytes')
-                    _call('sg_conv2d_wino_dgrad', d._ref, _p(gy), _p(weight), _p(out), _p(workspace(fb, dev)), fb, s)
+                    _call('sg_conv2d_wino_dgrad', d._ref, _p(gy), _p(weight), _p(out), _p(getattr(ctx, 'wino_ut', None)),
+                          _p(workspace(fb, dev)), fb, s)
                     return out
                 if folded:       # ReflectionPad(1)+3x3: gradient straight on the H x W grid (no padded grid, no fold pass)
                     out = torch.empty(d.N, c1 - c0, d.H, d.W, dtype=torch.float32, device=dev)
