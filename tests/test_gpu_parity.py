@@ -1455,3 +1455,92 @@ def test_masks_to_layout_gradients_wrt_masks_and_boxes(hip, pooling):
     close(vg.grad, vr.grad, 2e-5, 'd/dvecs')
     close(mg.grad, mr.grad, 2e-5, 'd/dmasks')
     close(bg.grad, br.grad, 1e-4, 'd/dboxes')
+
+
+# ------------------------------------------------------------------------------------------
+# f3 / f4: the collate -> device adapter on the GPU, the validation loop and the feature bank
+# ------------------------------------------------------------------------------------------
+def test_device_batch_prefetcher_equals_direct_copies_and_steps_identically(hip):
+    """f3 (coco.py:501-547 -> train.py:190-193): the pinned, side-stream, double-buffered adapter delivers exactly
+    ``batch_to`` of the collated batch plus host lists that match it, and a training step fed through it (host lists handed
+    to the model, as bench.py does) is bit-identical to a step fed the device batch directly."""
+    from scene_generation_amd.pipeline import DeviceBatchPrefetcher
+    from scene_generation_amd.trainer import Trainer
+    host = [make_batch(N=4, min_objs=2, max_objs=5, size=64, seed=70 + i) for i in range(3)]
+    staged = list(DeviceBatchPrefetcher(host, DEV))
+    assert len(staged) == 3
+    for hb, db in zip(host, staged):
+        for a, b in zip(batch_to(hb, DEV), db.batch):
+            assert a.dtype == b.dtype and torch.equal(a, b)
+        assert db.objs_host == hb.objs.tolist() and db.obj_to_img_host == hb.obj_to_img.tolist()
+        assert db.num_images == hb.imgs.size(0) and db.seg_offsets_host[-1] == hb.objs.numel()
+    args = parser.parse_args(['--image_size', '64,64', '--batch_size', '4', '--vgg_features_weight', '0', '--output_dir', '/tmp/o'])
+    res = []
+    for through in (True, False):
+        torch.manual_seed(0)
+        tr = Trainer(args, make_vocab())
+        for m in (tr.model, tr.netD, tr.obj_discriminator, tr.mask_discriminator):
+            fill_deterministic(m)
+        tr.model.noise_override = det((1, 64), 182).to(DEV)
+        random.seed(9)
+        for i in range(2):
+            if through:
+                db = staged[i]
+                tr.model.objs_host, tr.model.obj_to_img_host = db.objs_host, db.obj_to_img_host
+                out = tr.step(db.batch, use_gt=(i == 0))
+            else:
+                tr.model.objs_host = tr.model.obj_to_img_host = None
+                out = tr.step(batch_to(host[i], DEV), use_gt=(i == 0))
+        losses = {}
+        for L in (tr.generator_losses, tr.d_img_losses, tr.d_obj_losses, tr.d_mask_losses):
+            losses.update(dict(L.items()))
+        res.append((losses, out[0].detach().clone(), tr.optimizer.fp.flat.clone(), tr.optimizer_d_img.fp.flat.clone()))
+        del tr
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert torch.equal(a, b)
+
+
+def test_eval_hooks_feature_bank_and_check_model(hip, golden):
+    """f4: encode_features (scripts/encode_features.py:103-146) through the HIP crop / encoder / MLP against the reference's
+    rows; check_model (train.py:80-116) against the oracle's test-mode forward + the reference-pinned IoU."""
+    from scene_generation_amd.evaluate import jaccard, check_model, encode_features
+    from scene_generation_amd.model import Model
+    g = golden('eval_hooks')
+    tot, n5, n3 = jaccard(torch.from_numpy(g['boxes_a']).to(DEV), torch.from_numpy(g['boxes_b']).to(DEV))
+    assert abs(float(tot) - float(g['iou_sum'])) <= 1e-5 and n5 == int(g['n_gt_05']) and n3 == int(g['n_gt_03'])
+    kw = dict(image_size=(32, 32), gconv_hidden_dim=32, gconv_num_layers=2, mask_size=8, n_downsample_global=1,
+              appearance_normalization='batch', activation='leakyrelu-0.2', use_attributes=True, pool_size=2, rep_size=8)
+    vocab = make_vocab(12, 4, 35)
+    m = Model(vocab, **kw).to(DEV)
+    fill_deterministic(m)
+    m.eval()
+    b = make_batch(N=3, min_objs=2, max_objs=4, size=32, mask_size=8, num_objs=12, num_preds=4, seed=33)
+    bank = encode_features(m, [b], object_size=64)
+    assert sorted(bank) == list(range(12)) and sum(v.shape[0] for v in bank.values()) == b.objs.numel()
+    ref_rows = g['feat']
+    seen = {k: 0 for k in bank}
+    for row, label in zip(ref_rows, b.objs.tolist()):
+        got = bank[label][seen[label]]
+        seen[label] += 1
+        assert np.abs(got - row).max() <= 3e-5 * max(1.0, np.abs(row).max()), (label, got, row)
+    # check_model: same numbers as the oracle model run by hand (test-mode compositing, predicted vs ground-truth boxes)
+    ref = O.Model(vocab, **kw)
+    fill_deterministic(ref)
+    ref.eval()
+    noise = det((1, 64), 183)
+    m.noise_override, ref.noise_override = noise.to(DEV), noise
+    cfg = type('A', (), {'num_val_samples': 3})()
+    for use_gt in (True, False):
+        random.seed(4)
+        got = check_model(cfg, [b], m, None, use_gt)
+        random.seed(4)
+        with torch.no_grad():
+            if use_gt:
+                out = ref(b.imgs, b.objs, b.triples, b.obj_to_img, boxes_gt=b.boxes, masks_gt=b.masks, attributes=b.attributes,
+                          test_mode=True, use_gt_box=True)
+            else:
+                out = ref(b.imgs, b.objs, b.triples, b.obj_to_img, boxes_gt=b.boxes, masks_gt=None,
+                          attributes=torch.zeros_like(b.attributes), test_mode=True, use_gt_box=False)
+        want = float(jaccard(out[1], b.boxes)[0]) / b.boxes.size(0)
+        assert got[1:] == (None, None, None) and abs(got[0] - want) <= 1e-4 * max(1.0, abs(want)), (use_gt, got, want)

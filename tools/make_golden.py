@@ -424,6 +424,37 @@ def golden_step_full():
         del tr
 
 
+def golden_eval():
+    """f4 eval hooks: ``jaccard`` (metrics.py:27-35, the IoU that check_model accumulates, train.py:80-116) on boxes with
+    empty / partial / full overlaps, and the feature bank of scripts/encode_features.py:103-146
+    (``repr_net(image_encoder(crop_bbox_batch(...)))`` in eval mode) on a reduced model with closed-form weights."""
+    from scene_generation.metrics import jaccard
+    from scene_generation.bilinear import crop_bbox_batch
+    from scene_generation.model import Model
+    a = torch.tensor([[0.1, 0.1, 0.5, 0.6], [0.0, 0.0, 1.0, 1.0], [0.2, 0.3, 0.4, 0.9], [0.6, 0.6, 0.9, 0.9],
+                      [0.05, 0.5, 0.45, 0.95], [0.3, 0.3, 0.7, 0.7]])
+    b = torch.tensor([[0.1, 0.1, 0.5, 0.6], [0.25, 0.25, 0.75, 0.75], [0.5, 0.3, 0.8, 0.9], [0.55, 0.65, 0.95, 0.85],
+                      [0.0, 0.45, 0.5, 1.0], [0.31, 0.28, 0.69, 0.74]])
+    g = torch.Generator().manual_seed(5)
+    ra = torch.rand(40, 2, generator=g) * 0.5
+    ra = torch.cat([ra, ra + 0.1 + torch.rand(40, 2, generator=g) * 0.4], 1)
+    rb = (ra + (torch.rand(40, 4, generator=g) - 0.5) * 0.3).clamp(0, 1)
+    rb = torch.cat([torch.min(rb[:, :2], rb[:, 2:] - 0.02), rb[:, 2:]], 1)
+    pa, pb = torch.cat([a, ra]), torch.cat([b, rb])
+    tot, n5, n3 = jaccard(pa, pb)
+    vocab = make_vocab(12, 4, 35)
+    with fake_cuda():
+        m = Model(vocab, image_size=(32, 32), gconv_hidden_dim=32, gconv_num_layers=2, mask_size=8, n_downsample_global=1,
+                  appearance_normalization='batch', activation='leakyrelu-0.2', use_attributes=True, pool_size=2, rep_size=8)
+    fill_deterministic(m)
+    m.eval()
+    batch = make_batch(N=3, min_objs=2, max_objs=4, size=32, mask_size=8, num_objs=12, num_preds=4, seed=33)
+    with torch.no_grad():
+        crops = crop_bbox_batch(batch.imgs, batch.boxes, batch.obj_to_img, 64)
+        feat = m.repr_net(m.image_encoder(crops))
+    npz('eval_hooks', boxes_a=pa, boxes_b=pb, iou_sum=tot, n_gt_05=n5, n_gt_03=n3, feat=feat, objs=batch.objs)
+
+
 def golden_testmode():
     """masks_to_layout(test_mode=True) (layout.py:87-92,157-169) and Model.forward(test_mode=True,
     features=...) (model.py:111-117,158-163) of the reference, reduced widths."""
@@ -595,6 +626,6 @@ def golden_args():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     install_shims()
-    which = sys.argv[1:] or ['gconv', 'layout', 'crop', 'modules', 'losses', 'losses2', 'vgg', 'legacy', 'step', 'step_full', 'testmode', 'args']
+    which = sys.argv[1:] or ['gconv', 'layout', 'crop', 'modules', 'losses', 'losses2', 'vgg', 'legacy', 'step', 'step_full', 'eval', 'testmode', 'args']
     for w in which:
         globals()['golden_' + w]()
