@@ -154,12 +154,14 @@ class Model(nn.Module):
         pred_vecs = self.pred_embeddings(p.contiguous())
         if self.use_attributes:
             obj_vecs = ops.concat_cols(obj_vecs, attributes)
+        # the destination-major CSR of the triples (segmented pool, gather adjoint): built once for all graph-conv layers
+        csr = ops.build_csr(edges, objs.numel()) if objs.is_cuda else None
         if isinstance(self.gconv, Linear):
             obj_vecs = self.gconv(obj_vecs)
         else:
-            obj_vecs, pred_vecs = self.gconv(obj_vecs, pred_vecs, edges)
+            obj_vecs, pred_vecs = self.gconv(obj_vecs, pred_vecs, edges, csr=csr)
         if self.gconv_net is not None:
-            obj_vecs, pred_vecs = self.gconv_net(obj_vecs, pred_vecs, edges)
+            obj_vecs, pred_vecs = self.gconv_net(obj_vecs, pred_vecs, edges, csr=csr)
         return obj_vecs, pred_vecs
 
     def create_components_vecs(self, imgs, boxes, obj_to_img, objs, obj_vecs, features, objs_host=None):
