@@ -382,7 +382,11 @@ __global__ void bn_bwd_apply_flat_kernel(const float* __restrict__ x, const floa
 
 inline int bn_slices(int N, int C, int HW) {
   long cnt = (long)N * HW;
-  int S = (1024 + C - 1) / C;
+  // ~4096 workgroups per launch: the per-thread loops are chains of dependent loads, so the latency is hidden by running many
+  // short slices side by side (1024 workgroups of ~136 elements per thread ran at 0.2 of the HBM peak)
+  static int target = -1;
+  if (target < 0) { const char* e = getenv("SG_BN_BLOCKS"); target = e ? atoi(e) : 4096; }
+  int S = (target + C - 1) / C;
   const long maxS = cnt / 1024 > 0 ? cnt / 1024 : 1;      // at least 1024 elements per slice
   if (S > maxS) S = (int)maxS;
   return S < 1 ? 1 : S;

@@ -410,6 +410,8 @@ def test_fused_gconv_layer_equals_unfused(hip, O_, T_, Din, A, H_, Dout, pooling
     res = []
     saved = hip.GCONV_FUSED
     try:
+        hip.GCONV_FUSED = True
+        assert hip.gconv_fused_supported(Din + A, Din, H_, Dout)
         for fused in (True, False):
             hip.GCONV_FUSED = fused
             obj = obj0.to(DEV).requires_grad_()
@@ -423,7 +425,6 @@ def test_fused_gconv_layer_equals_unfused(hip, O_, T_, Din, A, H_, Dout, pooling
                 p.grad = None
     finally:
         hip.GCONV_FUSED = saved
-    assert hip.gconv_fused_supported(Din + A, Din, H_, Dout)
     for i, (a, b) in enumerate(zip(res[0], res[1])):
         assert torch.equal(a, b), 'tensor %d differs between the fused and the unfused layer: %g' % (i, float((a - b).abs().max()))
 
