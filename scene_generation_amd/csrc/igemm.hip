@@ -14,6 +14,7 @@
 #include "igemm_core.h"
 
 namespace sgk {
+thread_local double t_alg_bytes = 0.0;
 std::mutex g_tab_mu;
 std::map<TabKey, TabEntry> g_tabs;
 size_t g_tab_bytes = 0;
@@ -75,6 +76,7 @@ extern "C" size_t sg_conv2d_ws_bytes(const sgConvDesc* d, int kind) {
 extern "C" int sg_conv2d_fwd(const sgConvDesc* d, const float* x1, const float* x2, const float* w, const float* bias,
                              float* y, int act, float slope, void* ws, size_t ws_bytes, sgStream stream) {
   if (check_desc(d, "sg_conv2d_fwd")) return -1;
+  sgk::t_alg_bytes = 4.0 * ((double)d->N * (d->C1 + d->C2) * d->H * d->W + (double)d->Cout * (d->C1 + d->C2) * d->KS * d->KS + (double)d->N * d->Cout * d->OH * d->OW);
   SG_ARG_CHECK(x1 && w && y && ws, "sg_conv2d_fwd: null pointer");
   SG_ARG_CHECK(ws_bytes >= ktab_bytes((d->C1 + d->C2) * d->KS * d->KS), "sg_conv2d_fwd: workspace too small");
   SG_ARG_CHECK(d->C2 == 0 || x2, "sg_conv2d_fwd: C2>0 but x2 null");
@@ -91,6 +93,7 @@ extern "C" int sg_conv2d_fwd(const sgConvDesc* d, const float* x1, const float* 
 extern "C" int sg_conv2d_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, int c_begin, int c_end,
                                void* ws, size_t ws_bytes, sgStream stream) {
   if (check_desc(d, "sg_conv2d_dgrad")) return -1;
+  sgk::t_alg_bytes = 4.0 * ((double)d->N * (d->C1 + d->C2) * d->H * d->W + (double)d->Cout * (d->C1 + d->C2) * d->KS * d->KS + (double)d->N * d->Cout * d->OH * d->OW);
   const int Cin = d->C1 + d->C2, R = d->KS * d->KS;
   SG_ARG_CHECK(gy && w && gx && ws, "sg_conv2d_dgrad: null pointer");
   SG_ARG_CHECK(0 <= c_begin && c_begin < c_end && c_end <= Cin, "sg_conv2d_dgrad: bad channel range [%d,%d)", c_begin, c_end);
@@ -136,6 +139,7 @@ extern "C" size_t sg_conv2d_dgrad_folded_ws_bytes(const sgConvDesc* d) {
 extern "C" int sg_conv2d_dgrad_folded(const sgConvDesc* d, const float* gy, const float* w, float* gx, int c_begin, int c_end,
                                       void* ws, size_t ws_bytes, sgStream stream) {
   if (check_desc(d, "sg_conv2d_dgrad_folded")) return -1;
+  sgk::t_alg_bytes = 4.0 * ((double)d->N * (d->C1 + d->C2) * d->H * d->W + (double)d->Cout * (d->C1 + d->C2) * d->KS * d->KS + (double)d->N * d->Cout * d->OH * d->OW);
   SG_ARG_CHECK(dgrad_folded_ok(d), "sg_conv2d_dgrad_folded: unsupported desc (needs ReflectionPad(1) + 3x3, stride 1)");
   const int Cin = d->C1, R = 9;
   SG_ARG_CHECK(gy && w && gx && ws, "sg_conv2d_dgrad_folded: null pointer");
@@ -162,6 +166,7 @@ extern "C" int sg_conv2d_dgrad_folded(const sgConvDesc* d, const float* gy, cons
 extern "C" int sg_conv2d_wgrad(const sgConvDesc* d, const float* gy, const float* x1, const float* x2, float* gw,
                                float* gb, void* ws, size_t ws_bytes, sgStream stream) {
   if (check_desc(d, "sg_conv2d_wgrad")) return -1;
+  sgk::t_alg_bytes = 4.0 * ((double)d->N * (d->C1 + d->C2) * d->H * d->W + (double)d->Cout * (d->C1 + d->C2) * d->KS * d->KS + (double)d->N * d->Cout * d->OH * d->OW);
   SG_ARG_CHECK(gy && x1 && gw, "sg_conv2d_wgrad: null pointer");
   SG_ARG_CHECK(d->C2 == 0 || x2, "sg_conv2d_wgrad: C2>0 but x2 null");
   hipStream_t s = (hipStream_t)stream;
@@ -193,6 +198,7 @@ extern "C" int sg_conv2d_fwd_sparse(const sgConvDesc* d, const float* x1, const 
                                     const float* bias, const int32_t* chan_list, const int32_t* chan_cnt, int L, float* y,
                                     int act, float slope, void* ws, size_t ws_bytes, sgStream stream) {
   if (check_desc(d, "sg_conv2d_fwd_sparse") || check_sparse(d, chan_list, chan_cnt, L, "sg_conv2d_fwd_sparse")) return -1;
+  sgk::t_alg_bytes = 4.0 * ((double)d->N * L * d->H * d->W + (double)d->N * d->Cout * L * d->KS * d->KS + (double)d->N * d->Cout * d->OH * d->OW);
   SG_ARG_CHECK(x1 && w && y && ws, "sg_conv2d_fwd_sparse: null pointer");
   SG_ARG_CHECK(d->C2 == 0 || x2, "sg_conv2d_fwd_sparse: C2>0 but x2 null");
   SG_ARG_CHECK(ws_bytes >= sg_conv2d_sparse_ws_bytes(d, L, 0), "sg_conv2d_fwd_sparse: workspace too small");
@@ -209,6 +215,7 @@ extern "C" int sg_conv2d_wgrad_sparse(const sgConvDesc* d, const float* gy, cons
                                       const int32_t* chan_list, const int32_t* chan_cnt, int L, float* gw, float* gb,
                                       void* ws, size_t ws_bytes, sgStream stream) {
   if (check_desc(d, "sg_conv2d_wgrad_sparse") || check_sparse(d, chan_list, chan_cnt, L, "sg_conv2d_wgrad_sparse")) return -1;
+  sgk::t_alg_bytes = 4.0 * ((double)d->N * L * d->H * d->W + (double)d->N * d->Cout * L * d->KS * d->KS + (double)d->N * d->Cout * d->OH * d->OW);
   SG_ARG_CHECK(gy && x1 && gw && ws, "sg_conv2d_wgrad_sparse: null pointer");
   SG_ARG_CHECK(d->C2 == 0 || x2, "sg_conv2d_wgrad_sparse: C2>0 but x2 null");
   SG_ARG_CHECK(ws_bytes >= sg_conv2d_sparse_ws_bytes(d, L, 2), "sg_conv2d_wgrad_sparse: workspace too small");
@@ -226,6 +233,7 @@ extern "C" int sg_conv2d_fwd_perimage(const sgConvDesc* d, const float* x1, cons
                                       const float* bias, const int32_t* chan_list, const int32_t* chan_cnt, int L, float* y,
                                       int act, float slope, void* ws, size_t ws_bytes, sgStream stream) {
   if (check_desc(d, "sg_conv2d_fwd_perimage") || check_sparse(d, chan_list, chan_cnt, L, "sg_conv2d_fwd_perimage")) return -1;
+  sgk::t_alg_bytes = 4.0 * ((double)d->N * L * d->H * d->W + (double)d->N * d->Cout * L * d->KS * d->KS + (double)d->N * d->Cout * d->OH * d->OW);
   SG_ARG_CHECK(x1 && wimg && y && ws, "sg_conv2d_fwd_perimage: null pointer");
   SG_ARG_CHECK(d->C2 == 0 || x2, "sg_conv2d_fwd_perimage: C2>0 but x2 null");
   SG_ARG_CHECK(ws_bytes >= sg_conv2d_sparse_ws_bytes(d, L, 0), "sg_conv2d_fwd_perimage: workspace too small");
@@ -242,6 +250,7 @@ extern "C" int sg_conv2d_wgrad_perimage(const sgConvDesc* d, const float* gy, co
                                         const int32_t* chan_list, const int32_t* chan_cnt, int L, float* gwimg, void* ws,
                                         size_t ws_bytes, sgStream stream) {
   if (check_desc(d, "sg_conv2d_wgrad_perimage") || check_sparse(d, chan_list, chan_cnt, L, "sg_conv2d_wgrad_perimage")) return -1;
+  sgk::t_alg_bytes = 4.0 * ((double)d->N * L * d->H * d->W + (double)d->N * d->Cout * L * d->KS * d->KS + (double)d->N * d->Cout * d->OH * d->OW);
   SG_ARG_CHECK(gy && x1 && gwimg && ws, "sg_conv2d_wgrad_perimage: null pointer");
   SG_ARG_CHECK(d->C2 == 0 || x2, "sg_conv2d_wgrad_perimage: C2>0 but x2 null");
   SG_ARG_CHECK(ws_bytes >= sg_conv2d_sparse_ws_bytes(d, L, 2), "sg_conv2d_wgrad_perimage: workspace too small");
@@ -257,6 +266,7 @@ extern "C" int sg_conv2d_wgrad_perimage(const sgConvDesc* d, const float* gy, co
 extern "C" int sg_convT2d_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y,
                               void* ws, size_t ws_bytes, sgStream stream) {
   if (check_desc(d, "sg_convT2d_fwd")) return -1;
+  sgk::t_alg_bytes = 4.0 * ((double)d->N * (d->C1) * d->H * d->W + (double)d->Cout * (d->C1) * d->KS * d->KS + (double)d->N * d->Cout * d->OH * d->OW);
   SG_ARG_CHECK(x && w && y && ws, "sg_convT2d_fwd: null pointer");
   const int Cin = d->C1, R = d->KS * d->KS;
   SG_ARG_CHECK(d->C2 == 0 && d->upsample == 1 && !d->pad_reflect, "sg_convT2d_fwd: unsupported desc");
@@ -285,6 +295,7 @@ extern "C" int sg_convT2d_fwd(const sgConvDesc* d, const float* x, const float* 
 extern "C" int sg_convT2d_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, void* ws, size_t ws_bytes,
                                 sgStream stream) {
   if (check_desc(d, "sg_convT2d_dgrad")) return -1;
+  sgk::t_alg_bytes = 4.0 * ((double)d->N * (d->C1) * d->H * d->W + (double)d->Cout * (d->C1) * d->KS * d->KS + (double)d->N * d->Cout * d->OH * d->OW);
   SG_ARG_CHECK(gy && w && gx && ws, "sg_convT2d_dgrad: null pointer");
   SG_ARG_CHECK(ws_bytes >= ktab_bytes(d->Cout * d->KS * d->KS), "sg_convT2d_dgrad: workspace too small");
   hipStream_t s = (hipStream_t)stream;
@@ -300,6 +311,7 @@ extern "C" int sg_convT2d_dgrad(const sgConvDesc* d, const float* gy, const floa
 extern "C" int sg_convT2d_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, float* gb, void* ws,
                                 size_t ws_bytes, sgStream stream) {
   if (check_desc(d, "sg_convT2d_wgrad")) return -1;
+  sgk::t_alg_bytes = 4.0 * ((double)d->N * (d->C1) * d->H * d->W + (double)d->Cout * (d->C1) * d->KS * d->KS + (double)d->N * d->Cout * d->OH * d->OW);
   SG_ARG_CHECK(gy && x && gw, "sg_convT2d_wgrad: null pointer");
   hipStream_t s = (hipStream_t)stream;
   Gather g = make_gather(gy, nullptr, d->Cout, 0, d->OH, d->OW, 1, d->H, d->W, d->stride, d->pad, 0);
@@ -744,6 +756,7 @@ bool wino_ok(const sgConvDesc* d) { return wino_tile(d) != 0; }
 // C[m][b*cols + j] = sum_k A[b][m][k] * B[b*cols + j][k]   (16 batches, everything a multiple of the tile)
 void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, int K, double flops, hipStream_t s) {
   EpRowMajor ep{Cout, nullptr, M, 16 * cols, 16 * cols, SG_ACT_NONE, 0.f, 0};
+  sgk::t_alg_bytes = 4.0 * 16.0 * ((double)M * K + (double)cols * K + (double)M * cols);
   t_batch = BatchInfo{}; t_batch.cols_per_batch = cols; t_batch.nbatch = 16; t_batch.a_stride = M * K; t_batch.batch_major = 1;
   {
     SgProfScope prof(SG_K_WINO_GEMM_128, s, flops, 0);
@@ -992,6 +1005,7 @@ extern "C" int sg_linear_fwd(const float* x, const float* w, const float* b, flo
                              int act, float slope, sgStream stream) {
   SG_ARG_CHECK(x && w && y && rows > 0 && in_f > 0 && out_f > 0, "sg_linear_fwd: bad arguments");
   SG_ARG_CHECK(dense_sizes_ok(rows, in_f, out_f), "sg_linear_fwd: operand exceeds %.0f elements", SG_MAX_ELEMS);
+  sgk::t_alg_bytes = 4.0 * ((double)rows * in_f + (double)in_f * out_f + (double)rows * out_f);
   hipStream_t s = (hipStream_t)stream;
   EpRowMajor ep{y, b, rows, out_f, out_f, act, slope, 0};
   const bool vec = (in_f % 4 == 0) && aligned16(x) && aligned16(w);
@@ -1010,6 +1024,7 @@ extern "C" int sg_linear_bwd_data(const float* gy, const float* w, float* gx, in
                                   sgStream stream) {
   SG_ARG_CHECK(gy && w && gx && rows > 0 && in_f > 0 && out_f > 0, "sg_linear_bwd_data: bad arguments");
   SG_ARG_CHECK(dense_sizes_ok(rows, in_f, out_f), "sg_linear_bwd_data: operand exceeds %.0f elements", SG_MAX_ELEMS);
+  sgk::t_alg_bytes = 4.0 * ((double)rows * in_f + (double)in_f * out_f + (double)rows * out_f);
   hipStream_t s = (hipStream_t)stream;
   EpRowMajor ep{gx, nullptr, rows, in_f, in_f, SG_ACT_NONE, 0.f, 0};
   const bool vec = (out_f % 4 == 0) && aligned16(gy);
@@ -1028,6 +1043,7 @@ extern "C" int sg_linear_bwd_weight(const float* gy, const float* x, float* gw, 
                                     int out_f, sgStream stream) {
   SG_ARG_CHECK(gy && x && gw && rows > 0 && in_f > 0 && out_f > 0, "sg_linear_bwd_weight: bad arguments");
   SG_ARG_CHECK(dense_sizes_ok(rows, in_f, out_f), "sg_linear_bwd_weight: operand exceeds %.0f elements", SG_MAX_ELEMS);
+  sgk::t_alg_bytes = 4.0 * ((double)rows * in_f + (double)in_f * out_f + (double)rows * out_f);
   hipStream_t s = (hipStream_t)stream;
   EpRowMajor ep{gw, nullptr, out_f, in_f, in_f, SG_ACT_NONE, 0.f, 0};
   {

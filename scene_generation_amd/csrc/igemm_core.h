@@ -37,6 +37,10 @@ struct Sparse { const int* list; const int* cnt; int L; const float* wimg; float
 // stream B with an event wait.
 struct TabEntry { void* dev; size_t bytes; hipEvent_t ready; hipStream_t stream; };
 using TabKey = std::array<long long, 12>;
+// algorithmic bytes (operands read once + result written once) of the GEMM launches the current entry point issues: set by
+// the C-ABI entry points, written next to each launch when SG_LAUNCH_LOG=<file> (tools/pmc_db_summary.py joins that log with
+// the PMC database in dispatch order to print traffic / algorithmic-bytes ratios)
+extern thread_local double t_alg_bytes;
 extern std::mutex g_tab_mu;
 extern std::map<TabKey, TabEntry> g_tabs;
 extern size_t g_tab_bytes;
@@ -1171,6 +1175,10 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
   bi.xcd_splitk = (xs && t_grid_z == 0 && t_fixed_kchunk == 0 && bi.cols_per_batch == 0 && bi.par.ncls == 0 && bi.ksplit == 0 &&
                    grid.z >= 8 && grid.z % 8 == 0) ? 1 : 0;
   hipLaunchKernelGGL((igemm_kernel<CFG, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, N, K, kchunk, bi);
+  static FILE* lf = nullptr;
+  static int lf_init = 0;
+  if (!lf_init) { lf_init = 1; const char* e = getenv("SG_LAUNCH_LOG"); if (e && *e) lf = fopen(e, "a"); }
+  if (lf) { fprintf(lf, "%u %u %d %d %d %.0f\n", grid.x * 256u, grid.z, M, N, K, sgk::t_alg_bytes); fflush(lf); }
   return 0;
 }
 
@@ -1405,6 +1413,10 @@ inline NkPlan nk_plan(int M, int C, int KS2, int Kpix, bool two) {
   const int maxs = Kpix / (BK * 8) > 0 ? Kpix / (BK * 8) : 1;
   if (s > maxs) s = maxs;
   if (s > 64) s = 64;
+  // XCD-pinned split-K (SG_XCD_SPLITK, launch_cfg): needs a multiple of 8 k-chunks
+  static int xs8 = -1;
+  if (xs8 < 0) { const char* e = getenv("SG_XCD_SPLITK"); xs8 = e ? atoi(e) : 0; }
+  if (xs8 && s >= 6) { s = (s + 7) / 8 * 8; if (s > maxs) s = maxs / 8 * 8; if (s < 8) s = 8 <= maxs ? 8 : (int)((target + tiles - 1) / tiles); }
   p.splits = s < 1 ? 1 : s;
   return p;
 }

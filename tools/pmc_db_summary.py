@@ -3,7 +3,10 @@ stored as rocpd sqlite databases.  Prints a table and, with --json, writes {prof
 roofline.traffic.  Corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes: the counters are in KiB; on gfx950
 FETCH_SIZE reports half of the bytes of wide coalesced reads (x2); WRITE_SIZE is calibrated on adam_kernel, whose traffic is
 known exactly (16 B read + 12 B written per parameter).
-usage: python tools/pmc_db_summary.py <fetch.db> <write.db> [--json out.json]"""
+With --launch-log <file> (the SG_LAUNCH_LOG of the FETCH pass: one line per igemm launch, in launch order, carrying the
+ALGORITHMIC bytes of the conv / GEMM it belongs to -- operands read once + result written once) the table gains an
+"algorithmic MB/launch" column and the ratio (fetched + written) / algorithmic: > 1 = operands re-fetched from beyond L2.
+usage: python tools/pmc_db_summary.py <fetch.db> <write.db> [--json out.json] [--launch-log log.txt]"""
 import collections
 import json
 import re
@@ -32,6 +35,36 @@ def load(path, counter):
     return agg
 
 
+def load_alg(path, logpath):
+    """{(kernel, grid): mean algorithmic bytes per launch}: igemm dispatches of the FETCH pass in dispatch order, matched
+    one-to-one with the lines of the launch log (same process, single stream, graphs off)"""
+    db = sqlite3.connect(path)
+    rows = db.execute('select dispatch_id, kernel_name, grid_size from counters_collection where counter_name = ? '
+                      'order by dispatch_id', ('FETCH_SIZE',)).fetchall()
+    seen, disp = set(), []
+    for did, name, grid in rows:
+        if did in seen or 'igemm_kernel' not in name:
+            continue
+        seen.add(did)
+        disp.append((short(name), grid))
+    log = [l.split() for l in open(logpath) if l.strip()]
+    out = collections.defaultdict(lambda: [0, 0.0])
+    if len(log) != len(disp):
+        print('(launch log has %d lines, the database %d igemm dispatches: algorithmic column omitted)' % (len(log), len(disp)))
+        return {}
+    bad = 0
+    for (k, grid), l in zip(disp, log):
+        if int(l[0]) * max(int(l[1]), 1) != grid:
+            bad += 1
+            continue
+        a = out[(k, grid)]
+        a[0] += 1
+        a[1] += float(l[5])
+    if bad:
+        print('(%d of %d launches did not line up with the log and were skipped)' % (bad, len(log)))
+    return {k: v[1] / v[0] for k, v in out.items() if v[0]}
+
+
 def main():
     f, w = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
     # calibration: the largest adam launch (the generator's flat buffer)
@@ -42,8 +75,9 @@ def main():
     print('calibration on adam_kernel (%d parameters): read %.1f MB vs %.1f expected (x2 applied), written %.1f MB vs %.1f expected'
           % (n_params, rd_adam / 1e6, 16.0 * n_params / 1e6, wr_adam / 1e6, 12.0 * n_params / 1e6))
     wcal = 12.0 * n_params / wr_adam
-    print('| kernel | grid | launches | fetch MB/launch (x2) | write MB/launch (x%.3f) | avg us | GB/s |' % wcal)
-    print('|---|---|---|---|---|---|---|')
+    alg = load_alg(sys.argv[1], sys.argv[sys.argv.index('--launch-log') + 1]) if '--launch-log' in sys.argv else {}
+    print('| kernel | grid | launches | fetch MB/launch (x2) | write MB/launch (x%.3f) | avg us | GB/s | algorithmic MB/launch | traffic / algorithmic |' % wcal)
+    print('|---|---|---|---|---|---|---|---|---|')
     out = {}
     tot = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
     for k, a in sorted(f.items(), key=lambda kv: -kv[1][1]):
@@ -52,7 +86,10 @@ def main():
         t = tot[k[0]]
         t[0] += a[0]; t[1] += 2 * a[1]; t[2] += wcal * b[1] * a[0] / max(b[0], 1); t[3] += a[2]
         if a[1] * 2 > 0.005 * sum(x[1] * 2 for x in f.values()):
-            print('| %s | %d | %d | %.1f | %.1f | %.1f | %.0f |' % (k[0], k[1], a[0], fe / 1e6, wr / 1e6, us, (fe + wr) / us / 1e3))
+            ab = alg.get(k)
+            print('| %s | %d | %d | %.1f | %.1f | %.1f | %.0f | %s | %s |' % (
+                k[0], k[1], a[0], fe / 1e6, wr / 1e6, us, (fe + wr) / us / 1e3, '%.1f' % (ab / 1e6) if ab else '',
+                '%.2f' % ((fe + wr) / ab) if ab else ''))
     if '--json' in sys.argv:
         names = {'igemm<T128x128, LoadKContig<128, true, false>, LoadKContig<128, true, false>, EpRowMajorPlain>': 'wino_bgemm_t128'}
         for kname, kind in names.items():
@@ -61,7 +98,7 @@ def main():
                 out[kind] = {'bytes_per_launch': (t[1] + t[2]) / t[0], 'fetch_bytes_per_launch': t[1] / t[0],
                              'write_bytes_per_launch': t[2] / t[0], 'launches_sampled': t[0],
                              'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 (gfx950), WRITE '
-                                       'calibrated on adam_kernel: tools/pmc_db_summary.py, profiles/r02_pmc_traffic.md'}
+                                       'calibrated on adam_kernel: tools/pmc_db_summary.py, profiles/r03_pmc_traffic.md'}
         json.dump(out, open(sys.argv[sys.argv.index('--json') + 1], 'w'), indent=1)
 
 
