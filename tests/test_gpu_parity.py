@@ -805,7 +805,8 @@ def test_full_width_step_vs_reference_golden(hip, golden, tag):
     devs = run_step_full(golden('step_full_' + tag), make, to_device=lambda b: batch_to(b, DEV))
     _dump('parity_step_full_%s.json' % tag, [{k: (float(v) if not isinstance(v, str) else v) for k, v in d.items()} for d in devs])
     tols = [dict(loss=2e-6, out_abs=1e-4, out_stat=2e-6, param_stat=5e-4),
-            dict(loss=1.5e-3, out_abs=0.1, out_stat=1.5e-3, param_stat=6e-4)]
+            dict(loss=1.5e-3, out_abs=0.1, out_stat=1.5e-3, param_stat=6e-4) if tag == 'c2' else
+            dict(loss=6e-3, out_abs=0.2, out_stat=1.5e-3, param_stat=8e-4)]
     for it, (dev, tol) in enumerate(zip(devs, tols)):
         for k, t in tol.items():
             assert dev[k] <= t, (tag, it, k, dev[k], t, dev)

@@ -295,8 +295,12 @@ def test_eval_hooks_vs_reference(golden):
 # (m/sqrt(v) = +-1 when v = g^2): every parameter whose gradient is within round-off of zero moves by +-lr depending on the
 # rounding of the implementation -- e.g. the conv biases in front of InstanceNorm, whose true gradient is exactly 0 -- so
 # post-step parameters agree to ~lr and the second iteration's outputs to a few 1e-2.
-STEP_FULL_TOL = [dict(loss=5e-7, out_abs=4e-5, out_stat=1e-6, param_stat=5e-4),
-                 dict(loss=1.5e-3, out_abs=0.1, out_stat=1.5e-3, param_stat=6e-4)]
+# With 4 small images (c1) a single flipped update moves the second iteration more than with 8 larger ones (c2): measured
+# iteration-1 deviations of the oracle: c2 loss 6.3e-4 / outputs 4.0e-2, c1 loss 2.6e-3 / outputs 9.8e-2.
+STEP_FULL_TOL = {'c2': [dict(loss=5e-7, out_abs=4e-5, out_stat=1e-6, param_stat=5e-4),
+                        dict(loss=1.5e-3, out_abs=0.1, out_stat=1.5e-3, param_stat=6e-4)],
+                 'c1': [dict(loss=1e-6, out_abs=4e-5, out_stat=1e-6, param_stat=5e-4),
+                        dict(loss=6e-3, out_abs=0.2, out_stat=1.5e-3, param_stat=8e-4)]}
 
 
 @pytest.mark.parametrize('tag', ['c2', 'c1'])
@@ -306,7 +310,7 @@ def test_full_width_step_vs_reference(golden, tag):
     named losses, output checksums + slices and the checksum of EVERY post-step parameter / buffer of the oracle agree."""
     from step_full_common import run_step_full
     devs = run_step_full(golden('step_full_' + tag), lambda a, v: O.Trainer(a, v))
-    for it, (dev, tol) in enumerate(zip(devs, STEP_FULL_TOL)):
+    for it, (dev, tol) in enumerate(zip(devs, STEP_FULL_TOL[tag])):
         for k, t in tol.items():
             assert dev[k] <= t, (tag, it, k, dev[k], t, dev)
 
