@@ -397,6 +397,68 @@ struct LoadGatherKN {
   }
 };
 
+// B operand of conv fwd / dgrad when every 16-deep k-tile holds WHOLE channels: taps per channel NT = 1 << lg divides 16
+// (4x4 kernels: 16 taps; 1x1: 1; the parity classes of stride-2 3x3 / 4x4 transposed gathers: 1, 2 or 4) and K % 16 == 0.
+// The ROWS consecutive k a thread owns then always name the SAME taps, only the channel advances with the k-loop:
+//   * the (pixel, tap) byte offsets are computed once in init() and stay in ROWS VGPRs (invalid taps / pixel tail: 2^31,
+//     which the range check of the buffer load rejects => 0),
+//   * the channel offset is wave-uniform and goes into the SGPR offset operand of the buffer load.
+// A gathered element costs one VMEM instruction and NO vector-ALU work, no LDS tap table, no k-split table (LoadGatherKN:
+// 1 LDS read + 3 VALU per element and a scalar table fetch per tile whose lgkmcnt wait sat in front of the MFMAs; the f32 MFMA
+// does not overlap with VALU work).
+struct FixedTaps { int lg; unsigned tapcode; };      // lg < 4: tap ids of the class in the nibbles of tapcode; lg == 4: identity
+template <int BN, int MODE>
+struct LoadFixedKN {
+  Gather g; int Npix; int KS; int lg; unsigned tapcode;
+  static constexpr int LDS_INTS = 0;
+  static constexpr int ROWS = BN * BK / 256;
+  struct Stage { float r[ROWS]; };
+  int nl_, kr_;
+  unsigned voff_[ROWS];
+  unsigned shw4_;
+  __device__ __forceinline__ void set_batch(int, int, int) {}
+  __device__ __forceinline__ void init(int n0, int tid, int*, int, int) {
+    nl_ = tid % BN;
+    kr_ = __builtin_amdgcn_readfirstlane((tid / BN) * ROWS);   // wave-uniform (BN >= 64)
+    const int n = n0 + nl_;
+    const bool okn = n < Npix;
+    const int nn = okn ? n : 0;
+    const int phw = g.PH * g.PW;
+    const int img = nn / phw;
+    const int pix = nn - img * phw;
+    const int pi = pix / g.PW;
+    const int ph = pi * g.pstep + g.ph0, pw = (pix - pi * g.PW) * g.pstep + g.pw0;
+    int ah, aw;
+    if (MODE == 0) { ah = ph * g.stride - g.pad; aw = pw * g.stride - g.pad; }
+    else { ah = ph + g.pad; aw = pw + g.pad; }
+    const unsigned shw = (unsigned)(g.SH * g.SW);
+    shw4_ = shw * 4u;
+    const unsigned img1 = (unsigned)img * (unsigned)g.C1 * shw;
+    const int nt = 1 << lg;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const int ti = (kr_ + i) & (nt - 1);
+      const int t = lg == 4 ? ti : (int)((tapcode >> (4 * ti)) & 15u);
+      const int kh = t / KS, kw = t - kh * KS;
+      const int v = okn ? tap_offset<MODE>(g, ah, aw, kh, kw) : -1;
+      voff_[i] = v < 0 ? 0x80000000u : (img1 + (unsigned)v) * 4u;
+    }
+  }
+  __device__ __forceinline__ void prefetch(Stage&, int) const {}
+  __device__ __forceinline__ void load(Stage& st, int k0, int) const {
+    const __amdgpu_buffer_rsrc_t r1 = sg_rsrc(g.src1);
+    // channel of element i = (k0 + kr_ + i) >> lg; kr_ is a multiple of ROWS and k0 of 16, so it splits into a per-tile
+    // scalar and a loop-invariant per-element scalar
+    const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)(k0 + kr_) >> lg) * shw4_));
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const unsigned so = sb + (unsigned)(i >> lg) * shw4_;
+      st.r[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, (int)voff_[i], (int)so, 0));
+    }
+  }
+  __device__ __forceinline__ void store(const Stage& st, float* T) const { store_krun<ROWS, false>(T, nl_, kr_, st.r, 0u); }
+};
+
 // k -> (image, pixel) tables of the weight-gradient loaders.  k = img*PQ + pix walks every pixel of every image; splitting it
 // costs a division, and the gather side needs a 2-D decode plus padding / reflection on top (~50 VALU instructions).  Done
 // per 16-pixel k-tile by a few lanes it sat in EVERY wave's instruction stream (61 VALU per 8 MFMA in the 64x64 kernel: the
@@ -867,6 +929,7 @@ struct EpWgrad {     // tap-major virtual column n = t*cpad + cj  ->  slab[z][m]
 struct ParityClasses {
   int ncls; int tile0[5]; int Npix[4]; int K[4]; int PH[4], PW[4], ph0[4], pw0[4]; unsigned aoff[4];
   const void* ktab[4];
+  int lg[4]; unsigned tapcode[4];        // LoadFixedKN: taps per channel (log2) and tap ids of each class
 };
 struct BatchInfo {
   int cols_per_batch; int nbatch; const int* kcnt; int a_stride; int b_stride;
@@ -890,6 +953,11 @@ template <int BN, int KS, int MODE, bool TWO, bool MASK>
 __device__ __forceinline__ void set_class_b(LoadGatherKN<BN, KS, MODE, TWO, MASK>& l, const ParityClasses& p, int c) {
   l.ktab = reinterpret_cast<const KEntry*>(p.ktab[c]);
   l.g.PH = p.PH[c]; l.g.PW = p.PW[c]; l.g.ph0 = p.ph0[c]; l.g.pw0 = p.pw0[c]; l.Npix = p.Npix[c];
+}
+template <int BN, int MODE>
+__device__ __forceinline__ void set_class_b(LoadFixedKN<BN, MODE>& l, const ParityClasses& p, int c) {
+  l.g.PH = p.PH[c]; l.g.PW = p.PW[c]; l.g.ph0 = p.ph0[c]; l.g.pw0 = p.pw0[c]; l.Npix = p.Npix[c];
+  l.lg = p.lg[c]; l.tapcode = p.tapcode[c];
 }
 __device__ __forceinline__ void set_class_ep(EpNCHW& e, const ParityClasses& p, int c) {
   e.PHW = p.PH[c] * p.PW[c]; e.Npix = p.Npix[c]; e.PWs = p.PW[c]; e.h0 = p.ph0[c]; e.w0 = p.pw0[c];
@@ -1271,11 +1339,19 @@ Gather make_gather(const float* s1, const float* s2, int C1, int C2, int SH, int
   return g;
 }
 
+inline bool fixed_taps_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("SG_FIXEDTAP"); on = e ? atoi(e) : 1; }
+  return on != 0;
+}
+
 // ---- conv-shaped GEMM: K = (c, taps), N = pixels -------------------------------------------------
 template <class CFG, int BM, int BN, int KS, int MODE>
 int launch_ab(const float* A, int K, int M, bool vec, const Gather& g, int Npix, const KEntry* ktab, const EpNCHW& ep,
-              int splits, bool nomask, hipStream_t s) {
+              int splits, bool nomask, hipStream_t s, const FixedTaps* fx = nullptr) {
   const bool two = g.C2 > 0;
+  if (fx && vec && !two)          // whole channels per k-tile: taps fixed per thread, channel offset in an SGPR (LoadFixedKN)
+    return launch_cfg<CFG>(LoadKContig<BM, true>{A, K, M}, LoadFixedKN<BN, MODE>{g, Npix, KS, fx->lg, fx->tapcode}, ep, M, Npix, K, splits, s);
   if (MODE == 0 && two) {                                 // channel-concatenated sources only exist on the forward gather
     if (vec) {
       if (nomask) return launch_cfg<CFG>(LoadKContig<BM, true, false>{A, K, M}, LoadGatherKN<BN, KS, MODE, true, false>{g, Npix, ktab}, ep, M, Npix, K, splits, s);
@@ -1344,13 +1420,17 @@ int run_kn(const float* A, int M, int K, const Gather& g, int NB, const float* b
   const size_t nout = (size_t)M * Npix;
   EpNCHW ep{out, bias, g.PH * g.PW, Mtot, M, Npix, act, slope, 0, 0, 1, 0, 0, 0, 0};
   if (splits > 1) ep = EpNCHW{slabs, nullptr, g.PH * g.PW, Mtot, M, Npix, SG_ACT_NONE, 0.f, nout, 0, 1, 0, 0, 0, 0};
+  // 4x4 and 1x1 kernels on one source with whole channels per k-tile: fixed taps per thread (LoadFixedKN)
+  const FixedTaps fixed{KS == 4 ? 4 : 0, 0u};
+  const bool use_fixed = fixed_taps_enabled() && (KS == 4 || KS == 1) && vec && g.C2 == 0 && K % BK == 0 && vstride == 0;
+  const FixedTaps* fx = use_fixed ? &fixed : nullptr;
   {
     SgProfScope prof(sg_igemm_kind(MODE, KS, tile), s, flops, 0);
     switch (tile) {
-      case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, MODE>(A, K, M, true, g, Npix, ktab, ep, splits, nomask, s); break;
-      case 1: launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, nomask, s); break;
-      case 3: launch_ab<typename CfgFor<KS>::C64W, 64, 128, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, nomask, s); break;
-      default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, nomask, s); break;
+      case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, MODE>(A, K, M, true, g, Npix, ktab, ep, splits, nomask, s, fx); break;
+      case 1: launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, nomask, s, fx); break;
+      case 3: launch_ab<typename CfgFor<KS>::C64W, 64, 128, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, nomask, s, fx); break;
+      default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, MODE>(A, K, M, vec, g, Npix, ktab, ep, splits, nomask, s, fx); break;
     }
   }
   if (splits > 1)

@@ -53,6 +53,7 @@ int run_kn_parity(const float* W, int Rdim, int B, int m0, int M, const Gather& 
   PermClasses pc = {};
   int maxNpix = 0;
   bool vec = aligned16(wbase);
+  bool fixed_ok = fixed_taps_enabled() && KS <= 4;      // every class has 1, 2 or 4 taps and whole channels per k-tile
   double flops_issued = 0.0;
   for (int a = 0; a < 2; ++a) {
     for (int b = 0; b < 2; ++b) {
@@ -76,6 +77,10 @@ int run_kn_parity(const float* W, int Rdim, int B, int m0, int M, const Gather& 
                                                       reinterpret_cast<KEntry*>(dst), K, Kpad, shw, KS2, tl);
                                  });
       SG_ARG_CHECK(par.ktab[c] != nullptr, "conv: device allocation of a k-split table failed");
+      par.lg[c] = tl.n == 1 ? 0 : (tl.n == 2 ? 1 : (tl.n == 4 ? 2 : -1));
+      par.tapcode[c] = 0u;
+      for (int q = 0; q < tl.n && q < 4; ++q) par.tapcode[c] |= (unsigned)tl.t[q] << (4 * q);
+      fixed_ok = fixed_ok && par.lg[c] >= 0 && K % BK == 0;
       vec = vec && (K % 4 == 0);
       maxNpix = par.Npix[c] > maxNpix ? par.Npix[c] : maxNpix;
       flops_issued += flops * (4.0 * tl.n * PHa * PWb) / ((double)KS2 * g.PH * g.PW);
@@ -103,13 +108,15 @@ int run_kn_parity(const float* W, int Rdim, int B, int m0, int M, const Gather& 
   const KEntry* kt0 = reinterpret_cast<const KEntry*>(par.ktab[0]);
   t_batch = BatchInfo{};
   t_batch.par = par;
+  const FixedTaps fixed{par.lg[0], par.tapcode[0]};
+  const FixedTaps* fx = (fixed_ok && vec) ? &fixed : nullptr;
   {
     SgProfScope prof(sg_igemm_kind(1, KS, tile), s, flops_issued, 0);
     switch (tile) {
-      case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, 1>(wbase, par.K[0], M, true, gs, par.Npix[0], kt0, ep, 1, false, s); break;
-      case 1: launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, 1>(wbase, par.K[0], M, vec, gs, par.Npix[0], kt0, ep, 1, false, s); break;
-      case 3: launch_ab<typename CfgFor<KS>::C64W, 64, 128, KS, 1>(wbase, par.K[0], M, vec, gs, par.Npix[0], kt0, ep, 1, false, s); break;
-      default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, 1>(wbase, par.K[0], M, vec, gs, par.Npix[0], kt0, ep, 1, false, s); break;
+      case 0: launch_ab<typename CfgFor<KS>::C128, 128, 128, KS, 1>(wbase, par.K[0], M, true, gs, par.Npix[0], kt0, ep, 1, false, s, fx); break;
+      case 1: launch_ab<typename CfgFor<KS>::C64, 64, 64, KS, 1>(wbase, par.K[0], M, vec, gs, par.Npix[0], kt0, ep, 1, false, s, fx); break;
+      case 3: launch_ab<typename CfgFor<KS>::C64W, 64, 128, KS, 1>(wbase, par.K[0], M, vec, gs, par.Npix[0], kt0, ep, 1, false, s, fx); break;
+      default: launch_ab<typename CfgFor<KS>::C32, 32, 128, KS, 1>(wbase, par.K[0], M, vec, gs, par.Npix[0], kt0, ep, 1, false, s, fx); break;
     }
   }
   t_batch = BatchInfo{};
