@@ -42,7 +42,8 @@ int check_desc(const sgConvDesc* d, const char* who) {
 
 inline size_t wgrad_ws(int M, int C, int KS2, int Kpix, bool two) {
   const NkPlan pl = nk_plan(M, C, KS2, Kpix, two);
-  return (size_t)pl.splits * (size_t)M * KS2 * (pl.tap ? pl.cpad : C) * sizeof(float);
+  // (+ M per k-chunk: the row sums that become the bias gradient, see nk_run)
+  return (size_t)pl.splits * ((size_t)M * KS2 * (pl.tap ? pl.cpad : C) + (size_t)M) * sizeof(float);
 }
 
 }  // namespace
@@ -173,9 +174,10 @@ extern "C" int sg_conv2d_wgrad(const sgConvDesc* d, const float* gy, const float
   Gather g = make_gather(x1, x2, d->C1, d->C2, d->H, d->W, d->upsample, d->OH, d->OW, d->stride, d->pad, d->pad_reflect);
   g.bcast2 = d->x2_broadcast;
   const double flops = 2.0 * d->Cout * (double)(d->C1 + d->C2) * d->KS * d->KS * d->N * d->OH * d->OW;
-  if (int rc = sgk::nk_run(d->KS, gy, d->Cout, d->Cout, g, d->N, gw, ws, ws ? ws_bytes : 0, flops, s, nullptr)) return rc;
+  bool gb_done = false;      // the weight-gradient GEMM reads all of gy anyway: its loaders also produce the bias gradient
+  if (int rc = sgk::nk_run(d->KS, gy, d->Cout, d->Cout, g, d->N, gw, ws, ws ? ws_bytes : 0, flops, s, nullptr, gb, &gb_done)) return rc;
   SG_LAUNCH_CHECK("sg_conv2d_wgrad");
-  if (gb) return sg_channel_sum(gy, gb, d->N, d->Cout, d->OH * d->OW, ws, ws ? ws_bytes : 0, stream);
+  if (gb && !gb_done) return sg_channel_sum(gy, gb, d->N, d->Cout, d->OH * d->OW, ws, ws ? ws_bytes : 0, stream);
   return 0;
 }
 

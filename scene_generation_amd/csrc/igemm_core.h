@@ -55,8 +55,10 @@ int kn_sparse_run(int KS, const float* W, int M, int K, const Gather& g, int NB,
                   float slope, const Sparse& sp, void* ws, hipStream_t s);
 int kn_parity_run(int KS, const float* W, int Rdim, int B, int m0, int M, const Gather& g, int NB, const float* bias,
                   float* out, int Mtot, int act, float slope, double flops, void* ws, size_t ws_bytes, hipStream_t s);
+// gb (optional): row sums of A over all pixels = the bias gradient, produced by the GEMM's own loaders when the launch plan
+// allows it; *gb_done says whether it was (else the caller runs sg_channel_sum)
 int nk_run(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, float* out, void* ws, size_t ws_bytes,
-           double flops, hipStream_t s, const Sparse* sp);
+           double flops, hipStream_t s, const Sparse* sp, float* gb = nullptr, bool* gb_done = nullptr);
 }  // namespace sgk
 
 namespace {
@@ -473,19 +475,36 @@ constexpr int KBLK = 256;
 template <int BM>
 struct LoadPixKVec {
   const float* base; int M, Mtot, PQ; FastDiv dPQ;
+  float* rowsum;                 // optional [z][M] slab: row sums of the operand over the workgroup's k-range (= bias gradient)
   static constexpr int LDS_INTS = 2 * KBLK;
   static constexpr int Q = (BM * 4 + 255) / 256;
   struct Stage { float4 r[Q]; unsigned ok; };
-  int row_, kq_, tid_, kbeg_, kend_;
+  int row_, kq_, tid_, kbeg_, kend_, m0_;
   unsigned rowoff_[Q];
   int* lds_;
+  mutable float racc_[Q];
+  bool rs_on_ = false;
   __device__ __forceinline__ void init(int m0, int tid, int* lds, int kbeg, int kend) {
-    row_ = tid >> 2; kq_ = (tid & 3) * 4; tid_ = tid; lds_ = lds; kbeg_ = kbeg; kend_ = kend;
+    row_ = tid >> 2; kq_ = (tid & 3) * 4; tid_ = tid; lds_ = lds; kbeg_ = kbeg; kend_ = kend; m0_ = m0;
 #pragma unroll
     for (int i = 0; i < Q; ++i) {
       // rows beyond M read the last valid row: their products land in accumulator rows the epilogue never stores
       const int m = min(m0 + row_ + 64 * i, M - 1);
       rowoff_[i] = (unsigned)m * (unsigned)PQ;
+      racc_[i] = 0.f;
+    }
+  }
+  // row sums (see rowsum): only the workgroups of the first column tile accumulate (uniform branch in store())
+  __device__ __forceinline__ void rowsum_begin(bool first_col_tile) { rs_on_ = rowsum != nullptr && first_col_tile; }
+  __device__ __forceinline__ void rowsum_finish(int z) const {
+    if (!rs_on_) return;
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+      float v = racc_[i];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      const int m = m0_ + row_ + 64 * i;
+      if ((tid_ & 3) == 0 && row_ + 64 * i < BM && m < M) rowsum[(size_t)z * M + m] = v;
     }
   }
   __device__ __forceinline__ void set_batch(int, int, int) {}
@@ -519,6 +538,7 @@ struct LoadPixKVec {
         if (!st.ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
         *reinterpret_cast<float4*>(T + (row_ + 64 * i) * LDK + kq_) = v;
+        if (rs_on_) racc_[i] += (v.x + v.y) + (v.z + v.w);
       }
     }
   }
@@ -528,11 +548,32 @@ struct LoadPixKVec {
 template <int BM, bool MASK = true>
 struct LoadPixK {
   const float* base; int M, Mtot, PQ; FastDiv dPQ;
+  float* rowsum;                 // see LoadPixKVec
   static constexpr int LDS_INTS = 0;
   static constexpr int ROWS = BM / 16;
   struct Stage { float r[ROWS]; unsigned ok; };
   int m0_, mr_, kl_;
-  __device__ __forceinline__ void init(int m0, int tid, int*, int, int) { m0_ = m0; kl_ = tid & 15; mr_ = tid >> 4; }
+  mutable float racc_[ROWS];
+  bool rs_on_ = false;
+  __device__ __forceinline__ void init(int m0, int tid, int*, int, int) {
+    m0_ = m0; kl_ = tid & 15; mr_ = tid >> 4;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) racc_[i] = 0.f;
+  }
+  __device__ __forceinline__ void rowsum_begin(bool first_col_tile) { rs_on_ = rowsum != nullptr && first_col_tile; }
+  __device__ __forceinline__ void rowsum_finish(int z) const {
+    if (!rs_on_) return;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      float v = racc_[i];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8);
+      const int m = m0_ + mr_ + 16 * i;
+      if (kl_ == 0 && m < M) rowsum[(size_t)z * M + m] = v;
+    }
+  }
   __device__ __forceinline__ void set_batch(int, int, int) {}
   __device__ __forceinline__ void prefetch(Stage&, int) const {}
   __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
@@ -556,8 +597,11 @@ struct LoadPixK {
   }
   __device__ __forceinline__ void store(const Stage& st, float* T) const {
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i)
-      T[(mr_ + 16 * i) * LDK + kl_] = (SG_BUFLOAD || !MASK || ((st.ok >> i) & 1u)) ? st.r[i] : 0.f;
+    for (int i = 0; i < ROWS; ++i) {
+      const float v = (SG_BUFLOAD || !MASK || ((st.ok >> i) & 1u)) ? st.r[i] : 0.f;
+      T[(mr_ + 16 * i) * LDK + kl_] = v;
+      if (rs_on_) racc_[i] += v;
+    }
   }
 };
 
@@ -944,6 +988,12 @@ struct BatchInfo {
   ParityClasses par;
 };
 // per-class hooks: loaders / epilogues that can run a parity class overload these; everything else ignores the call
+template <class L> __device__ __forceinline__ void rowsum_begin(L&, bool) {}
+template <class L> __device__ __forceinline__ void rowsum_finish(const L&, int) {}
+template <int BM> __device__ __forceinline__ void rowsum_begin(LoadPixKVec<BM>& l, bool f) { l.rowsum_begin(f); }
+template <int BM> __device__ __forceinline__ void rowsum_finish(const LoadPixKVec<BM>& l, int z) { l.rowsum_finish(z); }
+template <int BM, bool MASK> __device__ __forceinline__ void rowsum_begin(LoadPixK<BM, MASK>& l, bool f) { l.rowsum_begin(f); }
+template <int BM, bool MASK> __device__ __forceinline__ void rowsum_finish(const LoadPixK<BM, MASK>& l, int z) { l.rowsum_finish(z); }
 template <class L> __device__ __forceinline__ void set_class_a(L&, unsigned, int) {}
 template <class L> __device__ __forceinline__ void set_class_b(L&, const ParityClasses&, int) {}
 template <class E> __device__ __forceinline__ void set_class_ep(E&, const ParityClasses&, int) {}
@@ -1033,6 +1083,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
 
   al.init(m0, tid, tapA, kbeg, kend);
   bl.init(n0, tid, tapB, kbeg, kend);
+  rowsum_begin(al, n0 == 0);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -1123,6 +1174,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
       mma(fa[(P - 1) & 1], fb[(P - 1) & 1]);
       buf ^= 1;
     }
+    rowsum_finish(al, bi.xcd_splitk ? zblk : (int)blockIdx.z);
     ep.store(acc, m0 + wm0, n0 + wn0, lane, bi.xcd_splitk ? zblk : (int)blockIdx.z);
     return;
   }
@@ -1174,6 +1226,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     __syncthreads();
     buf ^= 1;
   }
+  rowsum_finish(al, bi.xcd_splitk ? zblk : (int)blockIdx.z);
   ep.store(acc, m0 + wm0, n0 + wn0, lane, bi.xcd_splitk ? zblk : (int)blockIdx.z);
 }
 

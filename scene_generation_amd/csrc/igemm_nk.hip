@@ -50,14 +50,19 @@ __global__ void sparse_wgrad_perimage_kernel(const float* slabs, const int* cnt,
 // gw[m][c][t] = sum_z slab[z][m][t][c]: un-permutes the tap-major slabs of the weight-gradient GEMM (the GEMM epilogue
 // writes them coalesced; scattering 4-byte stores at stride KS2*4 from there cost 8x write amplification in HBM)
 __global__ void wgrad_unpermute_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ gw, int M, int C, int KS2,
-                                              int cpad, int S) {
+                                              int cpad, int S, const float* __restrict__ rowsum, float* __restrict__ gb) {
   // grid (ceil(C*KS2 / 256), M): one 32-bit division per thread.  (An LDS-transposed variant with fully coalesced slab reads
   // was measured SLOWER -- 21.7 vs 15.7 us per launch: the strided reads hit in L2, the extra barrier and the thinner loops
   // do not pay.)
   const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int m = blockIdx.y;
+  if (gb && j == 0) {                     // bias gradient: the k-chunks' row sums of gy (LoadPixK*::rowsum), fixed order
+    float b = 0.f;
+    for (int z = 0; z < S; ++z) b += rowsum[(size_t)z * M + m];
+    gb[m] = b;
+  }
   if (j >= (unsigned)(C * KS2)) return;
   const unsigned c = j / (unsigned)KS2, t = j - c * (unsigned)KS2;
-  const int m = blockIdx.y;
   const size_t zs = (size_t)M * KS2 * cpad;
   const float* p = slabs + ((size_t)m * KS2 + t) * cpad + c;
   float v = 0.f;
@@ -68,31 +73,32 @@ __global__ void wgrad_unpermute_reduce_kernel(const float* __restrict__ slabs, f
 template <int KS>
 void launch_nk_general(int tile, const float* A, int M, int Mtot, int PQ, const Gather& g, int Ncols, const EpRowMajor& ep,
                        int Kpix, int splits, hipStream_t s, const Sparse* sp = nullptr, int zdiv = 1) {
+  float* const rowsum = nullptr;
   const FastDiv dPQ((unsigned)PQ);
   const int* sl = sp ? sp->list : nullptr; const int* sc = sp ? sp->cnt : nullptr; const int L = sp ? sp->L : 0;
   if (tile == 2)
-    launch_cfg<CfgW32>(LoadPixK<32>{A, M, Mtot, PQ, dPQ}, LoadGatherNK<128, KS, false, true, NSW>{g, Ncols, sl, sc, L, zdiv}, ep,
+    launch_cfg<CfgW32>(LoadPixK<32>{A, M, Mtot, PQ, dPQ, rowsum}, LoadGatherNK<128, KS, false, true, NSW>{g, Ncols, sl, sc, L, zdiv}, ep,
                        M, Ncols, Kpix, splits, s);
   else
-    launch_cfg<CfgW64>(LoadPixK<64>{A, M, Mtot, PQ, dPQ}, LoadGatherNK<64, KS, false, true, NSW>{g, Ncols, sl, sc, L, zdiv}, ep,
+    launch_cfg<CfgW64>(LoadPixK<64>{A, M, Mtot, PQ, dPQ, rowsum}, LoadGatherNK<64, KS, false, true, NSW>{g, Ncols, sl, sc, L, zdiv}, ep,
                        M, Ncols, Kpix, splits, s);
 }
 
 template <class CFG, int BMv, int BNv>
 void launch_nk_tap(const float* A, int M, int Mtot, int PQ, bool vecA, const Gather& g, int KS, int Ccols, int cpad,
-                   const Sparse* sp, bool nomask, const EpWgrad& ep, int Kpix, int splits, hipStream_t s) {
+                   const Sparse* sp, bool nomask, const EpWgrad& ep, int Kpix, int splits, hipStream_t s, float* rowsum) {
   const FastDiv dPQ((unsigned)PQ), dPW((unsigned)g.PW);
   const int* sl = sp ? sp->list : nullptr; const int* sc = sp ? sp->cnt : nullptr; const int L = sp ? sp->L : 0;
   const int Nv = KS * KS * cpad;
   const bool two = g.C2 > 0;
 #define SG_TAP_B(TWOv, MASKv) LoadTapNK<BNv, TWOv, MASKv, CFG::NSUB>{g, KS, Ccols, cpad, sl, sc, L, dPQ, dPW}
   if (vecA) {
-    const LoadPixKVec<BMv> al{A, M, Mtot, PQ, dPQ};
+    const LoadPixKVec<BMv> al{A, M, Mtot, PQ, dPQ, rowsum};
     if (two) launch_cfg<CFG>(al, SG_TAP_B(true, true), ep, M, Nv, Kpix, splits, s);
     else if (nomask) launch_cfg<CFG>(al, SG_TAP_B(false, false), ep, M, Nv, Kpix, splits, s);
     else launch_cfg<CFG>(al, SG_TAP_B(false, true), ep, M, Nv, Kpix, splits, s);
   } else {
-    const LoadPixK<BMv> al{A, M, Mtot, PQ, dPQ};
+    const LoadPixK<BMv> al{A, M, Mtot, PQ, dPQ, rowsum};
     if (two) launch_cfg<CFG>(al, SG_TAP_B(true, true), ep, M, Nv, Kpix, splits, s);
     else if (nomask) launch_cfg<CFG>(al, SG_TAP_B(false, false), ep, M, Nv, Kpix, splits, s);
     else launch_cfg<CFG>(al, SG_TAP_B(false, true), ep, M, Nv, Kpix, splits, s);
@@ -101,7 +107,8 @@ void launch_nk_tap(const float* A, int M, int Mtot, int PQ, bool vecA, const Gat
 }
 
 int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, float* out, void* ws, size_t ws_bytes,
-              double flops, hipStream_t s, const Sparse* sp = nullptr) {
+              double flops, hipStream_t s, const Sparse* sp, float* gb, bool* gb_done) {
+  if (gb_done) *gb_done = false;
   const int PQ = g.PH * g.PW, KS2 = KS * KS;
   const int Kpix = NB * PQ;
   const int C = g.C1 + g.C2;
@@ -153,6 +160,12 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
   SG_ARG_CHECK(!pl.tap || (ws && ws_bytes >= mn * sizeof(float) * (size_t)splits), "wgrad: workspace too small");
   const int kchunk = sp ? PQ : sg_cdiv(sg_cdiv(Kpix, splits), 64) * 64;      // multiple of every BKT
   splits = sg_cdiv(Kpix, kchunk);
+  // bias gradient from the A loader's row sums: tap-major dense launches whose workspace has room for [splits][M] behind the slabs
+  static int fuse_gb = -1;
+  if (fuse_gb < 0) { const char* e = getenv("SG_WGRAD_ROWSUM"); fuse_gb = e ? atoi(e) : 1; }
+  float* rowsum = nullptr;
+  if (fuse_gb && gb && pl.tap && !sp && M == Mtot && ws_bytes >= (mn + (size_t)M) * sizeof(float) * (size_t)splits)
+    rowsum = reinterpret_cast<float*>(ws) + mn * (size_t)splits;
   if (sp) { t_fixed_kchunk = PQ; flops = 2.0 * M * (double)Ncols * Kpix; }
   float* dst = (splits > 1 || sp || pl.tap) ? reinterpret_cast<float*>(ws) : out;
   {
@@ -163,10 +176,10 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
       // mask-free gather: reflection padding and whole 16-pixel k-tiles (split chunks are multiples of 64)
       const bool nomask = g.reflect && (Kpix % (BK * NSW) == 0) && (!sp || PQ % (BK * NSW) == 0);
       switch (pl.tile) {
-        case 0: launch_nk_tap<CfgW128, 128, 128>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
-        case 1: launch_nk_tap<CfgW64, 64, 64>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
-        case 3: launch_nk_tap<CfgW64W, 64, 128>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
-        default: launch_nk_tap<CfgW32, 32, 128>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s); break;
+        case 0: launch_nk_tap<CfgW128, 128, 128>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s, rowsum); break;
+        case 1: launch_nk_tap<CfgW64, 64, 64>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s, rowsum); break;
+        case 3: launch_nk_tap<CfgW64W, 64, 128>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s, rowsum); break;
+        default: launch_nk_tap<CfgW32, 32, 128>(A, M, Mtot, PQ, vecA, g, KS, Ccols, pl.cpad, sp, nomask, ep, Kpix, splits, s, rowsum); break;
       }
     } else {
       const EpRowMajor ep{dst, nullptr, M, Ncols, Ncols, SG_ACT_NONE, 0.f, mn};
@@ -195,8 +208,11 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
     return 0;
   }
   if (pl.tap)
+  {
     hipLaunchKernelGGL(wgrad_unpermute_reduce_kernel, dim3(sg_cdiv((size_t)C * KS2, 256), M), dim3(256), 0, s, (const float*)ws, out,
-                       M, C, KS2, pl.cpad, splits);
+                       M, C, KS2, pl.cpad, splits, (const float*)rowsum, rowsum ? gb : nullptr);
+    if (rowsum && gb_done) *gb_done = true;
+  }
   else if (splits > 1)
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(sg_cdiv(mn, 256)), dim3(256), 0, s, (const float*)ws, out, mn, splits);
   return 0;
@@ -206,6 +222,6 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
 }  // namespace
 
 int sgk::nk_run(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, float* out, void* ws, size_t ws_bytes,
-                double flops, hipStream_t s, const Sparse* sp) {
-  return run_nk_ks(KS, A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s, sp);
+                double flops, hipStream_t s, const Sparse* sp, float* gb, bool* gb_done) {
+  return run_nk_ks(KS, A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s, sp, gb, gb_done);
 }

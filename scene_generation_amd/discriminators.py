@@ -13,7 +13,7 @@ SURVEY 8b) and share one pyramid walker.
 """
 import torch.nn as nn
 
-from . import ops
+from . import ops, streams
 from .bilinear import crop_bbox_batch
 from .generators import weights_init           # the same pix2pixHD initialiser as discriminators.py:57-63
 from .layers import (GlobalAvgPool, build_cnn, get_norm_layer, Conv2d, LeakyReLU, Sigmoid, Linear, BatchNorm2d,
@@ -178,12 +178,18 @@ class MultiscaleDiscriminator(_ScalePyramid):
         return ops.set_hints(ghost, factored=(f if a.requires_grad else f.detached()).with_planes(planes))
 
     def forward(self, input, input2=None):
-        """``input`` = the 207-channel tensor, or (layout, image) as two tensors (concat folded)."""
-        out, a, b = [], input, input2
+        """``input`` = the 207-channel tensor, or (layout, image) as two tensors (concat folded).  The scales only share
+        the (pooled) input: the pyramid is built first, then every scale runs on its own stream (streams.fork)."""
+        levels, a, b = [], input, input2
         for more, stages in self._scales():
-            out.append(self.singleD_forward(stages, a, b))
+            levels.append((stages, a, b))
             if more:
                 a, b = self._pool_label(a, b is not None), (None if b is None else self.downsample(b))
+        out = [None] * len(levels)
+        with streams.fork(input.device, 'imgD') as f:
+            for i, (stages, a, b) in enumerate(levels):
+                with f.branch(i):
+                    out[i] = self.singleD_forward(stages, a, b)
         return out
 
 
@@ -204,11 +210,16 @@ class MultiscaleMaskDiscriminator(_ScalePyramid):
         return feats
 
     def forward(self, input, cond):
-        out, h = [], input
+        levels, h = [], input
         for more, stages in self._scales():
-            out.append(self.singleD_forward(stages, h, cond))
+            levels.append((stages, h))
             if more:
                 h = self.downsample(h)
+        out = [None] * len(levels)
+        with streams.fork(input.device, 'maskD') as f:
+            for i, (stages, h) in enumerate(levels):
+                with f.branch(i):
+                    out[i] = self.singleD_forward(stages, h, cond)
         return out
 
 

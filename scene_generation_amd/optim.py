@@ -11,7 +11,7 @@ checkpoints round-trip.
 """
 import torch
 
-from . import ops
+from . import ops, streams
 
 
 class FlatParams:
@@ -100,6 +100,7 @@ class FusedAdam:
                      params=self.fp.params)]
 
     def zero_grad(self, set_to_none=False):
+        streams.join_all(self.fp.grad.device)      # weight-gradient kernels of side streams write this buffer (streams.py)
         ops.fill_(self.fp.grad, 0.0)
         self.fp.attach_grads()
         self._touched = [False] * len(self.fp.params)
@@ -111,6 +112,7 @@ class FusedAdam:
         self._touched = [True] * len(self.fp.params)
 
     def step(self):
+        streams.join_all(self.fp.grad.device)      # (see zero_grad)
         for h in self.pre_step_hooks:
             h()
         self.fp.attach_grads()

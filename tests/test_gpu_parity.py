@@ -429,6 +429,43 @@ def test_fused_gconv_layer_equals_unfused(hip, O_, T_, Din, A, H_, Dout, pooling
         assert torch.equal(a, b), 'tensor %d differs between the fused and the unfused layer: %g' % (i, float((a - b).abs().max()))
 
 
+def test_multiscale_discriminators_on_side_streams_are_bit_identical(hip):
+    """streams.py (SG_MULTISTREAM=1): the PatchGAN scales on one HIP stream each == all of them on the current stream: outputs
+    and every gradient bit-identical (no atomics, one writer per buffer), incl. gradients delivered into a FusedAdam's flat
+    buffer by kernels of the side streams (optimiser step after ``join_all``)."""
+    from scene_generation_amd import streams
+    from scene_generation_amd.discriminators import define_D, define_mask_D
+    from scene_generation_amd.optim import FusedAdam
+    lay, img = det((4, 9, 64, 64), 301), det((4, 3, 64, 64), 302)
+    msk, cond = det((6, 1, 32, 32), 303), torch.zeros(6, 5)
+    cond[torch.arange(6), torch.tensor([0, 3, 4, 1, 1, 2])] = 1
+    res = []
+    saved = streams.ENABLED
+    try:
+        for on in (False, True, False):
+            streams.ENABLED = on
+            netD = define_D(12, 16, 2, norm='instance', num_D=3).to(DEV)
+            netM = define_mask_D(1, 16, 2, norm='instance', num_D=2, num_objects=5).to(DEV)
+            fill_deterministic(netD); fill_deterministic(netM)
+            opt = FusedAdam(list(netD.parameters()) + list(netM.parameters()), lr=1e-3)
+            a, b = lay.to(DEV).requires_grad_(), img.to(DEV).requires_grad_()
+            m = msk.to(DEV).requires_grad_()
+            outs = netD(a, b) + netM(m, cond.to(DEV))
+            feats = [t for scale in outs for t in scale]
+            opt.zero_grad()
+            sum((t * t).mean() for t in feats).backward()
+            grads = opt.fp.grad.clone()
+            opt.step()
+            torch.cuda.synchronize()
+            res.append([t.detach().clone() for t in feats] + [a.grad.clone(), b.grad.clone(), m.grad.clone(), grads,
+                                                              opt.fp.flat.detach().clone()])
+    finally:
+        streams.ENABLED = saved
+    assert len(streams._POOL) >= 3                       # the side streams were really used
+    for i, (x, y, z) in enumerate(zip(*res)):
+        assert torch.equal(x, y) and torch.equal(x, z), 'tensor %d differs between one stream and a stream per scale' % i
+
+
 def test_embedding_onehot_concat(hip):
     table, idx = det((12, 16), 71), torch.tensor([3, 0, 11, 3, 3, 7])
     tr = table.clone().requires_grad_()

@@ -25,14 +25,18 @@ for spec in filter(None, os.environ.get('SG_BENCH_SHAPES', '').split(';')):
     SHAPES.append((f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4]), int(f[5]), int(f[6]), int(f[7]), f[8] == '1', int(f[9])))
 
 
-def timeit(fn, n=5):
-    fn(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        fn()
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n
+def timeit(fn, n=int(os.environ.get('SG_BENCH_ITERS', '10')), reps=3):
+    """best of ``reps`` runs of ``n`` back-to-back calls (HIP events on the launch stream)"""
+    fn(); fn(); torch.cuda.synchronize()
+    best = float('inf')
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / n)
+    return best
 
 
 for name, N, Cin, H, Cout, KS, st, pad, refl, ups in SHAPES:
