@@ -123,6 +123,19 @@ int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const float* x, f
 /* gx [N, C1, H, W] (all input channels): Winograd on the padded gradient grid + reflection fold */
 int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, const float* ut_saved,
                          void* ws, size_t ws_bytes, sgStream stream);
+/* Winograd F(2x2, 4x4) for the stride-1 4x4 convs of the PatchGANs (reference discriminators.py:221-228:
+   nn.Conv2d(nf_prev, nf, kernel_size=4, stride=1, padding=2), 256 -> 512 channels: the largest layer of the discriminator steps):
+   KS 4, stride 1, zero padding 0..3, one source, C1 and Cout multiples of 128, >= 512 output tiles.  25 multiplies per 2x2
+   output tile and channel pair instead of 64; fp32 throughout, results agree with sg_conv2d_fwd / _dgrad / _wgrad to fp32
+   rounding (asserted at the same tolerances; gb via sg_channel_sum).  ws: sg_conv2d_wino24_ws_bytes. */
+int sg_conv2d_wino24_supported(const sgConvDesc* d);
+size_t sg_conv2d_wino24_ws_bytes(const sgConvDesc* d);
+int sg_conv2d_wino24_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                         float slope, void* ws, size_t ws_bytes, sgStream stream);
+int sg_conv2d_wino24_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, void* ws, size_t ws_bytes,
+                           sgStream stream);
+int sg_conv2d_wino24_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, void* ws, size_t ws_bytes,
+                           sgStream stream);
 /* Direct (vector-ALU) kernels for ReflectionPad2d(3) + Conv2d(C, Cout <= 4, 7) [+ act]: the generator's RGB head
    (reference generators.py:88-90).  Same results as sg_conv2d_fwd / sg_conv2d_wgrad (gb via sg_channel_sum). */
 int sg_conv2d_smallm_supported(const sgConvDesc* d);

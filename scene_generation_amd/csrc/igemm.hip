@@ -755,40 +755,295 @@ int wino_tile(const sgConvDesc* d) {
 }
 bool wino_ok(const sgConvDesc* d) { return wino_tile(d) != 0; }
 
-// C[m][b*cols + j] = sum_k A[b][m][k] * B[b*cols + j][k]   (16 batches, everything a multiple of the tile)
-void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, int K, double flops, hipStream_t s) {
-  EpRowMajor ep{Cout, nullptr, M, 16 * cols, 16 * cols, SG_ACT_NONE, 0.f, 0};
-  sgk::t_alg_bytes = 4.0 * 16.0 * ((double)M * K + (double)cols * K + (double)M * cols);
-  t_batch = BatchInfo{}; t_batch.cols_per_batch = cols; t_batch.nbatch = 16; t_batch.a_stride = M * K; t_batch.batch_major = 1;
+// C[m][b*cols + j] = sum_k A[b][m][k] * B[b*cols + j][k]   (NB batches -- 16 for F(2x2,3x3), 25 (x k-chunks) for F(2x2,4x4) --,
+// everything a multiple of the tile)
+void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, int K, double flops, hipStream_t s, int NB = 16) {
+  EpRowMajor ep{Cout, nullptr, M, NB * cols, NB * cols, SG_ACT_NONE, 0.f, 0};
+  sgk::t_alg_bytes = 4.0 * NB * ((double)M * K + (double)cols * K + (double)M * cols);
+  t_batch = BatchInfo{}; t_batch.cols_per_batch = cols; t_batch.nbatch = NB; t_batch.a_stride = M * K; t_batch.batch_major = 1;
   {
     SgProfScope prof(SG_K_WINO_GEMM_128, s, flops, 0);
     static int wt = -1;
     if (wt < 0) { const char* e = getenv("SG_WINO_TILE"); wt = e ? atoi(e) : 0; }
     if (wt == 1)
-      launch_cfg<CfgD128x64>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<64, true, false>{B, K, 16 * cols}, ep, M,
-                             16 * cols, K, 1, s);
+      launch_cfg<CfgD128x64>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<64, true, false>{B, K, NB * cols}, ep, M,
+                             NB * cols, K, 1, s);
     else if (wt == 2)
-      launch_cfg<Cfg128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M,
-                         16 * cols, K, 1, s);
+      launch_cfg<Cfg128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols}, ep, M,
+                         NB * cols, K, 1, s);
     else if (wt == 3)       // the plain loop (before the software-pipelined form)
-      launch_cfg<CfgD128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M,
-                          16 * cols, K, 1, s);
+      launch_cfg<CfgD128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols}, ep, M,
+                          NB * cols, K, 1, s);
     else if (wt == 6)       // pipelined, 16-deep k-tiles (40 KB of LDS: three workgroups per CU): measured 0.763 vs 0.775 of peak
-      launch_cfg<TileCfg<128, 128, 2, 1, 1>>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols},
-                                             EpRowMajorPlain{Cout, 16 * cols}, M, 16 * cols, K, 1, s);
+      launch_cfg<TileCfg<128, 128, 2, 1, 1>>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
+                                             EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
     else if (wt == 5)       // the plain loop with the unconditional epilogue
-      launch_cfg<CfgD128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols},
-                          EpRowMajorPlain{Cout, 16 * cols}, M, 16 * cols, K, 1, s);
+      launch_cfg<CfgD128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
+                          EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
     else if (wt == 4)       // pipelined loop, general epilogue
-      launch_cfg<CfgDP128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols}, ep, M,
-                           16 * cols, K, 1, s);
+      launch_cfg<CfgDP128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols}, ep, M,
+                           NB * cols, K, 1, s);
     else
-      launch_cfg<CfgDP128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, 16 * cols},
-                           EpRowMajorPlain{Cout, 16 * cols}, M, 16 * cols, K, 1, s);
+      launch_cfg<CfgDP128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
+                           EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
   }
   t_batch = BatchInfo{};
 }
 
+
+// ================================================================================================
+// Winograd F(2x2, 4x4) for the stride-1 4x4 convs of the PatchGANs (discriminators.py:221-228: Conv2d(256, 512, 4, 1, 2), the
+// largest single layer of the discriminator steps): 25 multiplies per 2x2 output tile and channel pair instead of 64.
+// Interpolation points 0, 1, -1, -2, inf (the set with the smallest fp32 error of the ones tried: ~3x the direct kernel's):
+//   A^T = [1 1 1 1 0; 0 1 -1 -2 1]
+//   G   = [-1/2 0 0 0; 1/6 1/6 1/6 1/6; 1/2 -1/2 1/2 -1/2; -1/6 1/3 -2/3 4/3; 0 0 0 1]
+//   B^T = [-2 -1 2 1 0; 0 2 3 1 0; 0 -2 1 1 0; 0 -1 0 1 0; 0 -2 -1 2 1]
+//   y = A^T [(G g G^T) (.) (B^T d B)] A,   dL/dg = G^T [sum_tiles (A dy A^T) (.) (B^T d B)] G,   data gradient = the forward
+//   form on gy with the 180-degree-rotated, transposed filter and padding 3 - pad.
+// Forward / data gradient: 25 batched GEMMs [M x K] x [K x tiles]; weight gradient: 25 x S batched GEMMs over k-chunks of the
+// tiles (M x C is only a handful of 128-tiles: the chunks fill the chip), summed in a fixed order by the output transform.
+// ================================================================================================
+__device__ __forceinline__ void w24_bt(const float (&d)[5], float (&o)[5]) {
+  o[0] = -2.f * d[0] - d[1] + 2.f * d[2] + d[3];
+  o[1] = 2.f * d[1] + 3.f * d[2] + d[3];
+  o[2] = -2.f * d[1] + d[2] + d[3];
+  o[3] = d[3] - d[1];
+  o[4] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+}
+__device__ __forceinline__ void w24_g(const float (&g)[4], float (&o)[5]) {
+  o[0] = -0.5f * g[0];
+  o[1] = (g[0] + g[1] + g[2] + g[3]) * (1.f / 6.f);
+  o[2] = (g[0] - g[1] + g[2] - g[3]) * 0.5f;
+  o[3] = (-g[0] + 2.f * g[1] - 4.f * g[2] + 8.f * g[3]) * (1.f / 6.f);
+  o[4] = g[3];
+}
+__device__ __forceinline__ void w24_at(const float (&m)[5], float (&o)[2]) {
+  o[0] = m[0] + m[1] + m[2] + m[3];
+  o[1] = m[1] - m[2] - 2.f * m[3] + m[4];
+}
+__device__ __forceinline__ void w24_a(const float (&y)[2], float (&o)[5]) {      // A y
+  o[0] = y[0]; o[1] = y[0] + y[1]; o[2] = y[0] - y[1]; o[3] = y[0] - 2.f * y[1]; o[4] = y[1];
+}
+__device__ __forceinline__ void w24_gt(const float (&t)[5], float (&o)[4]) {     // G^T t
+  o[0] = -0.5f * t[0] + (t[1] - t[3]) * (1.f / 6.f) + 0.5f * t[2];
+  o[1] = (t[1] + 2.f * t[3]) * (1.f / 6.f) - 0.5f * t[2];
+  o[2] = (t[1] - 4.f * t[3]) * (1.f / 6.f) + 0.5f * t[2];
+  o[3] = (t[1] + 8.f * t[3]) * (1.f / 6.f) - 0.5f * t[2] + t[4];
+}
+
+// V = B^T d B of the 5x5 patch of tile p = (n, ti, tj) (patch origin (2ti + off, 2tj + off), zero outside the plane).
+// KMAJ = 0: V[xi][p][c] (GEMM operand with the channel as k; lanes along c: coalesced stores);
+// KMAJ = 1: V[xi*S + s][c][pc], p = s*Pc + pc (weight gradient: the tile index is k; lanes along p).  Rows p >= P are zeros.
+template <int KMAJ>
+__global__ void w24_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int C, int H, int W, int TH, int TW,
+                                 int off, size_t Pstride, int Pc, int S) {
+  const size_t P = (size_t)N * TH * TW, total = Pstride * C;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const size_t p = KMAJ ? idx % Pstride : idx / C;
+  const int c = (int)(KMAJ ? idx / Pstride : idx % C);
+  float d[5][5];
+  if (p < P) {
+    const int n = (int)(p / (TH * TW)), r = (int)(p - (size_t)n * TH * TW), ti = r / TW, tj = r - ti * TW;
+    const float* xp = x + ((size_t)n * C + c) * H * W;
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+      const int ih = 2 * ti + off + a;
+      const bool rok = (unsigned)ih < (unsigned)H;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const int iw = 2 * tj + off + b;
+        const bool ok = rok && (unsigned)iw < (unsigned)W;
+        d[a][b] = ok ? xp[ih * W + iw] : 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+      for (int b = 0; b < 5; ++b) d[a][b] = 0.f;
+  }
+  float t[5][5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {               // columns: t = B^T d
+    const float col[5] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j]};
+    float o[5];
+    w24_bt(col, o);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) t[i][j] = o[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {               // rows: V = t B
+    float o[5];
+    w24_bt(t[i], o);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const size_t xi = (size_t)(i * 5 + j);
+      if (KMAJ) {
+        const size_t sidx = p / (size_t)Pc, pc = p - sidx * (size_t)Pc;
+        V[((xi * S + sidx) * C + c) * (size_t)Pc + pc] = o[j];
+      } else {
+        V[(xi * Pstride + p) * C + c] = o[j];
+      }
+    }
+  }
+}
+
+// U[xi][r][c] = (G g G^T)[xi]; mode 0: r = co, c = ci, g = w[co][ci]; mode 1 (data gradient): r = ci, c = co, g = w[co][ci] rotated
+__global__ void w24_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int R, int Cc, int mode) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)R * Cc) return;
+  const int c = (int)(idx % Cc), r = (int)(idx / Cc);
+  const float* g = w + (mode ? ((size_t)c * R + r) : ((size_t)r * Cc + c)) * 16;
+  float k[4][4];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) k[i >> 2][i & 3] = mode ? g[15 - i] : g[i];
+  float t[5][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float col[4] = {k[0][j], k[1][j], k[2][j], k[3][j]};
+    float o[5];
+    w24_g(col, o);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) t[i][j] = o[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    float o[5];
+    w24_g(t[i], o);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) U[((size_t)(i * 5 + j) * R + r) * Cc + c] = o[j];
+  }
+}
+
+// y[n][m][2ti+a][2tj+b] = act((A^T Mx A)[a][b] + bias[m]),  Mx[m][xi*Pstride + p]; OH / OW may be odd (edge tiles are clipped)
+__global__ void w24_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias, float* __restrict__ y, int N,
+                                  int M, int OH, int OW, int TH, int TW, size_t Pstride, int act, float slope) {
+  const size_t P = (size_t)N * TH * TW;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * M) return;
+  const size_t p = idx % P;
+  const int m = (int)(idx / P);
+  const float* src = Mx + (size_t)m * 25 * Pstride + p;
+  float q[5][5];
+#pragma unroll
+  for (int i = 0; i < 25; ++i) q[i / 5][i % 5] = src[(size_t)i * Pstride];
+  float sres[2][5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const float col[5] = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j]};
+    float o[2];
+    w24_at(col, o);
+    sres[0][j] = o[0]; sres[1][j] = o[1];
+  }
+  const float b = bias ? bias[m] : 0.f;
+  const int n = (int)(p / (TH * TW)), r = (int)(p - (size_t)n * TH * TW), ti = r / TW, tj = r - ti * TW;
+  float* o = y + (((size_t)n * M + m) * OH + 2 * ti) * OW + 2 * tj;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    float v[2];
+    w24_at(sres[a], v);
+    if (2 * ti + a < OH) {
+      o[a * OW] = sg_apply_act(v[0] + b, act, slope);
+      if (2 * tj + 1 < OW) o[a * OW + 1] = sg_apply_act(v[1] + b, act, slope);
+    }
+  }
+}
+
+// Yt[xi*S + s][m][pc] = (A dy A^T)[xi] of the 2x2 gradient tile p = s*Pc + pc (zeros for p >= P and outside the plane)
+__global__ void w24_gy_kernel(const float* __restrict__ gy, float* __restrict__ Yt, int N, int M, int OH, int OW, int TH, int TW,
+                              size_t Pstride, int Pc, int S) {
+  const size_t P = (size_t)N * TH * TW;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Pstride * M) return;
+  const size_t p = idx % Pstride;
+  const int m = (int)(idx / Pstride);
+  float y2[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  if (p < P) {
+    const int n = (int)(p / (TH * TW)), r = (int)(p - (size_t)n * TH * TW), ti = r / TW, tj = r - ti * TW;
+    const float* g = gy + (((size_t)n * M + m) * OH + 2 * ti) * OW + 2 * tj;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        if (2 * ti + a < OH && 2 * tj + b < OW) y2[a][b] = g[a * OW + b];
+  }
+  float t[5][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float col[2] = {y2[0][j], y2[1][j]};
+    float o[5];
+    w24_a(col, o);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) t[i][j] = o[i];
+  }
+  const size_t sidx = p / (size_t)Pc, pc = p - sidx * (size_t)Pc;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    float o[5];
+    w24_a(t[i], o);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) Yt[(((size_t)(i * 5 + j) * S + sidx) * M + m) * (size_t)Pc + pc] = o[j];
+  }
+}
+
+// gw[m][c][4][4] = G^T (sum_s T[m][(xi*S + s)*C + c]) G
+__global__ void w24_wgrad_output_kernel(const float* __restrict__ T, float* __restrict__ gw, int M, int C, int S) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)M * C) return;
+  const int c = (int)(idx % C), m = (int)(idx / C);
+  const float* src = T + (size_t)m * 25 * S * C + c;
+  float q[5][5];
+#pragma unroll
+  for (int i = 0; i < 25; ++i) {
+    float v = 0.f;
+    for (int z = 0; z < S; ++z) v += src[((size_t)i * S + z) * C];
+    q[i / 5][i % 5] = v;
+  }
+  float t[4][5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const float col[5] = {q[0][j], q[1][j], q[2][j], q[3][j], q[4][j]};
+    float o[4];
+    w24_gt(col, o);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i][j] = o[i];
+  }
+  float* dst = gw + ((size_t)m * C + c) * 16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float o[4];
+    w24_gt(t[i], o);
+    *reinterpret_cast<float4*>(dst + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+struct W24Plan { int TH, TW, THd, TWd; size_t P, Ps, Pd, Pds; int S, Pc; };
+bool w24_plan(const sgConvDesc* d, W24Plan* pl) {
+  if (!d || d->KS != 4 || d->stride != 1 || d->C2 != 0 || d->upsample != 1 || d->pad_reflect || d->pad < 0 || d->pad > 3) return false;
+  if (d->C1 % 128 != 0 || d->Cout % 128 != 0 || d->OH < 2 || d->OW < 2) return false;
+  if (d->OH != d->H + 2 * d->pad - 3 || d->OW != d->W + 2 * d->pad - 3) return false;
+  W24Plan p;
+  p.TH = (d->OH + 1) / 2; p.TW = (d->OW + 1) / 2;         // forward / weight gradient: tiles of the output grid
+  p.THd = (d->H + 1) / 2; p.TWd = (d->W + 1) / 2;         // data gradient: tiles of the input grid
+  p.P = (size_t)d->N * p.TH * p.TW; p.Pd = (size_t)d->N * p.THd * p.TWd;
+  p.Ps = (p.P + 127) / 128 * 128; p.Pds = (p.Pd + 127) / 128 * 128;
+  // weight gradient: k-chunks of the tiles so that 25 * S * (M/128) * (C/128) workgroups fill the chip
+  const long t = 25L * (d->Cout / 128) * (d->C1 / 128);
+  int S = (int)((768 + t - 1) / t);
+  const int maxS = (int)(p.P / 256) > 0 ? (int)(p.P / 256) : 1;
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  p.Pc = (int)(((p.P + S - 1) / S + 31) / 32 * 32);
+  p.S = (int)((p.P + p.Pc - 1) / p.Pc);
+  const double cm = d->C1 > d->Cout ? d->C1 : d->Cout;
+  const double pm = (double)(p.Ps > p.Pds ? p.Ps : p.Pds) + 32.0 * p.S;
+  if (!(25.0 * pm * cm < 2147483647.0 && 25.0 * (double)d->C1 * d->Cout < 2147483647.0)) return false;
+  // the transforms move 25/4 x the activation bytes: below a few hundred tiles the direct kernel wins
+  if (p.P < 512) return false;
+  if (pl) *pl = p;
+  return true;
+}
 }  // namespace
 
 extern "C" int sg_conv2d_wino_supported(const sgConvDesc* d) { return wino_ok(d) ? 1 : 0; }
@@ -917,6 +1172,91 @@ extern "C" int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const 
   wino_bgemm(Yt, Vp, T, M, C, (int)P, 2.0 * M * (double)C * 16.0 * P, s);
   { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 25.0 * (double)M * C); hipLaunchKernelGGL(wino_wgrad_output_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, (const float*)T, gw, M, C); }
   SG_LAUNCH_CHECK("sg_conv2d_wino_wgrad");
+  return 0;
+}
+
+// ---- Winograd F(2x2, 4x4): see w24_* above ----------------------------------------------------------------------------------
+extern "C" int sg_conv2d_wino24_supported(const sgConvDesc* d) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("SG_WINO24"); on = e ? atoi(e) : 1; }
+  return (on && w24_plan(d, nullptr)) ? 1 : 0;
+}
+extern "C" size_t sg_conv2d_wino24_ws_bytes(const sgConvDesc* d) {
+  W24Plan p;
+  if (!w24_plan(d, &p)) return 0;
+  const size_t M = d->Cout, C = d->C1;
+  const size_t f = 25 * (M * C + p.Ps * C + p.Ps * M);
+  const size_t g = 25 * (M * C + p.Pds * M + p.Pds * C);
+  const size_t w = 25 * (size_t)p.S * ((size_t)p.Pc * (M + C) + M * C);
+  const size_t mx = f > g ? (f > w ? f : w) : (g > w ? g : w);
+  return mx * sizeof(float) + 256;
+}
+extern "C" int sg_conv2d_wino24_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y, int act,
+                                    float slope, void* ws, size_t ws_bytes, sgStream stream) {
+  W24Plan p;
+  SG_ARG_CHECK(w24_plan(d, &p), "sg_conv2d_wino24_fwd: unsupported desc");
+  SG_ARG_CHECK(x && w && y && ws && ws_bytes >= sg_conv2d_wino24_ws_bytes(d), "sg_conv2d_wino24_fwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int M = d->Cout, C = d->C1;
+  float* U = reinterpret_cast<float*>(ws);
+  float* V = U + (size_t)25 * M * C;
+  float* Mx = V + 25 * p.Ps * C;
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 26.0 * (double)M * C);
+    hipLaunchKernelGGL(w24_weight_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, w, U, M, C, 0); }
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * C * d->H * d->W + 25.0 * (double)p.Ps * C));
+    hipLaunchKernelGGL(w24_input_kernel<0>, dim3(sg_cdiv(p.Ps * C, 256)), dim3(256), 0, s, x, V, d->N, C, d->H, d->W, p.TH, p.TW,
+                       -d->pad, p.Ps, 0, 1); }
+  wino_bgemm(U, V, Mx, M, (int)p.Ps, C, 2.0 * M * (double)C * 25.0 * p.P, s, 25);
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * (25.0 * (double)p.P * M + (double)d->N * M * d->OH * d->OW));
+    hipLaunchKernelGGL(w24_output_kernel, dim3(sg_cdiv(p.P * M, 256)), dim3(256), 0, s, (const float*)Mx, bias, y, d->N, M, d->OH,
+                       d->OW, p.TH, p.TW, p.Ps, act, slope); }
+  SG_LAUNCH_CHECK("sg_conv2d_wino24_fwd");
+  return 0;
+}
+extern "C" int sg_conv2d_wino24_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, void* ws, size_t ws_bytes,
+                                      sgStream stream) {
+  W24Plan p;
+  SG_ARG_CHECK(w24_plan(d, &p), "sg_conv2d_wino24_dgrad: unsupported desc");
+  SG_ARG_CHECK(gy && w && gx && ws && ws_bytes >= sg_conv2d_wino24_ws_bytes(d), "sg_conv2d_wino24_dgrad: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int M = d->C1, K = d->Cout;             // gx[ci] = sum_co rot(w[co][ci]) * gy[co], padding 3 - pad
+  float* U = reinterpret_cast<float*>(ws);
+  float* V = U + (size_t)25 * M * K;
+  float* Mx = V + 25 * p.Pds * K;
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 26.0 * (double)M * K);
+    hipLaunchKernelGGL(w24_weight_kernel, dim3(sg_cdiv((size_t)M * K, 256)), dim3(256), 0, s, w, U, M, K, 1); }
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * K * d->OH * d->OW + 25.0 * (double)p.Pds * K));
+    hipLaunchKernelGGL(w24_input_kernel<0>, dim3(sg_cdiv(p.Pds * K, 256)), dim3(256), 0, s, gy, V, d->N, K, d->OH, d->OW, p.THd,
+                       p.TWd, -(3 - d->pad), p.Pds, 0, 1); }
+  wino_bgemm(U, V, Mx, M, (int)p.Pds, K, 2.0 * M * (double)K * 25.0 * p.Pd, s, 25);
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * (25.0 * (double)p.Pd * M + (double)d->N * M * d->H * d->W));
+    hipLaunchKernelGGL(w24_output_kernel, dim3(sg_cdiv(p.Pd * M, 256)), dim3(256), 0, s, (const float*)Mx, (const float*)nullptr, gx,
+                       d->N, M, d->H, d->W, p.THd, p.TWd, p.Pds, SG_ACT_NONE, 0.f); }
+  SG_LAUNCH_CHECK("sg_conv2d_wino24_dgrad");
+  return 0;
+}
+extern "C" int sg_conv2d_wino24_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, void* ws, size_t ws_bytes,
+                                      sgStream stream) {
+  W24Plan p;
+  SG_ARG_CHECK(w24_plan(d, &p), "sg_conv2d_wino24_wgrad: unsupported desc");
+  SG_ARG_CHECK(gy && x && gw && ws && ws_bytes >= sg_conv2d_wino24_ws_bytes(d), "sg_conv2d_wino24_wgrad: bad arguments");
+  SG_ARG_CHECK(aligned16(gw), "sg_conv2d_wino24_wgrad: gw must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int M = d->Cout, C = d->C1;
+  const size_t Pall = (size_t)p.S * p.Pc;       // tiles incl. the zero padding of the last k-chunk
+  float* Yt = reinterpret_cast<float*>(ws);
+  float* V = Yt + 25 * Pall * M;
+  float* T = V + 25 * Pall * C;
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * M * d->OH * d->OW + 25.0 * (double)Pall * M));
+    hipLaunchKernelGGL(w24_gy_kernel, dim3(sg_cdiv(Pall * M, 256)), dim3(256), 0, s, gy, Yt, d->N, M, d->OH, d->OW, p.TH, p.TW, Pall,
+                       p.Pc, p.S); }
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * C * d->H * d->W + 25.0 * (double)Pall * C));
+    hipLaunchKernelGGL(w24_input_kernel<1>, dim3(sg_cdiv(Pall * C, 256)), dim3(256), 0, s, x, V, d->N, C, d->H, d->W, p.TH, p.TW,
+                       -d->pad, Pall, p.Pc, p.S); }
+  wino_bgemm(Yt, V, T, M, C, p.Pc, 2.0 * M * (double)C * 25.0 * p.P, s, 25 * p.S);
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * (25.0 * p.S + 16.0) * (double)M * C);
+    hipLaunchKernelGGL(w24_wgrad_output_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, (const float*)T, gw, M, C, p.S); }
+  SG_LAUNCH_CHECK("sg_conv2d_wino24_wgrad");
   return 0;
 }
 

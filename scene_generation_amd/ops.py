@@ -228,7 +228,13 @@ class Conv2dFn(Function):
         ctx.wino = (x2 is None and sparse is None and WINOGRAD and bool(_q(d, 'sg_conv2d_wino_supported')))
         ctx.head = (x2 is None and sparse is None and HEADCONV and not ctx.wino and not ctx.smallm
                     and bool(_q(d, 'sg_conv2d_head_supported')))
-        if ctx.head:                # one output channel (PatchGAN score maps, mask_net's 1x1 head): vector-ALU reduction
+        ctx.wino24 = (x2 is None and sparse is None and WINOGRAD24 and not ctx.head and not ctx.smallm
+                      and bool(_q(d, 'sg_conv2d_wino24_supported')))
+        if ctx.wino24:              # stride-1 4x4 convs of the PatchGANs: Winograd F(2x2,4x4), 25 batched dense GEMMs
+            wsb = _q(d, 'sg_conv2d_wino24_ws_bytes')
+            _call('sg_conv2d_wino24_fwd', d._ref, _p(x1), _p(weight), _p(bias), _p(y), act, slope,
+                  _p(workspace(wsb, x1.device)), wsb, _stream())
+        elif ctx.head:                # one output channel (PatchGAN score maps, mask_net's 1x1 head): vector-ALU reduction
             wsb = _q(d, 'sg_conv2d_head_ws_bytes')
             _call('sg_conv2d_head_fwd', d._ref, _p(x1), _p(weight), _p(bias), _p(y), act, slope,
                   _p(workspace(wsb, x1.device)), wsb, _stream())
@@ -295,6 +301,11 @@ class Conv2dFn(Function):
                     out = torch.empty(d.N, d.C1, d.H, d.W, dtype=torch.float32, device=dev)
                     _call('sg_conv2d_head_dgrad', d._ref, _p(gy), _p(weight), _p(out), s)
                     return out
+                if ctx.wino24 and c0 == 0 and c1 == d.C1:   # Winograd F(2x2,4x4) on gy with the rotated, transposed filter
+                    out = torch.empty(d.N, d.C1, d.H, d.W, dtype=torch.float32, device=dev)
+                    fb = _q(d, 'sg_conv2d_wino24_ws_bytes')
+                    _call('sg_conv2d_wino24_dgrad', d._ref, _p(gy), _p(weight), _p(out), _p(workspace(fb, dev)), fb, s)
+                    return out
                 if ctx.wino and c0 == 0 and c1 == d.C1:     # Winograd on the padded gradient grid + reflection fold
                     out = torch.empty(d.N, d.C1, d.H, d.W, dtype=torch.float32, device=dev)
                     fb = _q(d, 'sg_conv2d_wino_ws_bytes')
@@ -333,7 +344,13 @@ class Conv2dFn(Function):
             if need_w:
                 gw = ow.buf
                 gb = ob.buf if need_b else None
-                if ctx.head:
+                if ctx.wino24:
+                    wsb = max(_q(d, 'sg_conv2d_wino24_ws_bytes'), _L().sg_channel_sum_ws_bytes(d.Cout))
+                    ws = workspace(wsb, dev)
+                    _call('sg_conv2d_wino24_wgrad', d._ref, _p(gy), _p(x1), _p(gw), _p(ws), wsb, s)
+                    if gb is not None:
+                        _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb, s)
+                elif ctx.head:
                     wsb = max(_q(d, 'sg_conv2d_head_ws_bytes'), _L().sg_channel_sum_ws_bytes(d.Cout))
                     ws = workspace(wsb, dev)
                     _call('sg_conv2d_head_wgrad', d._ref, _p(gy), _p(x1), _p(gw), _p(ws), wsb, s)
@@ -376,6 +393,8 @@ class Conv2dFn(Function):
 HEADCONV = os.environ.get('SG_HEADCONV', '1') != '0'
 # Winograd F(2x2,3x3) for the ResnetBlock convs (SG_WINOGRAD=0 keeps them on the direct implicit-GEMM kernels)
 WINOGRAD = os.environ.get('SG_WINOGRAD', '1') != '0'
+# Winograd F(2x2,4x4) for the stride-1 4x4 convs of the PatchGANs (SG_WINOGRAD24=0 keeps them on the direct kernels)
+WINOGRAD24 = os.environ.get('SG_WINOGRAD24', '1') != '0'
 # convs over a masks_to_layout() layout computed from its factored form (SG_FACTORED_LAYOUT=0: channel-sparse path instead)
 FACTORED_LAYOUT = os.environ.get('SG_FACTORED_LAYOUT', '1') != '0'
 

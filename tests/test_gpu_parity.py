@@ -100,6 +100,9 @@ CONV_CASES = [
     (7, 24, 0, 1, 1, 24, 3, 1, 1, False, 2, 0),        # mask_net first octave: 1x1 -> 2x2 (sub-pixel transposed conv)
     (3, 16, 0, 5, 7, 12, 3, 1, 1, False, 2, 0),        # sub-pixel transposed conv, odd non-square plane, Cin != Cout
     (9, 192, 0, 16, 16, 192, 3, 1, 1, False, 2, 0),    # mask_net last octave at full width (192 channels, 16 -> 32)
+    (8, 128, 0, 17, 17, 128, 4, 1, 2, False, 1, 2),    # Winograd F(2x2,4x4): PatchGAN k4 s1 p2 (17 -> 18), fused LeakyReLU
+    (8, 128, 0, 20, 14, 256, 4, 1, 1, False, 1, 0),    # F(2x2,4x4): pad 1, odd 19x13 output (clipped edge tiles), Cin != Cout
+    (8, 256, 0, 19, 19, 128, 4, 1, 0, False, 1, 1),    # F(2x2,4x4): valid conv, data gradient with padding 3, k-chunked wgrad
 ]
 
 
