@@ -889,6 +889,88 @@ __global__ void w24_input_kernel(const float* __restrict__ x, float* __restrict_
   }
 }
 
+// The same transform (layout V[xi][p][c]) for the small planes of the PatchGANs (H*W <= 639: the 17x17 / 18x18 / 9x9 / 10x10 maps):
+// the kernel above lets neighbouring lanes read neighbouring CHANNELS, H*W floats apart (measured 52-100 us per call, ~1 TB/s).
+// Here a workgroup stages the rows its tiles need of 64 channel planes of one image in LDS (lanes along the pixels: coalesced),
+// then the lanes run along the channel for the LDS reads (pitch H*W + 1: conflict-free) and the global stores (256 contiguous
+// bytes per wave).  grid = (C/64, N, row splits): the tile rows of an image are shared out over blockIdx.z to fill the chip.
+__global__ void __launch_bounds__(256) w24_input_small_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int C, int H,
+                                                             int W, int TH, int TW, int off, size_t Pstride, int rows_per,
+                                                             int pitch) {
+  extern __shared__ __attribute__((aligned(16))) float pl[];          // [64 channels][pitch]: input rows [rlo, rhi) of each plane
+  const int HW = H * W;
+  const int n = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
+  const int tr0 = (int)blockIdx.z * rows_per, tr1 = min(TH, tr0 + rows_per);
+  const int lane = tid & 63, g = tid >> 6;
+  const int rlo = max(0, 2 * tr0 + off), rhi = min(H, 2 * (tr1 - 1) + off + 5);
+  {
+    const int cnt = (rhi - rlo) * W;
+    const float* src = x + ((size_t)n * C + c0) * HW + rlo * W;
+    for (int ch = g; ch < 64; ch += 4)
+      for (int e = lane; e < cnt; e += 64) pl[ch * pitch + e] = src[(size_t)ch * HW + e];
+  }
+  __syncthreads();
+  const float* pc = pl + lane * pitch - rlo * W;
+  const size_t P = (size_t)N * TH * TW;
+  for (int t = tr0 * TW + g; t < tr1 * TW; t += 4) {
+    const int ti = t / TW, tj = t - ti * TW;
+    float d[5][5];
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+      const int ih = 2 * ti + off + a;
+      const bool rok = (unsigned)ih < (unsigned)H;
+#pragma unroll
+      for (int b = 0; b < 5; ++b) {
+        const int iw = 2 * tj + off + b;
+        const bool ok = rok && (unsigned)iw < (unsigned)W;
+        d[a][b] = ok ? pc[ih * W + iw] : 0.f;
+      }
+    }
+    float tt[5][5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const float col[5] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j]};
+      float o[5];
+      w24_bt(col, o);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) tt[i][j] = o[i];
+    }
+    const size_t p = (size_t)n * TH * TW + t;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      float o[5];
+      w24_bt(tt[i], o);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) V[((size_t)(i * 5 + j) * Pstride + p) * C + c0 + lane] = o[j];
+    }
+  }
+  if (n == 0 && blockIdx.z == 0)                 // rows [P, Pstride): zero padding for the 128-wide GEMM tiles
+    for (size_t p = P + g; p < Pstride; p += 4)
+      for (int xi = 0; xi < 25; ++xi) V[((size_t)xi * Pstride + p) * C + c0 + lane] = 0.f;
+}
+void w24_input_pc(const float* x, float* V, int N, int C, int H, int W, int TH, int TW, int off, size_t Pstride, hipStream_t s) {
+  const int HW = H * W;
+  SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)N * C * HW + 25.0 * (double)Pstride * C));
+  static int small = -1;
+  if (small < 0) { const char* e = getenv("SG_W24_SMALL"); small = e ? atoi(e) : 1; }
+  if (small && HW >= 144 && W <= 64 && C % 64 == 0) {
+    // tile rows per workgroup: as few as keep ~2048 workgroups busy (each stages 2*rows + 3 input rows of 64 planes: <= ~24 KB)
+    int rows_per = (int)(((long)(C / 64) * N * TH + 2047) / 2048);
+    if (rows_per < 1) rows_per = 1;
+    const int nrows = std::min(H, 2 * rows_per + 3);
+    const int pitch = (nrows * W) | 1;
+    const size_t lds = (size_t)64 * pitch * sizeof(float);
+    if (lds <= 64 * 1024) {
+      if (lds > 48 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&w24_input_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(w24_input_small_kernel, dim3(C / 64, N, sg_cdiv(TH, rows_per)), dim3(256), lds, s, x, V, N, C, H, W, TH, TW, off,
+                         Pstride, rows_per, pitch);
+      return;
+    }
+  }
+  hipLaunchKernelGGL(w24_input_kernel<0>, dim3(sg_cdiv(Pstride * C, 256)), dim3(256), 0, s, x, V, N, C, H, W, TH, TW, off, Pstride, 0, 1);
+}
+
 // U[xi][r][c] = (G g G^T)[xi]; mode 0: r = co, c = ci, g = w[co][ci]; mode 1 (data gradient): r = ci, c = co, g = w[co][ci] rotated
 __global__ void w24_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int R, int Cc, int mode) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1203,9 +1285,7 @@ extern "C" int sg_conv2d_wino24_fwd(const sgConvDesc* d, const float* x, const f
   float* Mx = V + 25 * p.Ps * C;
   { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 26.0 * (double)M * C);
     hipLaunchKernelGGL(w24_weight_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, w, U, M, C, 0); }
-  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * C * d->H * d->W + 25.0 * (double)p.Ps * C));
-    hipLaunchKernelGGL(w24_input_kernel<0>, dim3(sg_cdiv(p.Ps * C, 256)), dim3(256), 0, s, x, V, d->N, C, d->H, d->W, p.TH, p.TW,
-                       -d->pad, p.Ps, 0, 1); }
+  w24_input_pc(x, V, d->N, C, d->H, d->W, p.TH, p.TW, -d->pad, p.Ps, s);
   wino_bgemm(U, V, Mx, M, (int)p.Ps, C, 2.0 * M * (double)C * 25.0 * p.P, s, 25);
   { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * (25.0 * (double)p.P * M + (double)d->N * M * d->OH * d->OW));
     hipLaunchKernelGGL(w24_output_kernel, dim3(sg_cdiv(p.P * M, 256)), dim3(256), 0, s, (const float*)Mx, bias, y, d->N, M, d->OH,
@@ -1225,9 +1305,7 @@ extern "C" int sg_conv2d_wino24_dgrad(const sgConvDesc* d, const float* gy, cons
   float* Mx = V + 25 * p.Pds * K;
   { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 26.0 * (double)M * K);
     hipLaunchKernelGGL(w24_weight_kernel, dim3(sg_cdiv((size_t)M * K, 256)), dim3(256), 0, s, w, U, M, K, 1); }
-  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * K * d->OH * d->OW + 25.0 * (double)p.Pds * K));
-    hipLaunchKernelGGL(w24_input_kernel<0>, dim3(sg_cdiv(p.Pds * K, 256)), dim3(256), 0, s, gy, V, d->N, K, d->OH, d->OW, p.THd,
-                       p.TWd, -(3 - d->pad), p.Pds, 0, 1); }
+  w24_input_pc(gy, V, d->N, K, d->OH, d->OW, p.THd, p.TWd, -(3 - d->pad), p.Pds, s);
   wino_bgemm(U, V, Mx, M, (int)p.Pds, K, 2.0 * M * (double)K * 25.0 * p.Pd, s, 25);
   { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * (25.0 * (double)p.Pd * M + (double)d->N * M * d->H * d->W));
     hipLaunchKernelGGL(w24_output_kernel, dim3(sg_cdiv(p.Pd * M, 256)), dim3(256), 0, s, (const float*)Mx, (const float*)nullptr, gx,
