@@ -96,7 +96,9 @@ int run_kn_parity(const float* W, int Rdim, int B, int m0, int M, const Gather& 
   (void)maxNpix;
   long t128 = 0;
   for (int c = 0; c < par.ncls; ++c) t128 += (long)sg_cdiv(M, 128) * sg_cdiv(par.Npix[c], 128);
-  if (tile == 0 && (!vec || t128 < 384)) tile = 1;   // no split-K here
+  // no split-K here.  768: measured with the fixed-tap loaders (tools/conv_sweep.py) -- the dgrad of Conv2d(256, 512, 3, s2) at
+  // 32x32 (512 tiles of 128x128) runs 0.213 ms on 64x64 tiles against 0.275 ms; from 1024 tiles on the two are level
+  if (tile == 0 && (!vec || t128 < 768)) tile = 1;
   const int tBN = tile == 1 ? 64 : 128;
   par.tile0[0] = 0;
   for (int c = 0; c < par.ncls; ++c) par.tile0[c + 1] = par.tile0[c] + sg_cdiv(par.Npix[c], tBN);
