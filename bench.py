@@ -95,6 +95,8 @@ KERNEL_INSTANTIATIONS = {
     'wino_bgemm_t128': 'igemm_kernel<TileCfg<128,128,2,2,1>, LoadKContig<128,true,false>, LoadKContig<128,true,false>, EpRowMajorPlain>: '
                        'the 16 batched dense GEMMs of a Winograd F(2x2,3x3) conv (ResnetBlock / VGG19 convs), batch-major '
                        'tile order, 32-deep k-tiles, software-pipelined fragment reads',
+    'wino24_bgemm_t128': 'the same instantiation as wino_bgemm_t128: the 25 (x k-chunks) batched dense GEMMs of a Winograd F(2x2,4x4) '
+                         'conv (stride-1 4x4 convs of the PatchGANs, K = 256 / 512 channels)',
     'wino_bgemm_t64': 'igemm_kernel<TileCfg<64,64,2,1>, LoadKContig<64,true,false>, LoadKContig<64,true,false>, EpRowMajor>: '
                       'Winograd GEMMs of the 192-channel mask_net convs',
 }

@@ -762,7 +762,7 @@ void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, in
   sgk::t_alg_bytes = 4.0 * NB * ((double)M * K + (double)cols * K + (double)M * cols);
   t_batch = BatchInfo{}; t_batch.cols_per_batch = cols; t_batch.nbatch = NB; t_batch.a_stride = M * K; t_batch.batch_major = 1;
   {
-    SgProfScope prof(SG_K_WINO_GEMM_128, s, flops, 0);
+    SgProfScope prof(NB == 16 ? SG_K_WINO_GEMM_128 : SG_K_WINO24_GEMM, s, flops, 0);
     static int wt = -1;
     if (wt < 0) { const char* e = getenv("SG_WINO_TILE"); wt = e ? atoi(e) : 0; }
     if (wt == 1)
