@@ -125,7 +125,7 @@ int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const float* w, f
                          void* ws, size_t ws_bytes, sgStream stream);
 /* Winograd F(2x2, 4x4) for the stride-1 4x4 convs of the PatchGANs (reference discriminators.py:221-228:
    nn.Conv2d(nf_prev, nf, kernel_size=4, stride=1, padding=2), 256 -> 512 channels: the largest layer of the discriminator steps):
-   KS 4, stride 1, zero padding 0..3, one source, C1 and Cout multiples of 128, >= 512 output tiles.  25 multiplies per 2x2
+   KS 4, stride 1, zero padding 0..3, one source, C1 and Cout multiples of 128, >= 256 output tiles.  25 multiplies per 2x2
    output tile and channel pair instead of 64; fp32 throughout, results agree with sg_conv2d_fwd / _dgrad / _wgrad to fp32
    rounding (asserted at the same tolerances; gb via sg_channel_sum).  ws: sg_conv2d_wino24_ws_bytes. */
 int sg_conv2d_wino24_supported(const sgConvDesc* d);

@@ -1123,8 +1123,11 @@ bool w24_plan(const sgConvDesc* d, W24Plan* pl) {
   const double cm = d->C1 > d->Cout ? d->C1 : d->Cout;
   const double pm = (double)(p.Ps > p.Pds ? p.Ps : p.Pds) + 32.0 * p.S;
   if (!(25.0 * pm * cm < 2147483647.0 && 25.0 * (double)d->C1 * d->Cout < 2147483647.0)) return false;
-  // the transforms move 25/4 x the activation bytes: below a few hundred tiles the direct kernel wins
-  if (p.P < 512) return false;
+  // the transforms move 25/4 x the activation bytes and the GEMMs need >= 2 column tiles: measured at 256 -> 512 channels, the
+  // 6x6 maps of the third PatchGAN scale (288 tiles) still gain (forward 0.094 -> 0.064 ms, weight gradient 0.084 -> 0.062)
+  static int pmin = -1;
+  if (pmin < 0) { const char* e = getenv("SG_W24_PMIN"); pmin = e ? atoi(e) : 256; }
+  if (p.P < (size_t)pmin) return false;
   if (pl) *pl = p;
   return true;
 }
