@@ -342,6 +342,11 @@ int sg_scale(float* p, float alpha, int64_t n, sgStream stream);
 /* y += alpha * x : a second gradient contribution to a parameter slice of the flat gradient buffer (the first one is
  * written in place by the weight-gradient kernels; replaces autograd's AccumulateGrad add, trainer.py:262,278,299,324) */
 int sg_axpy(float* y, const float* x, float alpha, int64_t n, sgStream stream);
+/* out = a + b : the shortcut add of build_cnn's 'R' residual blocks (reference layers.py:84-118);
+ * out = alpha * a * b : nn.Dropout's mask multiply (layers.py:230, build_mlp(dropout=...)); the mask itself is drawn by the host
+ * framework's device RNG.  Neither is on the benchmark path. */
+int sg_add(const float* a, const float* b, float* out, int64_t n, sgStream stream);
+int sg_mul(const float* a, const float* b, float alpha, float* out, int64_t n, sgStream stream);
 /* total_loss = sum_i weight_i * loss_i over <= SG_WSUM_MAX device scalars (LossManager.add_loss, utils.py:50-57, and the
  * scale sums of GANLoss / calculate_features_loss, losses.py:166-172, trainer.py:331-340); terms_host = HOST array of
  * DEVICE pointers, weights_host = HOST array.  _bwd: gterms[i] = weights[i] * gout[0] */

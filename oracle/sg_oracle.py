@@ -223,8 +223,30 @@ class Interpolate(nn.Module):
                              align_corners=self.align_corners)
 
 
+class ResidualBlock(nn.Module):
+    """layers.py:84-118: x + branch(x), branch = [norm, act, conv, norm, act, conv] ('same' padding).  The reference runs the
+    branch twice and keeps the second result (:114-115) -- visible in BatchNorm's buffers, which advance twice -- and cannot run
+    with padding 0 (its shortcut slice is empty, :111-113)."""
+
+    def __init__(self, channels, normalization='batch', activation='relu', padding='same', kernel_size=3, init='default'):
+        super().__init__()
+        pad = 0 if padding == 'valid' else (kernel_size - 1) // 2
+        if pad == 0:
+            raise ValueError('ResidualBlock without padding: the reference shortcut is empty')
+        branch = []
+        for _ in range(2):
+            nrm = get_normalization_2d(channels, normalization)
+            branch += ([nrm] if nrm is not None else []) + [get_activation(activation),
+                                                            nn.Conv2d(channels, channels, kernel_size, padding=pad)]
+        self.net = nn.Sequential(*branch)
+
+    def forward(self, x):
+        self.net(x)
+        return x + self.net(x)
+
+
 def build_cnn(arch, normalization='batch', activation='relu', padding='same', pooling='max', init='default'):
-    """layers.py:128-212, restricted to the layer kinds the hot path uses (I, C, U, P)."""
+    """layers.py:128-212: layer kinds I, C, R, U, P."""
     specs = arch.split(',') if isinstance(arch, str) else list(arch)
     chans = 3
     if specs and specs[0][0] == 'I':
@@ -244,6 +266,10 @@ def build_cnn(arch, normalization='batch', activation='relu', padding='same', po
             pad = 0 if padding == 'valid' else (k - 1) // 2
             mods.append(nn.Conv2d(chans, oc, kernel_size=k, padding=pad, stride=st))
             chans = oc
+        elif s[0] == 'R':          # layers.py:172-177
+            mods.append(ResidualBlock(chans, normalization=normalization if seen_conv else 'none', activation=activation,
+                                      padding=padding))
+            seen_conv = True
         elif s[0] == 'U':
             mods.append(Interpolate(scale_factor=int(s[1:]), mode='nearest'))
         elif s[0] == 'P':

@@ -235,6 +235,29 @@ extern "C" int sg_axpy(float* y, const float* x, float alpha, int64_t n, sgStrea
   return 0;
 }
 
+// out = a + b / out = a * b * alpha: the shortcut add of build_cnn's residual blocks (layers.py:84-118) and the mask multiply of
+// nn.Dropout (layers.py:230) -- neither is on the benchmark path, both are plain HBM-bound passes
+__global__ void ewise_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n,
+                             int mul, float alpha) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = mul ? a[i] * b[i] * alpha : a[i] + b[i];
+}
+extern "C" int sg_add(const float* a, const float* b, float* out, int64_t n, sgStream stream) {
+  SG_ARG_CHECK(a && b && out && n >= 0, "sg_add: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(ewise_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, (size_t)n, 0, 1.f);
+  SG_LAUNCH_CHECK("sg_add");
+  return 0;
+}
+extern "C" int sg_mul(const float* a, const float* b, float alpha, float* out, int64_t n, sgStream stream) {
+  SG_ARG_CHECK(a && b && out && n >= 0, "sg_mul: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(ewise_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, (size_t)n, 1, alpha);
+  SG_LAUNCH_CHECK("sg_mul");
+  return 0;
+}
+
 extern "C" int sg_weighted_sum_fwd(const void* const* terms_host, const float* weights_host, int n, float* out,
                                    sgStream stream) {
   SG_ARG_CHECK(terms_host && weights_host && out && n > 0 && n <= SG_WSUM_MAX, "sg_weighted_sum_fwd: bad arguments (n=%d)", n);

@@ -245,6 +245,51 @@ def get_activation(name):
     return LeakyReLU(**kwargs)
 
 
+class Dropout(nn.Module):
+    """nn.Dropout (layers.py:230): the Bernoulli mask comes from torch's device generator, the multiply is a HIP launch; eval
+    mode is the identity.  (No reference pin is possible for the random mask; the arithmetic is tested against x * mask / (1-p).)"""
+
+    def __init__(self, p=0.5, inplace=False):
+        super().__init__()
+        if not 0.0 <= p <= 1.0:
+            raise ValueError('dropout probability has to be between 0 and 1, but got %r' % (p,))
+        self.p = float(p)
+
+    def forward(self, x):
+        return ops.dropout(x, self.p, self.training)
+
+    def extra_repr(self):
+        return 'p=%g' % self.p
+
+
+class ResidualBlock(nn.Module):
+    """build_cnn's 'R' layer (layers.py:84-118): x + [norm, act, Conv(K, same), norm, act, Conv(K, same)](x), state_dict keys
+    ``net.<i>`` as in the reference.  Two properties of the reference forward are kept:
+      * it evaluates the branch TWICE and adds the second result (layers.py:114-115), so BatchNorm running statistics and
+        ``num_batches_tracked`` advance twice per training forward -- done here too (only when it is observable: training mode
+        and a BatchNorm inside),
+      * with padding='valid' its shortcut slice ``x[:, :, 0:-0, 0:-0]`` is empty and the add fails: rejected at construction."""
+
+    def __init__(self, channels, normalization='batch', activation='relu', padding='same', kernel_size=3, init='default'):
+        super().__init__()
+        K, P = kernel_size, _get_padding(kernel_size, padding)
+        if P == 0:
+            raise ValueError('ResidualBlock(padding="valid") cannot run in the reference either: its shortcut slice is empty '
+                             '(layers.py:111-113)')
+        self.padding = P
+        mods = [get_normalization_2d(channels, normalization), get_activation(activation),
+                Conv2d(channels, channels, kernel_size=K, padding=P),
+                get_normalization_2d(channels, normalization), get_activation(activation),
+                Conv2d(channels, channels, kernel_size=K, padding=P)]
+        self.net = FusedSequential(*[m for m in mods if m is not None])
+
+    def forward(self, x):
+        if self.training and any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in self.net):
+            with torch.no_grad():
+                self.net(x)                      # the reference's first, discarded evaluation: only its buffer updates remain
+        return ops.add(x, self.net(x))
+
+
 def _get_padding(K, mode):
     if mode == 'valid':
         return 0
@@ -279,6 +324,10 @@ def build_cnn(arch, normalization='batch', activation='relu', padding='same', po
             stride = vals[2] if len(vals) == 3 else 1
             layers.append(Conv2d(cur_C, next_C, kernel_size=K, padding=_get_padding(K, padding), stride=stride))
             cur_C = next_C
+        elif s[0] == 'R':                                   # layers.py:172-177: residual block, no norm in front of the very first conv
+            layers.append(ResidualBlock(cur_C, normalization='none' if first_conv else normalization, activation=activation,
+                                        padding=padding, init=init))
+            first_conv = False
         elif s[0] == 'U':
             layers.append(Interpolate(scale_factor=int(s[1:]), mode='nearest'))
         elif s[0] == 'P':                                   # layers.py:181-189: 'P2' = 2x2 pooling, stride 2
@@ -313,7 +362,7 @@ def build_mlp(dim_list, activation='relu', batch_norm='none', dropout=0, final_n
             elif activation == 'leakyrelu':
                 layers.append(LeakyReLU())
         if dropout > 0:
-            raise NotImplementedError('dropout is unused on the training path (args.py has no dropout flag)')
+            layers.append(Dropout(p=dropout))
     return FusedSequential(*layers)
 
 
@@ -323,12 +372,14 @@ class ResnetBlock(nn.Module):
 
     def __init__(self, dim, padding_type, norm_layer, activation=None, use_dropout=False):
         super().__init__()
-        if padding_type != 'reflect' or use_dropout:
-            raise NotImplementedError('ResnetBlock: only reflect padding without dropout is used (generators.py:79)')
+        if padding_type != 'reflect':
+            raise NotImplementedError('ResnetBlock: only reflect padding is used (generators.py:79)')
         activation = ReLU(True) if activation is None else activation
-        self.conv_block = FusedSequential(
-            ReflectionPad2d(1), Conv2d(dim, dim, kernel_size=3, padding=0), norm_layer(dim), activation,
-            ReflectionPad2d(1), Conv2d(dim, dim, kernel_size=3, padding=0), norm_layer(dim))
+        first = [ReflectionPad2d(1), Conv2d(dim, dim, kernel_size=3, padding=0), norm_layer(dim), activation]
+        if use_dropout:                                     # layers.py:256-257 (pix2pixHD option, off in generators.py:79)
+            first.append(Dropout(0.5))
+        self.conv_block = FusedSequential(*first, ReflectionPad2d(1), Conv2d(dim, dim, kernel_size=3, padding=0),
+                                          norm_layer(dim))
 
     def forward(self, x):
         return self.conv_block(x, skip=x)

@@ -731,6 +731,56 @@ def activation(x, act, slope=0.0):
 # normalisation / pooling
 # =============================================================================================
 
+class AddFn(Function):
+    """a + b of two equally shaped tensors (the shortcut of build_cnn's residual blocks, layers.py:116)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32(a, 'add lhs'), _f32(b, 'add rhs')
+        assert a.shape == b.shape, 'add: shapes %s and %s differ' % (tuple(a.shape), tuple(b.shape))
+        out = torch.empty_like(a)
+        _call('sg_add', _p(a), _p(b), _p(out), a.numel(), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+class MaskMulFn(Function):
+    """x * mask * alpha with a constant mask (nn.Dropout: mask ~ Bernoulli(1 - p), alpha = 1 / (1 - p))"""
+
+    @staticmethod
+    def forward(ctx, x, mask, alpha):
+        x, mask = _f32(x, 'dropout input'), _f32(mask, 'dropout mask')
+        out = torch.empty_like(x)
+        _call('sg_mul', _p(x), _p(mask), float(alpha), _p(out), x.numel(), _stream())
+        ctx.save_for_backward(mask)
+        ctx.alpha = float(alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mask, = ctx.saved_tensors
+        g = _f32(g, 'dropout gradient')
+        gx = torch.empty_like(g)
+        _call('sg_mul', _p(g), _p(mask), ctx.alpha, _p(gx), g.numel(), _stream())
+        return gx, None, None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    if p >= 1.0:
+        return MaskMulFn.apply(x, torch.zeros_like(x), 0.0)
+    mask = torch.empty_like(x).bernoulli_(1.0 - p)          # the framework's device RNG: plumbing, like torch.empty
+    return MaskMulFn.apply(x, mask, 1.0 / (1.0 - p))
+
+
 class InstanceNormFn(Function):
     """act(InstanceNorm2d(x)) [+ skip]  (affine=False, eps 1e-5: layers.py:296)."""
 

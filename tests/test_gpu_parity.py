@@ -720,10 +720,10 @@ def test_fused_adam_skips_parameters_without_gradient(hip):
 # ------------------------------------------------------------------------------------------
 # modules vs reference goldens (same fixtures the oracle is pinned with)
 # ------------------------------------------------------------------------------------------
-def _run_module(g, mod, n_in):
+def _run_module(g, mod, n_in, train=True):
     fill_deterministic(mod)
     mod = mod.to(DEV)
-    mod.train()
+    mod.train(train)
     ins = []
     for i in range(n_in):
         t = torch.from_numpy(g['in%d' % i]).to(DEV)
@@ -761,6 +761,10 @@ def test_modules_vs_reference(hip, golden):
     IN = Lh.get_norm_layer('instance')
     _run_module(golden('mod_mlp'), Lh.build_mlp([10, 16, 6]), 1)
     _run_module(golden('mod_mask_net'), Gh.mask_net(24, 8), 1)
+    # residual blocks of build_cnn (BatchNorm buffers pin the reference's double evaluation of the branch), eval-mode dropout
+    _run_module(golden('mod_cnn_residual'), Lh.build_cnn('I6,R,C3-8-2,R,C3-4', normalization='batch',
+                                                         activation='leakyrelu-0.2', padding='same')[0], 1)
+    _run_module(golden('mod_mlp_dropout_eval'), Lh.build_mlp([10, 16, 6], dropout=0.3), 1, train=False)
     _run_module(golden('mod_encoder'), Gh.AppearanceEncoder(vocab, arch='C4-8-2,C4-16-2,C4-32-2', normalization='batch',
                                                             activation='leakyrelu-0.2', padding='valid', vecs_size=24), 1)
     _run_module(golden('mod_globalgen'), Gh.GlobalGenerator(12, 3, ngf=8, n_downsampling=2, n_blocks=2, norm_layer=IN), 1)
@@ -769,6 +773,30 @@ def test_modules_vs_reference(hip, golden):
                                                                     num_objects=12), 2)
     _run_module(golden('mod_objD'), Dh.AcCropDiscriminator(vocab, arch='C4-8-2,C4-16-2,C4-32-2', normalization='batch',
                                                            activation='leakyrelu-0.2', object_size=32, padding='valid'), 4)
+
+
+def test_dropout_and_residual_block_semantics(hip):
+    """layers.Dropout: training = x * Bernoulli(1-p) mask / (1-p) with the mask torch's device generator draws (re-drawn here from
+    the same seed), gradient through the same mask, eval = identity; ResnetBlock(use_dropout=True) builds and steps;
+    ResidualBlock without padding is refused like the reference's empty shortcut (layers.py:111-113)."""
+    from scene_generation_amd import layers as Lh
+    x = det((6, 40), 401).to(DEV).requires_grad_()
+    drop = Lh.Dropout(0.3).to(DEV)
+    torch.manual_seed(77)
+    y = drop(x)
+    torch.manual_seed(77)
+    mask = torch.empty_like(x).bernoulli_(0.7)
+    assert torch.equal(y.detach(), (x.detach() * mask * (1.0 / 0.7))) or float((y.detach() - x.detach() * mask / 0.7).abs().max()) < 1e-6
+    y.backward(torch.ones_like(y))
+    close(x.grad, mask / 0.7, 1e-6, 'dropout gradient')
+    drop.eval()
+    assert drop(x) is x
+    blk = Lh.ResnetBlock(16, 'reflect', Lh.get_norm_layer('instance'), use_dropout=True).to(DEV)
+    assert [type(m).__name__ for m in blk.conv_block][4] == 'Dropout'
+    out = blk(det((2, 16, 8, 8), 402).to(DEV))
+    assert out.shape == (2, 16, 8, 8) and torch.isfinite(out).all()
+    with pytest.raises(ValueError):
+        Lh.ResidualBlock(8, padding='valid')
 
 
 def test_imgD_folded_concat_equals_materialised(hip):

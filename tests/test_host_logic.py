@@ -307,3 +307,23 @@ def test_collate_adapter_contract_and_host_summaries():
         validate_collated(hb._replace(triples=tri))
     with _pt.raises(ValueError):
         validate_collated(hb._replace(boxes=hb.boxes[:-1]))
+
+
+def test_side_stream_fork_is_a_no_op_without_a_gpu():
+    """streams.fork on CPU tensors / with the switch off: every branch runs inline on the caller's (only) stream, join_all
+    does nothing -- the discriminators call it unconditionally."""
+    import torch
+    from scene_generation_amd import streams
+    order = []
+    with streams.fork(torch.device('cpu'), 'imgD') as f:
+        for i in range(3):
+            with f.branch(i):
+                order.append(i)
+    assert order == [0, 1, 2] and not f.on and f.used == []
+    streams.join_all(torch.device('cpu'))
+    saved = streams.ENABLED
+    try:
+        streams.ENABLED = True                     # opting in does not make a CPU device usable
+        assert not streams.fork(torch.device('cpu'), 'imgD').on
+    finally:
+        streams.ENABLED = saved

@@ -88,9 +88,9 @@ def test_crop_vs_reference(golden, case):
     close(feats.grad, g['g_feats'], 1e-4, 'g_feats')
 
 
-def _run_module(g, mod, n_in):
+def _run_module(g, mod, n_in, train=True):
     fill_deterministic(mod)
-    mod.train()
+    mod.train(train)
     ins = []
     for i in range(n_in):
         t = T(g['in%d' % i])
@@ -128,6 +128,10 @@ def test_modules_vs_reference(golden):
     IN = O.get_norm_layer('instance')
     _run_module(golden('mod_mlp'), O.build_mlp([10, 16, 6]), 1)
     _run_module(golden('mod_mask_net'), O.mask_net(24, 8), 1)
+    # residual blocks of build_cnn (BatchNorm buffers pin the reference's double evaluation of the branch), eval-mode dropout
+    _run_module(golden('mod_cnn_residual'), O.build_cnn('I6,R,C3-8-2,R,C3-4', normalization='batch',
+                                                        activation='leakyrelu-0.2', padding='same')[0], 1)
+    _run_module(golden('mod_mlp_dropout_eval'), O.build_mlp([10, 16, 6], dropout=0.3), 1, train=False)
     _run_module(golden('mod_encoder'), O.AppearanceEncoder(vocab, arch='C4-8-2,C4-16-2,C4-32-2',
                                                            normalization='batch', activation='leakyrelu-0.2',
                                                            padding='valid', vecs_size=24), 1)

@@ -254,6 +254,12 @@ def golden_modules():
     run_module('mod_encoder', AppearanceEncoder(vocab, arch='C4-8-2,C4-16-2,C4-32-2', normalization='batch',
                                                 activation='leakyrelu-0.2', padding='valid', vecs_size=24),
                [det((5, 3, 32, 32), 52)])
+    # build_cnn with residual blocks (layers.py:84-118,172-177): BatchNorm inside the block -> the buffers pin the reference's
+    # double evaluation of the branch; eval-mode dropout MLP (layers.py:229-230) is the identity
+    from scene_generation.layers import build_cnn
+    run_module('mod_cnn_residual', build_cnn('I6,R,C3-8-2,R,C3-4', normalization='batch', activation='leakyrelu-0.2',
+                                             padding='same')[0], [det((3, 6, 12, 12), 57)])
+    run_module('mod_mlp_dropout_eval', build_mlp([10, 16, 6], dropout=0.3), [det((5, 10), 58)], train=False)
     run_module('mod_globalgen', GlobalGenerator(12, 3, ngf=8, n_downsampling=2, n_blocks=2,
                                                 norm_layer=get_norm_layer('instance')),
                [det((2, 12, 16, 16), 53)])
