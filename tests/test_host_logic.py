@@ -327,3 +327,43 @@ def test_side_stream_fork_is_a_no_op_without_a_gpu():
         assert not streams.fork(torch.device('cpu'), 'imgD').on
     finally:
         streams.ENABLED = saved
+
+
+def test_winograd_f24_constants_are_exact_and_adjoint():
+    """The F(2x2,4x4) matrices hard-coded in csrc/igemm.hip (w24_bt / w24_g / w24_at / w24_a / w24_gt; derivation:
+    tools/winograd_f24.py): y = A^T[(G g G^T) . (B^T d B)]A is the 4x4 correlation of a 5x5 patch exactly (float64), and the
+    weight-gradient form G^T[(A dy A^T) . (B^T d B)]G is its adjoint."""
+    import numpy as np
+    AT = np.array([[1, 1, 1, 1, 0], [0, 1, -1, -2, 1]], dtype=np.float64)
+    G = np.array([[-1 / 2, 0, 0, 0], [1 / 6, 1 / 6, 1 / 6, 1 / 6], [1 / 2, -1 / 2, 1 / 2, -1 / 2], [-1 / 6, 1 / 3, -2 / 3, 4 / 3],
+                  [0, 0, 0, 1]], dtype=np.float64)
+    BT = np.array([[-2, -1, 2, 1, 0], [0, 2, 3, 1, 0], [0, -2, 1, 1, 0], [0, -1, 0, 1, 0], [0, -2, -1, 2, 1]], dtype=np.float64)
+    # the device helpers, transcribed: any edit of the kernel constants has to show up here
+    def w24_bt(d): return np.array([-2 * d[0] - d[1] + 2 * d[2] + d[3], 2 * d[1] + 3 * d[2] + d[3], -2 * d[1] + d[2] + d[3],
+                                    d[3] - d[1], -2 * d[1] - d[2] + 2 * d[3] + d[4]])
+    def w24_g(g): return np.array([-0.5 * g[0], (g[0] + g[1] + g[2] + g[3]) / 6, (g[0] - g[1] + g[2] - g[3]) * 0.5,
+                                   (-g[0] + 2 * g[1] - 4 * g[2] + 8 * g[3]) / 6, g[3]])
+    def w24_at(m): return np.array([m[0] + m[1] + m[2] + m[3], m[1] - m[2] - 2 * m[3] + m[4]])
+    def w24_a(y): return np.array([y[0], y[0] + y[1], y[0] - y[1], y[0] - 2 * y[1], y[1]])
+    def w24_gt(t): return np.array([-0.5 * t[0] + (t[1] - t[3]) / 6 + 0.5 * t[2], (t[1] + 2 * t[3]) / 6 - 0.5 * t[2],
+                                    (t[1] - 4 * t[3]) / 6 + 0.5 * t[2], (t[1] + 8 * t[3]) / 6 - 0.5 * t[2] + t[4]])
+    rng = np.random.RandomState(3)
+    e5, e4, e2 = np.eye(5), np.eye(4), np.eye(2)
+    assert np.allclose(np.stack([w24_bt(e) for e in e5], 1), BT) and np.allclose(np.stack([w24_g(e) for e in e4], 1), G)
+    assert np.allclose(np.stack([w24_at(e) for e in e5], 1), AT)
+    assert np.allclose(np.stack([w24_a(e) for e in e2], 1), AT.T) and np.allclose(np.stack([w24_gt(e) for e in e5], 1), G.T)
+    g, d, dy = rng.randn(4, 4), rng.randn(5, 5), rng.randn(2, 2)
+    y = AT @ ((G @ g @ G.T) * (BT @ d @ BT.T)) @ AT.T
+    ref = np.array([[(g * d[i:i + 4, j:j + 4]).sum() for j in range(2)] for i in range(2)])
+    assert np.abs(y - ref).max() < 1e-12
+    gw = G.T @ ((AT.T @ dy @ AT) * (BT @ d @ BT.T)) @ G               # d<dy, y>/dg
+    gref = np.array([[sum(dy[i, j] * d[i + a, j + b] for i in range(2) for j in range(2)) for b in range(4)] for a in range(4)])
+    assert np.abs(gw - gref).max() < 1e-12
+    # data gradient = the forward form on dy with the rotated filter and padding 3 - pad (here: full correlation, pad 3)
+    dyp = np.zeros((8, 8)); dyp[3:5, 3:5] = dy
+    gd = np.array([[(g[::-1, ::-1] * dyp[i:i + 4, j:j + 4]).sum() for j in range(5)] for i in range(5)])
+    gdref = np.zeros((5, 5))
+    for i in range(2):
+        for j in range(2):
+            gdref[i:i + 4, j:j + 4] += dy[i, j] * g
+    assert np.abs(gd - gdref).max() < 1e-12
