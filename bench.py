@@ -122,7 +122,11 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('SG_DIST_BACKEND', 'nccl')
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        import datetime
+        # a rank that never arrives must fail the run, not hang it: 10 minutes covers the slowest first import on a fresh box
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
+        from scene_generation_amd.parallel import first_contact
+        first_contact(dev)        # checked first collective: a wrong IPC mode / dead link fails HERE with a readable message
 
     from scene_generation_amd import ops, graphs
     from scene_generation_amd.args import parser
@@ -222,14 +226,14 @@ def main():
             exp_ms, n = r.exposed_ms()
             r.profile = False
             buckets = r.time_buckets()
-            iso = sum(ms for _, ms in buckets)
-            iso_total += iso
+            iso_ms = sum(ms for _, ms in buckets)
+            iso_total += iso_ms
             exposed_total += exp_ms / 3
             comm[names.get(id(r.optimizer), '?')] = {
                 'buckets': len(buckets), 'bytes': sum(b for b, _ in buckets), 'overlap_mode': bool(r.overlap),
-                'isolated_allreduce_ms': round(iso, 3),
+                'isolated_allreduce_ms': round(iso_ms, 3),
                 'per_bucket_ms': [round(ms, 3) for _, ms in buckets],
-                'algbw_GBps': round(sum(b for b, _ in buckets) / (iso * 1e-3) / 1e9, 1) if iso > 0 else None,
+                'algbw_GBps': round(sum(b for b, _ in buckets) / (iso_ms * 1e-3) / 1e9, 1) if iso_ms > 0 else None,
                 'exposed_ms_per_step': round(exp_ms / 3, 3)}
         comm['exposed_ms_per_step'] = round(exposed_total, 3)
         comm['isolated_ms_per_step'] = round(iso_total, 3)

@@ -199,8 +199,11 @@ __global__ void __launch_bounds__(256) layout_fwd_reg_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < CAP; ++j) {
       const bool on = live && j < nc;
+      // an image without objects (nc <= 0) must not touch boxes at all: o_beg may equal O there, i.e. one row past the end
+      // (block-uniform branch)
       const size_t o = (size_t)(o_beg + c0 + (j < nc ? j : 0));
-      const float x0 = boxes[o * 4 + 0], y0 = boxes[o * 4 + 1], x1 = boxes[o * 4 + 2], y1 = boxes[o * 4 + 3];
+      float x0 = 0.f, y0 = 0.f, x1 = 1.f, y1 = 1.f;
+      if (nc > 0) { x0 = boxes[o * 4 + 0]; y0 = boxes[o * 4 + 1]; x1 = boxes[o * 4 + 2]; y1 = boxes[o * 4 + 3]; }
       const Tap ty = make_tap(box_coord(Y, y0, y1), M, ac);
 #pragma unroll
       for (int v = 0; v < 4; ++v) {

@@ -491,7 +491,11 @@ extern "C" int sg_conv2d_head_wgrad(const sgConvDesc* d, const float* gy, const 
   const HeadGeom g = head_geom(d);
   float* part = reinterpret_cast<float*>(ws);
   const dim3 grid(g.chunks, d->N);
-  const size_t lds = ((size_t)g.CH * g.PH * g.PW + 2 * (size_t)d->OH * d->OW) * sizeof(float);
+  // the staged planes are reused as a 256-float reduction buffer at the end of the kernel: tiny maps (a 1x1 head on a
+  // < 16-pixel map, a 3x3 head on a 1x1 map) stage fewer than 256 floats -- never allocate less
+  size_t lds_floats = (size_t)g.CH * g.PH * g.PW + 2 * (size_t)d->OH * d->OW;
+  if (lds_floats < 256) lds_floats = 256;
+  const size_t lds = lds_floats * sizeof(float);
   const size_t nw = (size_t)d->C1 * d->KS * d->KS;
   {
     SgProfScope prof(SG_K_HEAD, s, 2.0 * d->C1 * d->KS * d->KS * (double)d->N * d->OH * d->OW, head_bytes(d));

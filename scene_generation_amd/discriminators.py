@@ -188,8 +188,9 @@ class MultiscaleDiscriminator(_ScalePyramid):
         out = [None] * len(levels)
         with streams.fork(input.device, 'imgD') as f:
             for i, (stages, a, b) in enumerate(levels):
-                with f.branch(i):
+                with f.branch(i, reads=(a, b)):
                     out[i] = self.singleD_forward(stages, a, b)
+                    f.produced(out[i])
         return out
 
 
@@ -218,8 +219,9 @@ class MultiscaleMaskDiscriminator(_ScalePyramid):
         out = [None] * len(levels)
         with streams.fork(input.device, 'maskD') as f:
             for i, (stages, h) in enumerate(levels):
-                with f.branch(i):
+                with f.branch(i, reads=(h, cond)):
                     out[i] = self.singleD_forward(stages, h, cond)
+                    f.produced(out[i])
         return out
 
 

@@ -81,7 +81,9 @@ def encode_features(model, loader, object_size=64, device=None, max_objects=None
             if max_objects is not None and count >= max_objects:
                 break
     rep = rep if rep is not None else getattr(model, 'rep_size', 0)
-    return {label: (np.stack(rows) if rows else np.zeros((0, rep))) for label, rows in chunks.items()}
+    # float64 banks like the reference's features.npy: encode_features.py:121,133 appends float32 rows to np.zeros((0, rep)),
+    # and numpy promotes to float64 (the KMeans centres downstream inherit the dtype)
+    return {label: (np.stack(rows).astype(np.float64) if rows else np.zeros((0, rep))) for label, rows in chunks.items()}
 
 
 def cluster_features(features, n_clusters, random_state=0):

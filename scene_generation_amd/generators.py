@@ -53,6 +53,18 @@ def define_G(input_nc, output_nc, ngf, n_downsample_global=3, n_blocks_global=9,
                            get_norm_layer(norm)).apply(weights_init)
 
 
+class _RangeRunner(object):
+    """``h -> seq(h, start=a, end=b)`` as an OBJECT holding the sequential: ``copy.deepcopy`` of a GlobalGenerator (EMA copy,
+    model snapshot) then rebinds the graphed segments to the COPY's layers through the memo (a closure / lambda is atomic to
+    deepcopy and would keep running the original's layers -- ADVICE r3)."""
+
+    def __init__(self, seq, a, b):
+        self.seq, self.a, self.b = seq, a, b
+
+    def __call__(self, h):
+        return self.seq(h, start=self.a, end=self.b)
+
+
 class GlobalGenerator(nn.Module):
     """pix2pixHD global generator (generators.py:62-91): 7x7 stem, stride-2 encoder, residual trunk, transposed-conv
     decoder, 7x7 tanh head.  One flat Sequential => the reference's ``model.<index>`` state_dict keys."""
@@ -94,7 +106,7 @@ class GlobalGenerator(nn.Module):
                       for a, b in zip(cuts[:-1], cuts[1:])]
 
     def _runner(self, a, b):
-        return lambda h: self.model(h, start=a, end=b)
+        return _RangeRunner(self.model, a, b)
 
     def forward(self, input):
         h = self.model(input, end=2)          # ReflectionPad2d(3) + Conv7x7 over the layout

@@ -81,6 +81,35 @@ def broadcast_int(value, device, src=0):
     return int(t.item())
 
 
+def first_contact(device, timeout_s=120.0):
+    """The first collective of the default group, checked: a one-element SUM all-reduce whose result must equal the world size.
+    RCCL sets its rings up lazily, so a broken transport (most often the IPC mode: this driver only supports dmabuf IPC,
+    ``HSA_ENABLE_IPC_MODE_LEGACY=0``; the legacy mode fails with ``hipIpcGetMemHandle: invalid argument``) otherwise shows up as
+    an opaque error -- or a hang -- inside the first gradient bucket.  Collective: call on every rank right after
+    ``init_process_group``."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    world, backend = dist.get_world_size(), dist.get_backend()
+    t = torch.ones(1, device=device if backend != 'gloo' or torch.cuda.is_available() else 'cpu')
+    try:
+        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+        import datetime
+        try:
+            work.wait(timeout=datetime.timedelta(seconds=timeout_s))
+        except TypeError:                                 # (backends whose Work.wait takes no timeout)
+            work.wait()
+        got = float(t.item())
+    except Exception as e:
+        raise RuntimeError(
+            'scene_generation_amd.parallel: the first %s collective failed on rank %d of %d: %r.  Environment: '
+            'HSA_ENABLE_IPC_MODE_LEGACY=%s (must be 0 on hosts whose driver only supports dmabuf IPC), MASTER_ADDR=%s, '
+            'device %s, visible devices %d.  Re-run with NCCL_DEBUG=INFO for the transport RCCL picked.'
+            % (backend, dist.get_rank(), world, e, os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'),
+               os.environ.get('MASTER_ADDR'), device, torch.cuda.device_count() if torch.cuda.is_available() else 0)) from e
+    if got != float(world):
+        raise RuntimeError('scene_generation_amd.parallel: first all-reduce returned %r, expected %d' % (got, world))
+
+
 def init_distributed(backend=None):
     """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns (rank, world)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -92,8 +121,11 @@ def init_distributed(backend=None):
     if backend == 'nccl':
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (see first_contact)
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
+        first_contact('cuda:%d' % torch.cuda.current_device() if torch.cuda.is_available() else 'cpu')
     control_group()
     return rank, world
 

@@ -12,7 +12,9 @@ tools/probe/multistream_probe.py: forward + backward of the three scales 6.14 ->
     # leaving the fork makes the current stream wait for every branch
 
 Rules that keep this safe:
-  * every tensor a branch reads was produced before the fork (or inside the branch); branch outputs are consumed after the join,
+  * every tensor a branch reads was produced before the fork (or inside the branch) and is named in ``branch(i, reads=...)``;
+    branch outputs are consumed after the join and named in ``produced(...)`` -- both are ``record_stream``-ed on the other
+    stream, so the caching allocator never recycles a block a kernel of the other stream may still be using,
   * autograd runs the backward of an operator on the stream of its forward and synchronises across streams itself -- but the
     weight-gradient kernels write straight into the optimiser's flat gradient buffer (ops.GradOut), which autograd does not
     see: whoever reads that buffer (optimiser step, gradient all-reduce) calls ``join_all()`` first,
@@ -61,19 +63,42 @@ class fork(object):
             self.main = torch.cuda.current_stream(self.device)
         return self
 
-    def branch(self, i):
+    def branch(self, i, reads=()):
+        """``reads``: tensors allocated on the main stream that kernels of this branch read (its inputs; autograd keeps them
+        for the branch's backward, which runs on the same side stream).  They are recorded on the side stream so that the
+        caching allocator does not hand their block to another main-stream kernel while a side-stream kernel may still be
+        reading it (the block is reused only after the side-stream work queued at free time has finished -- ADVICE r3)."""
         if not self.on or i == 0:
             return contextlib.nullcontext()
         s = side_stream(self.device, self.group, i)
         s.wait_stream(self.main)
         self.used.append(s)
+        for t in _tensors(reads):
+            t.record_stream(s)
+        self._side = True
         return torch.cuda.stream(s)
+
+    def produced(self, outputs):
+        """tensors a side branch allocated and the code behind the join consumes (and frees) on the main stream"""
+        if self.on and torch.cuda.current_stream(self.device) != self.main:
+            for t in _tensors(outputs):
+                t.record_stream(self.main)
 
     def __exit__(self, *exc):
         if self.on:
             for s in self.used:
                 self.main.wait_stream(s)
         return False
+
+
+def _tensors(x):
+    if isinstance(x, torch.Tensor):
+        if x.is_cuda and x.untyped_storage().size() > 0:
+            yield x
+    elif isinstance(x, (list, tuple)):
+        for y in x:
+            for t in _tensors(y):
+                yield t
 
 
 def join_all(device=None):

@@ -113,3 +113,39 @@ def test_two_rank_hip_trainer_matches_sequential_shards(backend):
     assert res[0][3] == res[1][3], 'the use_gt coin must be identical on all ranks'
     for n in OPTS:
         assert np.array_equal(res[0][2][n], res[1][2][n]), '%s: ranks diverged after two steps' % n
+
+
+def test_bench_dp_leg_executes_two_ranks_on_one_gpu():
+    """bench.py's multi-GPU leg exactly as the driver launches it (``python -m torch.distributed.run --nproc-per-node N bench.py
+    --gpus N``), with two ranks sharing this box's one GPU over gloo (SG_DIST_BACKEND=gloo SG_SHARE_GPU=1): first-contact check,
+    Trainer(distributed=True) at FULL widths (12 x 64 MB generator buckets), the deferred generator step, ``time_buckets``,
+    ``exposed_ms`` and the JSON contract.  VERDICT r3: the first 8-GPU run must not be the first execution of this code."""
+    import json
+    import subprocess
+    env = dict(os.environ, SG_DIST_BACKEND='gloo', SG_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '3',
+           '--batch_per_gpu', '8', '--no_secondary', '--no_legs', '--cpu_baseline', 'off']
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, 'bench.py --gpus 2 failed:\n%s\n%s' % (r.stdout[-3000:], r.stderr[-6000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
+    assert len(lines) == 1, 'exactly ONE JSON line from rank 0, got %d:\n%s' % (len(lines), r.stdout[-3000:])
+    out = json.loads(lines[0])
+    try:
+        d = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'bench_dp2_gloo.json'), 'w') as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    assert out['n_gpus'] == 2 and out['rccl_ranks'] == 2 and out['dist_backend'] == 'gloo'
+    assert out['scaling'] == 'weak' and out['config']['global_batch'] == 16 and out['config']['parallelism'] == 'dp2'
+    assert out['steps'] == 2 and out['warmup'] == 3 and out['value'] > 0 and out['ms_per_step'] > 0
+    assert abs(out['value'] - 16 * 2 / (out['ms_per_step'] * 2e-3)) < 1e-6 * out['value']       # whole-job images / max-rank time
+    ar = out['allreduce']
+    assert ar['G']['buckets'] >= 12 and ar['G']['bytes'] > 700e6 and ar['G']['overlap_mode'] is True
+    for name in ('D_img', 'D_obj', 'D_mask'):
+        assert ar[name]['buckets'] >= 1 and ar[name]['isolated_allreduce_ms'] > 0
+    assert ar['overlap_fraction'] is not None and ar['overlap_fraction'] == ar['overlap_fraction']      # finite, not NaN
+    assert ar['isolated_ms_per_step'] > 0 and ar['exposed_ms_per_step'] >= 0
+    assert 'roofline' in out and out['roofline']['frac'] > 0

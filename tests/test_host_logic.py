@@ -367,3 +367,21 @@ def test_winograd_f24_constants_are_exact_and_adjoint():
         for j in range(2):
             gdref[i:i + 4, j:j + 4] += dy[i, j] * g
     assert np.abs(gd - gdref).max() < 1e-12
+
+
+def test_deepcopy_of_global_generator_rebinds_graphed_segments():
+    """a deep-copied GlobalGenerator (EMA copy / snapshot) must run ITS OWN layers in the graphed tail segments and
+    list ITS OWN parameters there, not the original's."""
+    import copy
+    from scene_generation_amd.generators import define_G
+    g = define_G(6, 3, 4, n_downsample_global=2, n_blocks_global=3)
+    g2 = copy.deepcopy(g)
+    own = {id(p) for p in g2.parameters()}
+    orig = {id(p) for p in g.parameters()}
+    assert len(g2._tail) == len(g._tail) and own.isdisjoint(orig)
+    for seg, seg0 in zip(g2._tail, g._tail):
+        assert seg is not seg0 and seg.fn.seq is g2.model and seg0.fn.seq is g.model
+        assert (seg.fn.a, seg.fn.b) == (seg0.fn.a, seg0.fn.b)
+        assert seg.params and all(id(p) in own for p in seg.params)
+        assert all(m2 is not m for m2, m in zip(seg.modules, seg0.modules))
+        assert all(any(m2 is x for x in g2.model) for m2 in seg.modules)
