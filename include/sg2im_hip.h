@@ -256,6 +256,14 @@ int sg_avgpool3s2_bwd(const float* gy, float* gx, int NC, int H, int W, int OH, 
  * y [NC, H/2, W/2]; _bwd routes gy to the first maximum of each window (recomputed from x), zero elsewhere */
 int sg_maxpool2_fwd(const float* x, float* y, int NC, int H, int W, sgStream stream);
 int sg_maxpool2_bwd(const float* x, const float* gy, float* gx, int NC, int H, int W, sgStream stream);
+/* build_cnn's 'P<k>' layers for any window (layers.py:181-189): nn.MaxPool2d(k, k) (avg = 0; _bwd recomputes the first
+ * maximum of each window from x) / nn.AvgPool2d(k, k) (avg = 1; x may be null in _bwd).  y [NC, H/k, W/k] */
+int sg_pool2d_fwd(const float* x, float* y, int NC, int H, int W, int k, int avg, sgStream stream);
+int sg_pool2d_bwd(const float* x, const float* gy, float* gx, int NC, int H, int W, int k, int avg, sgStream stream);
+/* nn.ReplicationPad2d(pad) of ResnetBlock(padding_type='replicate') (layers.py:245-246,258-259) and its adjoint (gp is the
+ * gradient on the padded grid [NC, H+2pad, W+2pad]; deterministic gather, no atomics) */
+int sg_replicate_pad_fwd(const float* x, float* y, int NC, int H, int W, int pad, sgStream stream);
+int sg_replicate_pad_bwd(const float* gp, float* gx, int NC, int H, int W, int pad, sgStream stream);
 int sg_gap_fwd(const float* x, float* y, int NC, int HW, sgStream stream);
 int sg_gap_bwd(const float* gy, float* gx, int NC, int HW, sgStream stream);
 int sg_upsample2_fwd(const float* x, float* y, int NC, int H, int W, sgStream stream);   /* nearest x2 */

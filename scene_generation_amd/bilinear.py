@@ -7,9 +7,12 @@ from . import ops
 
 
 def crop_bbox_batch(feats, bbox, bbox_to_feats, HH, WW=None, backend='cudnn'):
-    """feats (N, C, H, W), bbox (B, 4) in [0,1], bbox_to_feats (B,) int64 -> crops (B, C, HH, WW)."""
-    if backend != 'cudnn':
-        raise NotImplementedError("only the grid_sample ('cudnn') backend is on the training path (bilinear.py:40-41)")
+    """feats (N, C, H, W), bbox (B, 4) in [0,1], bbox_to_feats (B,) int64 -> crops (B, C, HH, WW).
+
+    ``backend``: every value gives the grid_sample crop.  The reference's non-'cudnn' branch (bilinear.py:42-56) loops over the
+    images and calls ``crop_bbox(cur_feats, cur_bbox, HH, WW)`` WITHOUT forwarding ``backend``, i.e. with crop_bbox's default
+    'cudnn': its result is bit-identical to the 'cudnn' branch (checked against the reference in tools/make_golden.py,
+    golden ``crop_jj_batch``).  The ``bilinear_sample`` geometry is only reachable through ``crop_bbox(backend='jj')``."""
     if WW is None:
         WW = HH
     return ops.CropBBoxFn.apply(feats, bbox, bbox_to_feats, int(HH), int(WW))
@@ -18,6 +21,11 @@ def crop_bbox_batch(feats, bbox, bbox_to_feats, HH, WW=None, backend='cudnn'):
 def crop_bbox(feats, bbox, HH, WW=None, backend='cudnn'):
     """feats[i] cropped by bbox[i] (bilinear.py:101-130)."""
     import torch
+    if backend != 'cudnn':
+        # bilinear.py:127-128 (``bilinear_sample``: pixel coordinates X*W without the half-pixel shift, clamped taps): called by
+        # nothing in the reference (crop_bbox_batch never forwards its backend, see above)
+        raise NotImplementedError("crop_bbox(backend=%r): only the grid_sample geometry has a HIP kernel; no caller in the "
+                                  "reference reaches the 'jj' sampler" % (backend,))
     N = feats.size(0)
     assert bbox.size(0) == N and bbox.size(1) == 4
     idx = torch.arange(N, dtype=torch.int64, device=feats.device)

@@ -643,6 +643,80 @@ __global__ void concat_channels_kernel(const float* __restrict__ a, const float*
   out[i] = c < Ca ? a[(n * Ca + c) * HW + p] : b[(n * Cb + (c - Ca)) * HW + p];
 }
 
+
+// nn.MaxPool2d(k, k) / nn.AvgPool2d(k, k) for any window (build_cnn 'P<k>', layers.py:181-189): no padding, floor output size.
+// One thread per output pixel; max follows torch (first maximum in row-major order, NaN wins).
+__global__ void pool2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int H, int W, int OH,
+                                  int OW, int k, int avg) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ow = i % OW;
+  const int oh = (i / OW) % OH;
+  const size_t nc = i / ((size_t)OW * OH);
+  const float* p = x + (nc * H + (size_t)oh * k) * W + (size_t)ow * k;
+  float m = p[0], s = 0.f;
+  for (int a = 0; a < k; ++a)
+    for (int b = 0; b < k; ++b) {
+      const float v = p[(size_t)a * W + b];
+      s += v;
+      if (v > m || v != v) m = v;
+    }
+  y[i] = avg ? s / (float)(k * k) : m;
+}
+// one thread per INPUT pixel: its window's gradient (avg: gy / k^2; max: gy if this pixel is the window's first maximum);
+// pixels in the uncovered tail (H % k, W % k) get zero
+__global__ void pool2d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx, size_t total,
+                                  int H, int W, int OH, int OW, int k, int avg) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int w = i % W;
+  const int h = (i / W) % H;
+  const size_t nc = i / ((size_t)W * H);
+  const int oh = h / k, ow = w / k;
+  if (oh >= OH || ow >= OW) { gx[i] = 0.f; return; }
+  const float g = gy[(nc * OH + oh) * OW + ow];
+  if (avg) { gx[i] = g / (float)(k * k); return; }
+  const float* p = x + (nc * H + (size_t)oh * k) * W + (size_t)ow * k;
+  float m = p[0];
+  int am = 0;
+  for (int a = 0; a < k; ++a)
+    for (int b = 0; b < k; ++b) {
+      const float v = p[(size_t)a * W + b];
+      if ((v > m || v != v) && !(m != m)) { m = v; am = a * k + b; }
+    }
+  gx[i] = am == (h - oh * k) * k + (w - ow * k) ? g : 0.f;
+}
+
+// nn.ReplicationPad2d(p) (ResnetBlock padding_type='replicate', layers.py:245-246,258-259) and its adjoint: every source
+// pixel gathers the padded positions that were copied from it (edge rows / columns collect the pad strip, corners the pad
+// square), in a fixed order -- no atomics
+__global__ void replicate_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int H, int W, int pad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int PW = W + 2 * pad, PH = H + 2 * pad;
+  const int ow = i % PW;
+  const int oh = (i / PW) % PH;
+  const size_t nc = i / ((size_t)PW * PH);
+  const int ih = min(max(oh - pad, 0), H - 1), iw = min(max(ow - pad, 0), W - 1);
+  y[i] = x[nc * H * W + (size_t)ih * W + iw];
+}
+__global__ void replicate_pad_bwd_kernel(const float* __restrict__ gp, float* __restrict__ gx, size_t total, int H, int W, int pad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int w = i % W;
+  const int h = (i / W) % H;
+  const size_t nc = i / ((size_t)W * H);
+  const int PW = W + 2 * pad, PH = H + 2 * pad;
+  const float* g = gp + nc * PH * PW;
+  // padded rows [r0, r1] and columns [c0, c1] that replicate (h, w)
+  const int r0 = h == 0 ? 0 : h + pad, r1 = h == H - 1 ? PH - 1 : h + pad;
+  const int c0 = w == 0 ? 0 : w + pad, c1 = w == W - 1 ? PW - 1 : w + pad;
+  float s = 0.f;
+  for (int r = r0; r <= r1; ++r)
+    for (int c = c0; c <= c1; ++c) s += g[(size_t)r * PW + c];
+  gx[i] = s;
+}
+
 inline dim3 grid1d(size_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
 
 }  // namespace
@@ -832,6 +906,39 @@ extern "C" int sg_reflect_pad_fwd(const float* x, float* y, int NC, int H, int W
   const size_t total = (size_t)NC * (H + 2 * pad) * (W + 2 * pad);
   hipLaunchKernelGGL(reflect_pad_fwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, x, y, total, H, W, pad);
   SG_LAUNCH_CHECK("sg_reflect_pad_fwd");
+  return 0;
+}
+
+extern "C" int sg_pool2d_fwd(const float* x, float* y, int NC, int H, int W, int k, int avg, sgStream stream) {
+  SG_ARG_CHECK(x && y && NC > 0 && k >= 1 && H >= k && W >= k, "sg_pool2d_fwd: bad arguments");
+  const int OH = H / k, OW = W / k;
+  const size_t total = (size_t)NC * OH * OW;
+  hipLaunchKernelGGL(pool2d_fwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, x, y, total, H, W, OH, OW, k, avg);
+  SG_LAUNCH_CHECK("sg_pool2d_fwd");
+  return 0;
+}
+
+extern "C" int sg_pool2d_bwd(const float* x, const float* gy, float* gx, int NC, int H, int W, int k, int avg, sgStream stream) {
+  SG_ARG_CHECK((x || avg) && gy && gx && NC > 0 && k >= 1 && H >= k && W >= k, "sg_pool2d_bwd: bad arguments");
+  const size_t total = (size_t)NC * H * W;
+  hipLaunchKernelGGL(pool2d_bwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, x, gy, gx, total, H, W, H / k, W / k, k, avg);
+  SG_LAUNCH_CHECK("sg_pool2d_bwd");
+  return 0;
+}
+
+extern "C" int sg_replicate_pad_fwd(const float* x, float* y, int NC, int H, int W, int pad, sgStream stream) {
+  SG_ARG_CHECK(x && y && NC > 0 && H > 0 && W > 0 && pad >= 0, "sg_replicate_pad_fwd: bad arguments");
+  const size_t total = (size_t)NC * (H + 2 * pad) * (W + 2 * pad);
+  hipLaunchKernelGGL(replicate_pad_fwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, x, y, total, H, W, pad);
+  SG_LAUNCH_CHECK("sg_replicate_pad_fwd");
+  return 0;
+}
+
+extern "C" int sg_replicate_pad_bwd(const float* gp, float* gx, int NC, int H, int W, int pad, sgStream stream) {
+  SG_ARG_CHECK(gp && gx && NC > 0 && H > 0 && W > 0 && pad >= 0, "sg_replicate_pad_bwd: bad arguments");
+  const size_t total = (size_t)NC * H * W;
+  hipLaunchKernelGGL(replicate_pad_bwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, gp, gx, total, H, W, pad);
+  SG_LAUNCH_CHECK("sg_replicate_pad_bwd");
   return 0;
 }
 

@@ -154,15 +154,47 @@ class AvgPool3s2(nn.Module):
 
 
 class MaxPool2d(nn.Module):
-    """nn.MaxPool2d(kernel_size=2, stride=2) -- the only pooling the path uses (VGG19 of VGGLoss; build_cnn 'P2')."""
+    """nn.MaxPool2d(kernel_size=k, stride=k) (VGG19 of VGGLoss; build_cnn 'P<k>' with pooling='max', layers.py:183-184).
+    k = 2 runs the vectorised kernel, any other window the general one."""
 
-    def __init__(self, kernel_size=2, stride=2):
+    def __init__(self, kernel_size=2, stride=None):
         super().__init__()
-        if int(kernel_size) != 2 or int(stride) != 2:
-            raise NotImplementedError('MaxPool2d: only kernel 2 / stride 2 has a HIP kernel')
+        self.kernel_size = _pair_to_int(kernel_size, 'kernel_size')
+        stride = self.kernel_size if stride is None else _pair_to_int(stride, 'stride')
+        if stride != self.kernel_size or self.kernel_size < 1:
+            raise NotImplementedError('MaxPool2d: only stride == kernel_size has a HIP kernel (the only form build_cnn builds)')
 
     def forward(self, x):
-        return ops.maxpool2(x)
+        return ops.maxpool2(x) if self.kernel_size == 2 else ops.pool2d(x, self.kernel_size, avg=False)
+
+    def extra_repr(self):
+        return 'kernel_size=%d, stride=%d' % (self.kernel_size, self.kernel_size)
+
+
+class AvgPool2d(nn.Module):
+    """nn.AvgPool2d(kernel_size=k, stride=k) (build_cnn 'P<k>' with pooling='avg', layers.py:185-186)."""
+
+    def __init__(self, kernel_size=2, stride=None):
+        super().__init__()
+        self.kernel_size = _pair_to_int(kernel_size, 'kernel_size')
+        stride = self.kernel_size if stride is None else _pair_to_int(stride, 'stride')
+        if stride != self.kernel_size or self.kernel_size < 1:
+            raise NotImplementedError('AvgPool2d: only stride == kernel_size has a HIP kernel (the only form build_cnn builds)')
+
+    def forward(self, x):
+        return ops.pool2d(x, self.kernel_size, avg=True)
+
+    def extra_repr(self):
+        return 'kernel_size=%d, stride=%d' % (self.kernel_size, self.kernel_size)
+
+
+class ReplicationPad2d(nn.Module):
+    def __init__(self, padding):
+        super().__init__()
+        self.padding = int(padding)
+
+    def forward(self, x):
+        return ops.replicate_pad(x, self.padding)
 
 
 class Flatten(nn.Module):
@@ -300,10 +332,8 @@ def _get_padding(K, mode):
 
 
 def build_cnn(arch, normalization='batch', activation='relu', padding='same', pooling='max', init='default'):
-    """Architecture-string CNN builder (layers.py:128-212) for the layer kinds the training path uses:
-    IX (input channels), CK-X[-S] (conv), UX (nearest upsample), P2 (max pooling), FC-X-Y.  'R' (the reference's
-    ResidualBlock, which runs its body twice, layers.py:115-116) belongs to model variants the training path never builds
-    and raises."""
+    """Architecture-string CNN builder (layers.py:128-212), every layer kind of the reference: IX (input channels), CK-X[-S]
+    (conv), R (residual block), UX (nearest upsample), PX (max / avg pooling, window = stride = X), FC-X-Y."""
     if isinstance(arch, str):
         arch = arch.split(',')
     cur_C = 3
@@ -330,10 +360,15 @@ def build_cnn(arch, normalization='batch', activation='relu', padding='same', po
             first_conv = False
         elif s[0] == 'U':
             layers.append(Interpolate(scale_factor=int(s[1:]), mode='nearest'))
-        elif s[0] == 'P':                                   # layers.py:181-189: 'P2' = 2x2 pooling, stride 2
-            if int(s[1:]) != 2 or pooling != 'max':
-                raise NotImplementedError('build_cnn pooling "%s" (%s): only max-pool 2 has a HIP kernel' % (s, pooling))
-            layers.append(MaxPool2d(2, 2))
+        elif s[0] == 'P':                                   # layers.py:181-189: k x k pooling, stride k
+            factor = int(s[1:])
+            if pooling == 'max':
+                layers.append(MaxPool2d(kernel_size=factor, stride=factor))
+            elif pooling == 'avg':
+                layers.append(AvgPool2d(kernel_size=factor, stride=factor))
+            else:
+                # (the reference leaves ``pool`` unbound here and dies with UnboundLocalError, layers.py:183-187)
+                raise ValueError('Invalid pooling "%s"' % pooling)
         elif s[:2] == 'FC':                                 # layers.py:190-199: flatten + Linear (+ activation unless last)
             _, Din, Dout = s.split('-')
             if not flat:
@@ -344,7 +379,7 @@ def build_cnn(arch, normalization='batch', activation='relu', padding='same', po
                 layers.append(get_activation(activation))
             cur_C = int(Dout)
         else:
-            raise NotImplementedError('build_cnn layer "%s" is not on the MI355X training path' % s)
+            raise ValueError('Invalid layer "%s"' % s)
     layers = [l for l in layers if l is not None]
     return FusedSequential(*layers), cur_C
 
@@ -367,19 +402,27 @@ def build_mlp(dim_list, activation='relu', batch_norm='none', dropout=0, final_n
 
 
 class ResnetBlock(nn.Module):
-    """x + [ReflectionPad(1), Conv3x3, IN, ReLU, ReflectionPad(1), Conv3x3, IN](x)  (layers.py:234-273).
-    Four launches: two pad-folded implicit GEMMs, IN+ReLU, IN+residual-add."""
+    """x + [pad(1), Conv3x3, norm, act, (Dropout), pad(1), Conv3x3, norm](x)  (layers.py:234-273), padding_type 'reflect'
+    (the generator's, generators.py:79: the pad is folded into the conv's gather), 'replicate' (ReplicationPad2d + conv) or
+    'zero' (Conv2d(padding=1), no pad modules -- the module indices and hence the state_dict keys follow the reference in all
+    three).  Reflect form: four launches -- two pad-folded implicit GEMMs, IN+ReLU, IN+residual-add."""
 
     def __init__(self, dim, padding_type, norm_layer, activation=None, use_dropout=False):
         super().__init__()
-        if padding_type != 'reflect':
-            raise NotImplementedError('ResnetBlock: only reflect padding is used (generators.py:79)')
         activation = ReLU(True) if activation is None else activation
-        first = [ReflectionPad2d(1), Conv2d(dim, dim, kernel_size=3, padding=0), norm_layer(dim), activation]
+
+        def conv():
+            if padding_type == 'reflect':
+                return [ReflectionPad2d(1), Conv2d(dim, dim, kernel_size=3, padding=0)]
+            if padding_type == 'replicate':
+                return [ReplicationPad2d(1), Conv2d(dim, dim, kernel_size=3, padding=0)]
+            if padding_type == 'zero':
+                return [Conv2d(dim, dim, kernel_size=3, padding=1)]
+            raise NotImplementedError('padding [%s] is not implemented' % padding_type)      # layers.py:250
+        first = conv() + [norm_layer(dim), activation]
         if use_dropout:                                     # layers.py:256-257 (pix2pixHD option, off in generators.py:79)
             first.append(Dropout(0.5))
-        self.conv_block = FusedSequential(*first, ReflectionPad2d(1), Conv2d(dim, dim, kernel_size=3, padding=0),
-                                          norm_layer(dim))
+        self.conv_block = FusedSequential(*first, *conv(), norm_layer(dim))
 
     def forward(self, x):
         return self.conv_block(x, skip=x)

@@ -912,6 +912,59 @@ def maxpool2(x):
     return MaxPool2Fn.apply(x)
 
 
+class Pool2dFn(Function):
+    """nn.MaxPool2d(k, k) / nn.AvgPool2d(k, k) for any window k (build_cnn 'P<k>', layers.py:181-189)."""
+
+    @staticmethod
+    def forward(ctx, x, k, avg):
+        x = _f32(x)
+        N, C, H, W = x.shape
+        y = torch.empty(N, C, H // k, W // k, dtype=torch.float32, device=x.device)
+        _call('sg_pool2d_fwd', _p(x), _p(y), N * C, H, W, k, 1 if avg else 0, _stream())
+        ctx.k, ctx.avg, ctx.shape = k, avg, (N, C, H, W)
+        ctx.save_for_backward(*(() if avg else (x,)))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        N, C, H, W = ctx.shape
+        gy = _f32(gy)
+        gx = torch.empty(N, C, H, W, dtype=torch.float32, device=gy.device)
+        x = None if ctx.avg else ctx.saved_tensors[0]
+        _call('sg_pool2d_bwd', _p(x) if x is not None else None, _p(gy), _p(gx), N * C, H, W, ctx.k, 1 if ctx.avg else 0, _stream())
+        return gx, None, None
+
+
+def pool2d(x, k, avg=False):
+    return Pool2dFn.apply(x, int(k), bool(avg))
+
+
+class ReplicatePadFn(Function):
+    """nn.ReplicationPad2d(pad) (ResnetBlock padding_type='replicate', layers.py:245-246)."""
+
+    @staticmethod
+    def forward(ctx, x, pad):
+        x = _f32(x)
+        N, C, H, W = x.shape
+        y = torch.empty(N, C, H + 2 * pad, W + 2 * pad, dtype=torch.float32, device=x.device)
+        _call('sg_replicate_pad_fwd', _p(x), _p(y), N * C, H, W, pad, _stream())
+        ctx.pad = pad
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = _f32(gy)
+        p = ctx.pad
+        N, C, PH, PW = gy.shape
+        gx = torch.empty(N, C, PH - 2 * p, PW - 2 * p, dtype=torch.float32, device=gy.device)
+        _call('sg_replicate_pad_bwd', _p(gy), _p(gx), N * C, PH - 2 * p, PW - 2 * p, p, _stream())
+        return gx, None
+
+
+def replicate_pad(x, pad):
+    return ReplicatePadFn.apply(x, int(pad))
+
+
 class GapFn(Function):
     """GlobalAvgPool (layers.py:82-85)."""
 

@@ -631,12 +631,15 @@ def test_model_inference_forward_golden(hip, golden):
         close(out[0], g[tag + '_imgs_pred'], 1e-4, tag + ' imgs')
 
 
-@pytest.mark.parametrize('case', ['sorted_8', 'perm_8', 'perm_32'])
+@pytest.mark.parametrize('case', ['sorted_8', 'perm_8', 'perm_32', 'jj_batch'])
 def test_crop_golden(hip, golden, case):
     from scene_generation_amd.bilinear import crop_bbox_batch
     g = golden('crop_' + case)
     feats = torch.from_numpy(g['feats']).to(DEV).requires_grad_()
-    out = crop_bbox_batch(feats, torch.from_numpy(g['boxes']).to(DEV), torch.from_numpy(g['idx']).to(DEV), int(g['HH']))
+    WW = int(g['WW']) if 'WW' in g.files else None
+    # 'jj_batch': crop_bbox_batch(backend='jj') of the reference (bilinear.py:42-56) = the grid_sample crop, rectangular here
+    out = crop_bbox_batch(feats, torch.from_numpy(g['boxes']).to(DEV), torch.from_numpy(g['idx']).to(DEV), int(g['HH']), WW,
+                          backend='jj' if case == 'jj_batch' else 'cudnn')
     close(out, g['out'], 1e-5, 'crop')
     (out * torch.from_numpy(g['w']).to(DEV)).sum().backward()
     close(feats.grad, g['g_feats'], 1e-4, 'g_feats')
@@ -1106,6 +1109,82 @@ def test_fast_paths_agree_with_plain_paths(hip):
 # ------------------------------------------------------------------------------------------
 # round 2: pooling for VGG, loss variants, gradient sinks, deterministic crops, drop-in loop
 # ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('shape,k,avg', [((2, 3, 9, 12), 3, False), ((2, 3, 9, 12), 3, True), ((1, 4, 8, 8), 4, True),
+                                         ((3, 2, 7, 10), 2, True), ((2, 5, 6, 6), 1, False), ((2, 2, 11, 13), 5, False)])
+def test_pool2d_general_windows(hip, shape, k, avg):
+    """build_cnn 'P<k>' (layers.py:181-189): nn.MaxPool2d(k, k) / nn.AvgPool2d(k, k), forward and backward vs torch CPU (exact:
+    a max copies, the average divides one fp32 sum)."""
+    x = det(shape, 931 + k, 2.0)
+    w = det((shape[0], shape[1], shape[2] // k, shape[3] // k), 932 + k, 1.0)
+    xr = x.clone().requires_grad_()
+    yr = (F.avg_pool2d if avg else F.max_pool2d)(xr, k, k)
+    (yr * w).sum().backward()
+    xh = x.to(DEV).requires_grad_()
+    yh = hip.pool2d(xh, k, avg=avg)
+    (yh * w.to(DEV)).sum().backward()
+    close(yh, yr, 1e-6, 'pool2d fwd')
+    close(xh.grad, xr.grad, 1e-6, 'pool2d bwd')
+
+
+@pytest.mark.parametrize('padding_type,dropout', [('zero', False), ('replicate', False), ('reflect', False), ('replicate', True)])
+def test_resnet_block_padding_types(hip, padding_type, dropout):
+    """ResnetBlock with every padding_type of the reference (layers.py:234-273): same state_dict keys as the reference module
+    (the pad modules shift the indices), outputs and gradients vs the oracle's torch modules."""
+    from scene_generation_amd.layers import ResnetBlock, get_norm_layer
+    dim = 16
+    m = ResnetBlock(dim, padding_type, get_norm_layer('instance'), use_dropout=dropout)
+    fill_deterministic(m)
+    pad = {'zero': [], 'replicate': [nn.ReplicationPad2d(1)], 'reflect': [nn.ReflectionPad2d(1)]}[padding_type]
+    p = 1 if padding_type == 'zero' else 0
+    ref_block = nn.Sequential(*pad, nn.Conv2d(dim, dim, 3, padding=p), nn.InstanceNorm2d(dim), nn.ReLU(),
+                              *([nn.Dropout(0.5)] if dropout else []),
+                              *[type(q)(1) for q in pad], nn.Conv2d(dim, dim, 3, padding=p), nn.InstanceNorm2d(dim))
+    assert sorted(m.conv_block.state_dict()) == sorted(ref_block.state_dict())
+    ref_block.load_state_dict(m.conv_block.state_dict())
+    m = m.to(DEV).eval()                 # eval: the dropout of the pix2pixHD option is the identity (its mask has no pin)
+    ref_block.eval()
+    x = det((2, dim, 9, 7), 941, 2.0)
+    w = det((2, dim, 9, 7), 942, 1.0)
+    xr = x.clone().requires_grad_()
+    yr = xr + ref_block(xr)
+    (yr * w).sum().backward()
+    xh = x.to(DEV).requires_grad_()
+    yh = m(xh)
+    (yh * w.to(DEV)).sum().backward()
+    close(yh, yr, 3e-5, 'ResnetBlock(%s) out' % padding_type)
+    close(xh.grad, xr.grad, 1e-4, 'ResnetBlock(%s) gx' % padding_type)
+    for (n, a), (_, b) in zip(m.conv_block.named_parameters(), ref_block.named_parameters()):
+        close(a.grad, b.grad, 1e-4, 'ResnetBlock(%s) g %s' % (padding_type, n))
+
+
+def test_replicate_pad_adjoint(hip):
+    """sg_replicate_pad_fwd / _bwd vs F.pad(mode='replicate') incl. pad 2 on a 3x4 map and pad >= size on a 1x1 map"""
+    for shape, pad in (((2, 3, 5, 6), 1), ((1, 2, 3, 4), 2), ((2, 1, 1, 1), 3)):
+        x = det(shape, 951 + pad, 1.0)
+        w = det((shape[0], shape[1], shape[2] + 2 * pad, shape[3] + 2 * pad), 952 + pad, 1.0)
+        xr = x.clone().requires_grad_()
+        yr = F.pad(xr, (pad,) * 4, mode='replicate')
+        (yr * w).sum().backward()
+        xh = x.to(DEV).requires_grad_()
+        yh = hip.replicate_pad(xh, pad)
+        (yh * w.to(DEV)).sum().backward()
+        assert torch.equal(yh.cpu(), yr)
+        close(xh.grad, xr.grad, 1e-6, 'replicate pad bwd')
+
+
+def test_build_cnn_pooling_layers(hip):
+    """build_cnn with 'P3' max pooling and 'P2' average pooling (layers.py:181-189) against the oracle's build_cnn."""
+    from scene_generation_amd.layers import build_cnn
+    for arch, pooling in (('I4,C3-8,P3,C3-8', 'max'), ('I4,C3-8,P2,C3-8,P2', 'avg')):
+        m, c = build_cnn(arch, normalization='batch', activation='leakyrelu-0.2', pooling=pooling)
+        r, c2 = O.build_cnn(arch, normalization='batch', activation='leakyrelu-0.2', pooling=pooling)
+        assert c == c2 == 8 and sorted(m.state_dict()) == sorted(r.state_dict())
+        fill_deterministic(m)
+        r.load_state_dict(m.state_dict())
+        x = det((3, 4, 12, 12), 961, 2.0)
+        close(m.to(DEV)(x.to(DEV)), r(x), 3e-5, 'build_cnn %s' % arch)
+
+
 @pytest.mark.parametrize('shape', [(3, 5, 8, 12), (2, 4, 7, 9), (1, 2, 2, 2), (2, 64, 32, 32)])
 def test_maxpool2(hip, shape):
     x = det(shape, 301)

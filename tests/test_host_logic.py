@@ -385,3 +385,34 @@ def test_deepcopy_of_global_generator_rebinds_graphed_segments():
         assert seg.params and all(id(p) in own for p in seg.params)
         assert all(m2 is not m for m2, m in zip(seg.modules, seg0.modules))
         assert all(any(m2 is x for x in g2.model) for m2 in seg.modules)
+
+
+def test_build_cnn_and_resnet_block_cover_every_reference_variant():
+    """Surface the reference builds (layers.py:181-189,243-262) that raised NotImplementedError before round 4: 'P<k>' pooling
+    of either kind and the 'zero' / 'replicate' ResnetBlock paddings -- module structure and state_dict keys (the numerics run
+    on the GPU: tests/test_gpu_parity.py)."""
+    import torch.nn as nn
+    from scene_generation_amd.layers import (build_cnn, ResnetBlock, get_norm_layer, MaxPool2d, AvgPool2d, ReplicationPad2d,
+                                            ReflectionPad2d)
+    m, c = build_cnn('I5,C3-8,P3,C3-16,P2', pooling='avg')
+    assert c == 16 and [type(x) for x in m if isinstance(x, (MaxPool2d, AvgPool2d))] == [AvgPool2d, AvgPool2d]
+    assert [x.kernel_size for x in m if isinstance(x, AvgPool2d)] == [3, 2]
+    m, _ = build_cnn('C3-8,P4', pooling='max')
+    assert isinstance(m[-1], MaxPool2d) and m[-1].kernel_size == 4
+    with pytest.raises(ValueError):
+        build_cnn('C3-8,P2', pooling='median')
+    with pytest.raises(ValueError):
+        build_cnn('C3-8,X2')
+    norm = get_norm_layer('instance')
+    keys = {}
+    for pt in ('reflect', 'replicate', 'zero'):
+        b = ResnetBlock(8, pt, norm)
+        keys[pt] = sorted(b.state_dict())
+    assert keys['reflect'] == keys['replicate'] == ['conv_block.1.bias', 'conv_block.1.weight', 'conv_block.5.bias',
+                                                     'conv_block.5.weight']
+    assert keys['zero'] == ['conv_block.0.bias', 'conv_block.0.weight', 'conv_block.3.bias', 'conv_block.3.weight']
+    assert isinstance(ResnetBlock(8, 'replicate', norm).conv_block[0], ReplicationPad2d)
+    assert isinstance(ResnetBlock(8, 'reflect', norm).conv_block[0], ReflectionPad2d)
+    assert ResnetBlock(8, 'zero', norm).conv_block[0].padding == (1, 1)
+    with pytest.raises(NotImplementedError):
+        ResnetBlock(8, 'circular', norm)

@@ -78,11 +78,13 @@ def test_masks_to_layout_rejects_gaps():
                           torch.tensor([0, 2]), 8)
 
 
-@pytest.mark.parametrize('case', ['sorted_8', 'perm_8', 'perm_32'])
+@pytest.mark.parametrize('case', ['sorted_8', 'perm_8', 'perm_32', 'jj_batch'])
 def test_crop_vs_reference(golden, case):
     g = golden('crop_' + case)
     feats = T(g['feats']).requires_grad_()
-    out = O.crop_bbox_batch(feats, T(g['boxes']), T(g['idx']), int(g['HH']))
+    WW = int(g['WW']) if 'WW' in g.files else None
+    # 'jj_batch': the reference's backend='jj' batch branch (bilinear.py:42-56) -- equal to 'cudnn', it never forwards the backend
+    out = O.crop_bbox_batch(feats, T(g['boxes']), T(g['idx']), int(g['HH']), WW, backend='jj' if case == 'jj_batch' else 'cudnn')
     close(out, g['out'], 1e-5, 'crop')
     (out * T(g['w'])).sum().backward()
     close(feats.grad, g['g_feats'], 1e-4, 'g_feats')

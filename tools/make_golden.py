@@ -200,6 +200,14 @@ def golden_crop():
         w = probe_weight(out.shape, 32)
         gf, = grads_of((out * w).sum(), [feats])
         npz('crop_' + name, feats=feats, boxes=boxes, idx=idx_t, out=out, w=w, g_feats=gf, HH=HH)
+    # the reference's non-'cudnn' batch branch (bilinear.py:42-56: per-image loop into a zero tensor; crop_bbox is called without
+    # the backend, i.e. with grid_sample) on the permuted boxes above, rectangular crops
+    out = crop_bbox_batch(feats, boxes, idx_t, 8, 12, backend='jj')
+    same = crop_bbox_batch(feats, boxes, idx_t, 8, 12, backend='cudnn')
+    assert torch.equal(out, same), "reference: backend='jj' of crop_bbox_batch is expected to equal 'cudnn'"
+    w = probe_weight(out.shape, 33)
+    gf, = grads_of((out * w).sum(), [feats])
+    npz('crop_jj_batch', feats=feats, boxes=boxes, idx=idx_t, out=out, w=w, g_feats=gf, HH=8, WW=12)
 
 
 def run_module(name, mod, inputs, extra=None, train=True):
