@@ -14,7 +14,8 @@
  *   - `stream` is a hipStream_t passed as void*; every launch goes to that stream, in order
  *   - return 0 = OK; <0 = argument error detected before launch; >0 = hipError_t from the launch
  *     sg_last_error_string() describes the last non-zero return on the calling thread
- *   - thread-safe for distinct streams (the only global state is the opt-in profiler, see sg_prof_*)
+ *   - thread-safe for distinct streams.  Global state, all of it: the opt-in profiler (sg_prof_*), the shape-table cache
+ *     (sg_plan_cache_*: mutex-guarded) and the option table (sg_set_option: atomic ints, initialised once at load time)
  */
 #ifndef SG2IM_HIP_H
 #define SG2IM_HIP_H
@@ -39,6 +40,16 @@ enum { SG_LOSS_MSE_CONST = 0, SG_LOSS_MSE = 1, SG_LOSS_L1 = 2, SG_LOSS_BCE_LOGIT
 
 int sg_version(void);
 const char* sg_last_error_string(void);
+/* Tuning / debugging switches (which kernel variant or threshold a launch plan uses; results stay within the tolerances of
+ * the parity suite for every setting).  Each switch has a compiled-in default and is initialised ONCE, when the library is
+ * loaded, from the environment variable SG_<NAME> (upper case) if that is set; afterwards the library never reads the
+ * environment.  sg_set_option stores atomically: launches planned after the call see the new value.  Names:
+ * sg_option_name(0 .. sg_num_options()-1).  Returns -1 for an unknown name. */
+int sg_num_options(void);
+const char* sg_option_name(int index);
+int sg_option_default(int index);
+int sg_get_option(const char* name, int* value);
+int sg_set_option(const char* name, int value);
 /* device bytes held by the shape-table cache; drop it (synchronises the tables' build events) */
 size_t sg_plan_cache_bytes(void);
 int sg_plan_cache_clear(void);

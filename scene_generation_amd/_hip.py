@@ -105,3 +105,26 @@ def last_error():
 def check(rc, name):
     if rc != 0:
         raise RuntimeError('%s failed (rc=%d): %s' % (name, rc, last_error()))
+
+
+# ---- tuning / debugging switches of the library (include/sg2im_hip.h: sg_set_option) --------------------------------
+def set_option(name, value):
+    """Change a launch-plan switch of the library at run time (they are otherwise fixed when the library is loaded: compiled-in
+    default, or the environment variable SG_<NAME>)."""
+    check(lib().sg_set_option(name.encode(), int(value)), 'sg_set_option')
+
+
+def get_option(name):
+    v = ctypes.c_int(0)
+    check(lib().sg_get_option(name.encode(), ctypes.cast(ctypes.pointer(v), ctypes.c_void_p)), 'sg_get_option')
+    return v.value
+
+
+def options():
+    """{name: (current value, compiled-in default)} of every switch"""
+    L = lib()
+    out = {}
+    for i in range(L.sg_num_options()):
+        name = L.sg_option_name(i).decode()
+        out[name] = (get_option(name), L.sg_option_default(i))
+    return out

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "../../include/sg2im_hip.h"
 
 #define SG_WAVE 64
@@ -25,6 +26,37 @@ void sg_set_error(const char* fmt, ...);
       return (int)e__;                                                      \
     }                                                                       \
   } while (0)
+
+// ---- tuning / debugging switches (include/sg2im_hip.h: sg_set_option) -------------------------------------------
+// One table (runtime.hip), initialised ONCE when the library is loaded: compiled-in default, overridden by the environment
+// variable SG_<NAME> if set.  After that the library never reads the environment; sg_set_option() stores atomically.  (Until
+// round 4 every switch was an environment lookup cached in an unsynchronised function-local static: a data race on first use from two
+// threads, and state the header did not admit to.)
+enum SgOpt {
+  SG_OPT_TILE,            // force the tile of the gather GEMMs: 0 128x128, 1 64x64, 2 32x128, 3 64x128; -1 = chosen per shape
+  SG_OPT_T128_MIN,        // 128x128 tiles from this many tiles on
+  SG_OPT_TILE3,           // allow 64x128 tiles
+  SG_OPT_TILE3_MIN,       // ... from this many tiles on
+  SG_OPT_SPLITS,          // force the split-K count of the conv-shaped GEMMs; -1 = chosen per shape
+  SG_OPT_FIXEDTAP,        // LoadFixedKN loaders (taps in VGPRs, channel offset in the SGPR operand)
+  SG_OPT_WINO_WT,         // LDS-staged Winograd filter transform (0: one thread per filter)
+  SG_OPT_W24_SMALL,       // LDS-staged F(2x2,4x4) input transform
+  SG_OPT_W24_S,           // force the k-chunk count of the F(2x2,4x4) weight gradient; -1 = chosen per shape
+  SG_OPT_W24_PMIN,        // fewest tiles for which F(2x2,4x4) is used
+  SG_OPT_WINO_ADJOINT,    // adjoint-form data gradient of the reflection-padded Winograd convs
+  SG_OPT_WINO24,          // F(2x2,4x4) for the stride-1 4x4 convs
+  SG_OPT_LINEAR_NSUB,     // k-tile depth (x16) of the LDS-tiled dense layers
+  SG_OPT_LINEAR_SKINNY,   // dense layers with at most this many 32x32 output tiles run the register-streaming kernel (skinny.hip)
+  SG_OPT_WGRAD_ROWSUM,    // bias gradient from the weight-gradient GEMM's A loader
+  SG_OPT_LAYOUT_REG,      // register-resident masks_to_layout forward
+  SG_OPT_LAYOUT_DSPLIT,   // channel chunks per masks_to_layout tile
+  SG_OPT_BN_BLOCKS,       // workgroups per BatchNorm statistics launch
+  SG_OPT_INSTNORM_REG,    // register-resident InstanceNorm
+  SG_OPT_COUNT
+};
+extern std::atomic<int> g_sg_opt[SG_OPT_COUNT];
+static inline int sg_opt(int id) { return g_sg_opt[id].load(std::memory_order_relaxed); }
+extern FILE* g_sg_launch_log;      // SG_LAUNCH_LOG=<file> at load time: one line per GEMM launch (tools/pmc_db_summary.py)
 
 // ---- profiler kinds (bench.py roofline leg) -------------------------------------------------
 // ids 0..47: one per igemm instantiation family: (gather family f, kernel size index k, tile t) -> f*16 + k*4 + t

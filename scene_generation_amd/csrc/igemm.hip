@@ -540,9 +540,7 @@ __global__ void __launch_bounds__(256) wino_weight_lds_kernel(const float* __res
 // one entry for the three call sites (SG_WINO_WT=0 keeps the per-thread kernel).  ``UT``: see wino_weight_lds_kernel; returns
 // whether it was written
 inline bool wino_weight(const float* w, float* U, int R, int Cc, int flip, hipStream_t s, float* UT = nullptr) {
-  static int lds = -1;
-  if (lds < 0) { const char* e = getenv("SG_WINO_WT"); lds = e ? atoi(e) : 1; }
-  if (lds && R % 32 == 0 && Cc % 32 == 0 && aligned16(w)) {
+  if (sg_opt(SG_OPT_WINO_WT) && R % 32 == 0 && Cc % 32 == 0 && aligned16(w)) {
     hipLaunchKernelGGL(wino_weight_lds_kernel, dim3((R / 32) * (Cc / 32)), dim3(256), 0, s, w, U, R, Cc, flip,
                        flip == 0 ? UT : nullptr);
     return flip == 0 && UT != nullptr;
@@ -763,29 +761,10 @@ void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, in
   t_batch = BatchInfo{}; t_batch.cols_per_batch = cols; t_batch.nbatch = NB; t_batch.a_stride = M * K; t_batch.batch_major = 1;
   {
     SgProfScope prof(NB == 16 ? SG_K_WINO_GEMM_128 : SG_K_WINO24_GEMM, s, flops, 0);
-    static int wt = -1;
-    if (wt < 0) { const char* e = getenv("SG_WINO_TILE"); wt = e ? atoi(e) : 0; }
-    if (wt == 1)
-      launch_cfg<CfgD128x64>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<64, true, false>{B, K, NB * cols}, ep, M,
-                             NB * cols, K, 1, s);
-    else if (wt == 2)
-      launch_cfg<Cfg128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols}, ep, M,
-                         NB * cols, K, 1, s);
-    else if (wt == 3)       // the plain loop (before the software-pipelined form)
-      launch_cfg<CfgD128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols}, ep, M,
-                          NB * cols, K, 1, s);
-    else if (wt == 6)       // pipelined, 16-deep k-tiles (40 KB of LDS: three workgroups per CU): measured 0.763 vs 0.775 of peak
-      launch_cfg<TileCfg<128, 128, 2, 1, 1>>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
-                                             EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
-    else if (wt == 5)       // the plain loop with the unconditional epilogue
-      launch_cfg<CfgD128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
-                          EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
-    else if (wt == 4)       // pipelined loop, general epilogue
-      launch_cfg<CfgDP128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols}, ep, M,
-                           NB * cols, K, 1, s);
-    else
-      launch_cfg<CfgDP128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
-                           EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
+    // 128x128 tiles, 32-deep k-tiles, software-pipelined fragment reads, unconditional epilogue (the variants this replaced --
+    // 128x64 tiles, 16-deep tiles, the plain loop, the general epilogue -- measured 1.5..9 % slower: profiles/r03_sweep_tiles.txt)
+    launch_cfg<CfgDP128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
+                         EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
   }
   t_batch = BatchInfo{};
 }
@@ -951,9 +930,7 @@ __global__ void __launch_bounds__(256) w24_input_small_kernel(const float* __res
 void w24_input_pc(const float* x, float* V, int N, int C, int H, int W, int TH, int TW, int off, size_t Pstride, hipStream_t s) {
   const int HW = H * W;
   SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)N * C * HW + 25.0 * (double)Pstride * C));
-  static int small = -1;
-  if (small < 0) { const char* e = getenv("SG_W24_SMALL"); small = e ? atoi(e) : 1; }
-  if (small && HW >= 144 && W <= 64 && C % 64 == 0) {
+  if (sg_opt(SG_OPT_W24_SMALL) && HW >= 144 && W <= 64 && C % 64 == 0) {
     // tile rows per workgroup: as few as keep ~2048 workgroups busy (each stages 2*rows + 3 input rows of 64 planes: <= ~24 KB)
     int rows_per = (int)(((long)(C / 64) * N * TH + 2047) / 2048);
     if (rows_per < 1) rows_per = 1;
@@ -1114,7 +1091,7 @@ bool w24_plan(const sgConvDesc* d, W24Plan* pl) {
   // channels, 2592 tiles: S = 2 -> 0.251 ms, 3 -> 0.261, 4 -> 0.276, 6 -> 0.277: longer k-loops beat more workgroups)
   const long t = 25L * (d->Cout / 128) * (d->C1 / 128);
   int S = (int)((400 + t - 1) / t);
-  { static int fs = -2; if (fs == -2) { const char* e = getenv("SG_W24_S"); fs = e ? atoi(e) : -1; } if (fs > 0) S = fs; }   // tuning aid
+  if (sg_opt(SG_OPT_W24_S) > 0) S = sg_opt(SG_OPT_W24_S);   // tuning aid
   const int maxS = (int)(p.P / 256) > 0 ? (int)(p.P / 256) : 1;
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
@@ -1125,9 +1102,7 @@ bool w24_plan(const sgConvDesc* d, W24Plan* pl) {
   if (!(25.0 * pm * cm < 2147483647.0 && 25.0 * (double)d->C1 * d->Cout < 2147483647.0)) return false;
   // the transforms move 25/4 x the activation bytes and the GEMMs need >= 2 column tiles: measured at 256 -> 512 channels, the
   // 6x6 maps of the third PatchGAN scale (288 tiles) still gain (forward 0.094 -> 0.064 ms, weight gradient 0.084 -> 0.062)
-  static int pmin = -1;
-  if (pmin < 0) { const char* e = getenv("SG_W24_PMIN"); pmin = e ? atoi(e) : 256; }
-  if (p.P < (size_t)pmin) return false;
+  if (p.P < (size_t)sg_opt(SG_OPT_W24_PMIN)) return false;
   if (pl) *pl = p;
   return true;
 }
@@ -1155,9 +1130,7 @@ extern "C" size_t sg_conv2d_wino_ws_bytes(const sgConvDesc* d) {
 // direct folded form.  Zero padding: the same correlation straight on the H x W grid (2.25x fewer MACs); behind a folded x2
 // upsample the result is on the upsampled grid and is summed back 2x2.
 static bool wino_adjoint_shape(const sgConvDesc* d) {
-  static int adj = -1;
-  if (adj < 0) { const char* e = getenv("SG_WINO_ADJOINT"); adj = e ? atoi(e) : 1; }
-  return adj && wino_ok(d) && d->pad_reflect && d->upsample == 1 && d->H * d->W <= 256 && (d->H * d->W) % 4 == 0 &&
+  return sg_opt(SG_OPT_WINO_ADJOINT) && wino_ok(d) && d->pad_reflect && d->upsample == 1 && d->H * d->W <= 256 && (d->H * d->W) % 4 == 0 &&
          d->C1 % 64 == 0 && d->Cout % 64 == 0;
 }
 // floats of the transposed filter transform sg_conv2d_wino_fwd can hand to sg_conv2d_wino_dgrad (0: that conv's data gradient
@@ -1264,9 +1237,7 @@ extern "C" int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const 
 
 // ---- Winograd F(2x2, 4x4): see w24_* above ----------------------------------------------------------------------------------
 extern "C" int sg_conv2d_wino24_supported(const sgConvDesc* d) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("SG_WINO24"); on = e ? atoi(e) : 1; }
-  return (on && w24_plan(d, nullptr)) ? 1 : 0;
+  return (sg_opt(SG_OPT_WINO24) && w24_plan(d, nullptr)) ? 1 : 0;
 }
 extern "C" size_t sg_conv2d_wino24_ws_bytes(const sgConvDesc* d) {
   W24Plan p;
@@ -1415,8 +1386,7 @@ int run_dense(const A64& a64, const B64& b64, const A32& a32, const B128& b128, 
               int K, hipStream_t s) {
   // these GEMMs are a chain of K/16 dependent load -> LDS -> MFMA rounds on a grid that does not even fill the chip
   // (graph-conv MLPs: ~150 workgroups): 32-deep k-tiles halve the number of rounds.  SG_LINEAR_NSUB=1 restores depth 16.
-  static int deep = -1;
-  if (deep < 0) { const char* e = getenv("SG_LINEAR_NSUB"); deep = e ? atoi(e) : 2; }
+  const int deep = sg_opt(SG_OPT_LINEAR_NSUB);
   if (deep == 2 && K >= 64) {
     if (M <= 32) return launch_cfg<TileCfg<32, 128, 1, 2>>(a32, b128, ep, M, N, K, 1, s);
     return launch_cfg<TileCfg<64, 64, 2, 2>>(a64, b64, ep, M, N, K, 1, s);
@@ -1435,7 +1405,9 @@ extern "C" int sg_linear_fwd(const float* x, const float* w, const float* b, flo
   EpRowMajor ep{y, b, rows, out_f, out_f, act, slope, 0};
   const bool vec = (in_f % 4 == 0) && aligned16(x) && aligned16(w);
   SgProfScope prof(SG_K_LINEAR, s, 2.0 * rows * (double)in_f * out_f, 0);
-  if (vec)
+  if (sgk::skinny_shape(rows, out_f))          // small layer: latency-bound, register-streaming kernel (skinny.hip)
+    sgk::skinny_gemm(x, in_f, 1, w, in_f, 1, y, b, nullptr, rows, out_f, in_f, act, slope, s);
+  else if (vec)
     run_dense(LoadKContig<64, true>{x, in_f, rows}, LoadKContig<64, true>{w, in_f, out_f},
               LoadKContig<32, true>{x, in_f, rows}, LoadKContig<128, true>{w, in_f, out_f}, ep, rows, out_f, in_f, s);
   else
@@ -1454,7 +1426,9 @@ extern "C" int sg_linear_bwd_data(const float* gy, const float* w, float* gx, in
   EpRowMajor ep{gx, nullptr, rows, in_f, in_f, SG_ACT_NONE, 0.f, 0};
   const bool vec = (out_f % 4 == 0) && aligned16(gy);
   SgProfScope prof(SG_K_LINEAR, s, 2.0 * rows * (double)in_f * out_f, 0);
-  if (vec)
+  if (sgk::skinny_shape(rows, in_f))           // gx[rows][in_f] = sum_o gy[row][o] w[o][in_f]: B(n = i, k = o) = w[o*in_f + i]
+    sgk::skinny_gemm(gy, out_f, 1, w, in_f, 0, gx, nullptr, nullptr, rows, in_f, out_f, SG_ACT_NONE, 0.f, s);
+  else if (vec)
     run_dense(LoadKContig<64, true>{gy, out_f, rows}, LoadXContig<64>{w, in_f, in_f}, LoadKContig<32, true>{gy, out_f, rows},
               LoadXContig<128>{w, in_f, in_f}, ep, rows, in_f, out_f, s);
   else
@@ -1473,8 +1447,13 @@ extern "C" int sg_linear_bwd_weight(const float* gy, const float* x, float* gw, 
   EpRowMajor ep{gw, nullptr, out_f, in_f, in_f, SG_ACT_NONE, 0.f, 0};
   {
     SgProfScope prof(SG_K_LINEAR, s, 2.0 * rows * (double)in_f * out_f, 0);
-    run_dense(LoadXContig<64>{gy, out_f, out_f}, LoadXContig<64>{x, in_f, in_f}, LoadXContig<32>{gy, out_f, out_f},
-              LoadXContig<128>{x, in_f, in_f}, ep, out_f, in_f, rows, s);
+    if (sgk::skinny_shape(out_f, in_f)) {      // gw[o][i] = sum_row gy[row][o] x[row][i]: both operands row-index-major;
+      // the bias gradient (column sums of gy = row sums of the A operand) comes out of the same launch
+      sgk::skinny_gemm(gy, out_f, 0, x, in_f, 0, gw, nullptr, gb, out_f, in_f, rows, SG_ACT_NONE, 0.f, s);
+      gb = nullptr;
+    } else
+      run_dense(LoadXContig<64>{gy, out_f, out_f}, LoadXContig<64>{x, in_f, in_f}, LoadXContig<32>{gy, out_f, out_f},
+                LoadXContig<128>{x, in_f, in_f}, ep, out_f, in_f, rows, s);
   }
   SG_LAUNCH_CHECK("sg_linear_bwd_weight");
   if (gb) return sg_channel_sum(gy, gb, rows, out_f, 1, nullptr, 0, stream);   // column sums of gy[rows][out_f]

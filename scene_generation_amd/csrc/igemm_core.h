@@ -59,6 +59,14 @@ int kn_parity_run(int KS, const float* W, int Rdim, int B, int m0, int M, const 
 // allows it; *gb_done says whether it was (else the caller runs sg_channel_sum)
 int nk_run(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, float* out, void* ws, size_t ws_bytes,
            double flops, hipStream_t s, const Sparse* sp, float* gb = nullptr, bool* gb_done = nullptr);
+// register-streaming GEMM for small dense layers (skinny.hip): C[M][N] = act(sum_k A(m,k) B(n,k) + bias[n]);
+// *_kcontig: 1 = elem(x, k) = p[x*ld + k], 0 = elem(x, k) = p[k*ld + x]
+// rowsum (optional): [M] row sums of A over k, written by the workgroups of the first column tile
+int skinny_gemm(const float* a, int lda, int a_kcontig, const float* b, int ldb, int b_kcontig, float* c, const float* bias,
+                float* rowsum, int M, int N, int K, int act, float slope, hipStream_t s);
+inline bool skinny_shape(int M, int N) {
+  return (long)sg_cdiv(M, 32) * sg_cdiv(N, 32) <= (long)sg_opt(SG_OPT_LINEAR_SKINNY);
+}
 }  // namespace sgk
 
 namespace {
@@ -983,8 +991,6 @@ struct BatchInfo {
   // batch_major: tiles are numbered batch-major (all tiles of batch 0, then batch 1, ...), so that with the XCD remap
   // below every XCD works on whole batches and their operands stay in ITS L2 (batched Winograd GEMMs)
   int batch_major;
-  // xcd_splitk: plain split-K launch (grid.z = splits, a multiple of 8, (tiles * splits) % 8 == 0): see the kernel
-  int xcd_splitk;
   ParityClasses par;
 };
 // per-class hooks: loaders / epilogues that can run a parity class overload these; everything else ignores the call
@@ -1047,17 +1053,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     set_class_b(bl, bi.par, c);
     set_class_ep(ep, bi.par, c);
   }
-  int zblk = blockIdx.z;
-  if (bi.xcd_splitk) {
-    // experiment (SG_XCD_SPLITK=1, grid.z a multiple of 8): split-K slabs pinned to XCDs -- workgroups are handed to the 8
-    // XCDs round-robin in linear (z, x) order; re-numbered so that XCD i runs k-chunks i, i+8, ... of every tile.  Measured
-    // neutral (532.9 vs 531.6 images/s, identical conv micro-benchmarks), so it is off by default.
-    const unsigned lin = blockIdx.z * gridDim.x + blockIdx.x, xcd = lin & 7u, idx = lin >> 3;
-    zblk = (int)(xcd + 8u * (idx / gridDim.x));
-    const int t = (int)(idx % gridDim.x);
-    m0 = (t / tiles_n) * BM;
-    n0 = (t % tiles_n) * BN;
-  }
+  const int zblk = blockIdx.z;
   int kbeg = zblk * kchunk;
   int kend = min(K, kbeg + kchunk);
   if (bi.ksplit > 0) {
@@ -1174,8 +1170,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
       mma(fa[(P - 1) & 1], fb[(P - 1) & 1]);
       buf ^= 1;
     }
-    rowsum_finish(al, bi.xcd_splitk ? zblk : (int)blockIdx.z);
-    ep.store(acc, m0 + wm0, n0 + wn0, lane, bi.xcd_splitk ? zblk : (int)blockIdx.z);
+    rowsum_finish(al, zblk);
+    ep.store(acc, m0 + wm0, n0 + wn0, lane, zblk);
     return;
   }
   for (int k0 = kbeg; k0 < kend; k0 += BKT) {
@@ -1226,8 +1222,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     __syncthreads();
     buf ^= 1;
   }
-  rowsum_finish(al, bi.xcd_splitk ? zblk : (int)blockIdx.z);
-  ep.store(acc, m0 + wm0, n0 + wn0, lane, bi.xcd_splitk ? zblk : (int)blockIdx.z);
+  rowsum_finish(al, zblk);
+  ep.store(acc, m0 + wm0, n0 + wn0, lane, zblk);
 }
 
 // tile configurations.  Measured on MI355X (tools/bench_conv.py): these kernels are limited by the vector-memory
@@ -1252,26 +1248,19 @@ using CfgW128 = TileCfg<128, 128, 2, NSW>;
 using CfgW64 = TileCfg<64, 64, 2, NSW>;
 using CfgW32 = TileCfg<32, 128, 1, NSW>;
 using CfgW64W = TileCfg<64, 128, 2, NSW>;
-using CfgD128 = TileCfg<128, 128, 2, 2, 0>;   // dense Winograd GEMMs (plain loop: SG_WINO_TILE=3)
 using CfgDP128 = TileCfg<128, 128, 2, 2, 1>; // ... software-pipelined fragment reads, barrier before the last phase
-using CfgD128x64 = TileCfg<128, 64, 2, 1>;   // experiment (SG_WINO_TILE=1): half-width tiles, 4-5 workgroups per CU
 
 inline int pick_tile(int M, int N) {
-  static int force = -2;
-  if (force == -2) { const char* e = getenv("SG_TILE"); force = e ? atoi(e) : -1; }
-  if (force >= 0) return force;
+  const int force = sg_opt(SG_OPT_TILE);
+  if (force >= 0 && force <= 3) return force;
   if (M <= 32) return 2;
   // measured (tools/bench_conv.py): 128x128 tiles win when M is large (>= 512 rows, split-K fills the chip) or when
   // there are enough of them anyway; 64-row tiles otherwise -- 128 pixels wide (tile 3) while that still leaves >= 3
   // workgroups per CU, else 64x64
   const long t128 = (long)sg_cdiv(M, 128) * sg_cdiv(N, 128);
   const bool low_waste = sg_cdiv(M, 128) * 128 * 20 <= M * 23 && N >= 512;
-  static int t128_min = -1, wide_min = -1;           // thresholds (tuning aids: SG_T128_MIN, SG_TILE3_MIN; SG_TILE3=0 disables 64x128)
-  if (t128_min < 0) { const char* e = getenv("SG_T128_MIN"); t128_min = e ? atoi(e) : 384; }
+  const int t128_min = sg_opt(SG_OPT_T128_MIN), wide_min = sg_opt(SG_OPT_TILE3_MIN), wide = sg_opt(SG_OPT_TILE3);     // tuning aids
   if (M >= 96 && low_waste && (M >= 512 || t128 >= t128_min)) return 0;
-  static int wide = -1;
-  if (wide < 0) { const char* e = getenv("SG_TILE3"); wide = e ? atoi(e) : 1; }
-  if (wide_min < 0) { const char* e = getenv("SG_TILE3_MIN"); wide_min = e ? atoi(e) : 768; }
   if (wide && (long)sg_cdiv(M, 64) * sg_cdiv(N, 128) >= wide_min) return 3;
   return 1;
 }
@@ -1291,14 +1280,8 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
   if (t_fixed_kchunk > 0) kchunk = t_fixed_kchunk;
   dim3 grid(tiles, 1, t_grid_z > 0 ? t_grid_z : ((splits > 1 || t_fixed_kchunk > 0) ? sg_cdiv(K, kchunk) : 1));
   BatchInfo bi = t_batch;
-  static int xs = -1;
-  if (xs < 0) { const char* e = getenv("SG_XCD_SPLITK"); xs = e ? atoi(e) : 0; }     // measured neutral on MI355X: off
-  bi.xcd_splitk = (xs && t_grid_z == 0 && t_fixed_kchunk == 0 && bi.cols_per_batch == 0 && bi.par.ncls == 0 && bi.ksplit == 0 &&
-                   grid.z >= 8 && grid.z % 8 == 0) ? 1 : 0;
   hipLaunchKernelGGL((igemm_kernel<CFG, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, N, K, kchunk, bi);
-  static FILE* lf = nullptr;
-  static int lf_init = 0;
-  if (!lf_init) { lf_init = 1; const char* e = getenv("SG_LAUNCH_LOG"); if (e && *e) lf = fopen(e, "a"); }
+  FILE* lf = g_sg_launch_log;
   if (lf) { fprintf(lf, "%u %u %d %d %d %.0f\n", grid.x * 256u, grid.z, M, N, K, sgk::t_alg_bytes); fflush(lf); }
   return 0;
 }
@@ -1393,9 +1376,7 @@ Gather make_gather(const float* s1, const float* s2, int C1, int C2, int SH, int
 }
 
 inline bool fixed_taps_enabled() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("SG_FIXEDTAP"); on = e ? atoi(e) : 1; }
-  return on != 0;
+  return sg_opt(SG_OPT_FIXEDTAP) != 0;
 }
 
 // ---- conv-shaped GEMM: K = (c, taps), N = pixels -------------------------------------------------
@@ -1427,8 +1408,7 @@ inline int kn_tiles(int M, int Npix) {
                 : (t == 1 ? sg_cdiv(M, 64) * sg_cdiv(Npix, 64) : (t == 3 ? sg_cdiv(M, 64) * sg_cdiv(Npix, 128) : sg_cdiv(Npix, 128)));
 }
 inline int kn_splits(int M, int Npix, int K) {
-  static int force = -2;
-  if (force == -2) { const char* e = getenv("SG_SPLITS"); force = e ? atoi(e) : -1; }
+  const int force = sg_opt(SG_OPT_SPLITS);
   if (force > 0) return force;
   const int tiles = kn_tiles(M, Npix);
   // workgroups wanted in flight: ~6 per CU of the 64x64 / 32x128 kernels, 3 per CU (the register limit) of 128x128
@@ -1532,12 +1512,6 @@ inline NkPlan nk_plan(int M, int C, int KS2, int Kpix, bool two) {
     const double w64 = (double)sg_cdiv(M, 64) * 64 * sg_cdiv(C, 64) * 64;
     if (w128 * 0.7 < w64) p.tile = 0;
   }
-  // opt-in (SG_NK_TILE3=1): 64 rows x 128 columns where the 64x64 tile was chosen and 128-wide channel tiles pad no further
-  // (each wave owns 32x64: two accumulators per fragment read).  Parity-tested; none of the benchmark's 64x64 weight-gradient
-  // launches qualifies (their inputs have 64 channels), so it is not the default.
-  static int nk3 = -1;
-  if (nk3 < 0) { const char* e = getenv("SG_NK_TILE3"); nk3 = e ? atoi(e) : 0; }
-  if (nk3 && p.tile == 1 && p.tap && sg_cdiv(C, 128) * 128 == sg_cdiv(C, 64) * 64) p.tile = 3;
   const int BMt = p.tile == 0 ? 128 : ((p.tile == 1 || p.tile == 3) ? 64 : 32), BNt = p.tile == 1 ? 64 : 128;
   p.cpad = p.tap ? sg_cdiv(C, BNt) * BNt : 0;
   const long tiles = (long)sg_cdiv(M, BMt) * (p.tap ? (long)KS2 * (p.cpad / BNt) : (long)sg_cdiv((long)C * KS2, BNt));
@@ -1546,10 +1520,6 @@ inline NkPlan nk_plan(int M, int C, int KS2, int Kpix, bool two) {
   const int maxs = Kpix / (BK * 8) > 0 ? Kpix / (BK * 8) : 1;
   if (s > maxs) s = maxs;
   if (s > 64) s = 64;
-  // XCD-pinned split-K (SG_XCD_SPLITK, launch_cfg): needs a multiple of 8 k-chunks
-  static int xs8 = -1;
-  if (xs8 < 0) { const char* e = getenv("SG_XCD_SPLITK"); xs8 = e ? atoi(e) : 0; }
-  if (xs8 && s >= 6) { s = (s + 7) / 8 * 8; if (s > maxs) s = maxs / 8 * 8; if (s < 8) s = 8 <= maxs ? 8 : (int)((target + tiles - 1) / tiles); }
   p.splits = s < 1 ? 1 : s;
   return p;
 }

@@ -161,8 +161,7 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
   const int kchunk = sp ? PQ : sg_cdiv(sg_cdiv(Kpix, splits), 64) * 64;      // multiple of every BKT
   splits = sg_cdiv(Kpix, kchunk);
   // bias gradient from the A loader's row sums: tap-major dense launches whose workspace has room for [splits][M] behind the slabs
-  static int fuse_gb = -1;
-  if (fuse_gb < 0) { const char* e = getenv("SG_WGRAD_ROWSUM"); fuse_gb = e ? atoi(e) : 1; }
+  const int fuse_gb = sg_opt(SG_OPT_WGRAD_ROWSUM);
   float* rowsum = nullptr;
   if (fuse_gb && gb && pl.tap && !sp && M == Mtot && ws_bytes >= (mn + (size_t)M) * sizeof(float) * (size_t)splits)
     rowsum = reinterpret_cast<float*>(ws) + mn * (size_t)splits;

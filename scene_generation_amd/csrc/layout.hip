@@ -534,15 +534,12 @@ extern "C" int sg_masks_to_layout_fwd(const float* vecs, const float* boxes, con
   if (cap > max_fit) cap = max_fit;
   const size_t lds_bytes = (size_t)cap * per_obj;
   SgProfScope prof(SG_K_LAYOUT_FWD, s, 0, 4.0 * N * D * (double)H * W + 4.0 * O * D + (masks_i64 ? 8.0 : 4.0) * O * M * M);
-  static int regform = -1;
-  if (regform < 0) { const char* e = getenv("SG_LAYOUT_REG"); regform = e ? atoi(e) : 1; }      // 0: the LDS-staged kernel
+  const int regform = sg_opt(SG_OPT_LAYOUT_REG);      // 0: the LDS-staged kernel
   if (regform && use_vec == 4 && (size_t)D * 12 * sizeof(float) <= 64 * 1024) {
     const int tiles = sg_cdiv(H * W, 1024);
     // channel chunks per tile (grid.z): measured SLOWER on MI355X (4 chunks: 78 vs 69 us averaged over the kind, the whole
     // dense-layout step 47.5 vs 43.5 ms) -- interleaved store streams of different chunks -- so one workgroup writes all D
-    static int dsplit_env = -1;
-    if (dsplit_env < 0) { const char* e = getenv("SG_LAYOUT_DSPLIT"); dsplit_env = e ? atoi(e) : 1; }
-    int dsplit = dsplit_env;
+    int dsplit = sg_opt(SG_OPT_LAYOUT_DSPLIT);
     dsplit = dsplit < 1 ? 1 : (dsplit > 8 ? 8 : dsplit);
     if (dsplit > D / 16) dsplit = D / 16 > 0 ? D / 16 : 1;
     const int dchunk = sg_cdiv(D, dsplit);

@@ -384,8 +384,7 @@ inline int bn_slices(int N, int C, int HW) {
   long cnt = (long)N * HW;
   // ~4096 workgroups per launch: the per-thread loops are chains of dependent loads, so the latency is hidden by running many
   // short slices side by side (1024 workgroups of ~136 elements per thread ran at 0.2 of the HBM peak)
-  static int target = -1;
-  if (target < 0) { const char* e = getenv("SG_BN_BLOCKS"); target = e ? atoi(e) : 4096; }
+  const int target = sg_opt(SG_OPT_BN_BLOCKS) > 0 ? sg_opt(SG_OPT_BN_BLOCKS) : 4096;
   int S = (target + C - 1) / C;
   const long maxS = cnt / 1024 > 0 ? cnt / 1024 : 1;      // at least 1024 elements per slice
   if (S > maxS) S = (int)maxS;
@@ -726,8 +725,7 @@ extern "C" int sg_instnorm_fwd(const float* x, const float* skip, float* y, floa
   SG_ARG_CHECK(x && y && mean && rstd && NC > 0 && HW > 0, "sg_instnorm_fwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   SgProfScope prof(SG_K_INSTNORM, s, 0, (double)NC * HW * 4.0 * (skip ? 3 : 2));      // algorithmic: x (+ skip) in, y out
-  static int reg = -1;
-  if (reg < 0) { const char* e = getenv("SG_INSTNORM_REG"); reg = e ? atoi(e) : 1; }      // 0: the three-pass kernels
+  const int reg = sg_opt(SG_OPT_INSTNORM_REG);      // 0: the three-pass kernels
   int G = 0, E = 0;
   instnorm_shape(HW, 64, G, E);
   if (reg && G > 0) {
@@ -743,8 +741,7 @@ extern "C" int sg_instnorm_bwd(const float* x, const float* gy, const float* mea
   SG_ARG_CHECK(x && gy && mean && rstd && gx && NC > 0 && HW > 0, "sg_instnorm_bwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   SgProfScope prof(SG_K_INSTNORM_BWD, s, 0, (double)NC * HW * 4.0 * 3);      // algorithmic: x, gy in, gx out
-  static int reg = -1;
-  if (reg < 0) { const char* e = getenv("SG_INSTNORM_REG"); reg = e ? atoi(e) : 1; }
+  const int reg = sg_opt(SG_OPT_INSTNORM_REG);
   int G = 0, E = 0;
   instnorm_shape(HW, 32, G, E);                        // (two register arrays: 2 x 32 values per thread at most)
   if (reg && G > 0) {

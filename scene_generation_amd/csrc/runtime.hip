@@ -3,6 +3,9 @@
 #include <stdarg.h>
 #include <mutex>
 #include <vector>
+#include <stdlib.h>
+#include <string.h>
+#include <ctype.h>
 
 static thread_local char t_err[512] = "ok";
 
@@ -17,6 +20,55 @@ extern "C" const char* sg_last_error_string(void) { return t_err; }
 extern "C" int sg_version(void) { return 100; }
 
 int g_sg_prof_on = 0;
+
+// ---- option table ------------------------------------------------------------------------------------------------
+std::atomic<int> g_sg_opt[SG_OPT_COUNT];
+FILE* g_sg_launch_log = nullptr;
+namespace {
+struct OptDef { const char* name; int def; };
+const OptDef kOpts[SG_OPT_COUNT] = {
+    {"tile", -1}, {"t128_min", 384}, {"tile3", 1}, {"tile3_min", 768}, {"splits", -1}, {"fixedtap", 1}, {"wino_wt", 1},
+    {"w24_small", 1}, {"w24_s", -1}, {"w24_pmin", 256}, {"wino_adjoint", 1}, {"wino24", 1}, {"linear_nsub", 2},
+    {"linear_skinny", 2048}, {"wgrad_rowsum", 1}, {"layout_reg", 1}, {"layout_dsplit", 1}, {"bn_blocks", 4096},
+    {"instnorm_reg", 1}};
+// runs when the shared library is loaded, before any entry point can be called: the ONLY place the environment is read
+struct OptInit {
+  OptInit() {
+    for (int i = 0; i < SG_OPT_COUNT; ++i) {
+      char env[64] = "SG_";
+      size_t n = 3;
+      for (const char* c = kOpts[i].name; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)toupper((unsigned char)*c);
+      env[n] = 0;
+      const char* e = getenv(env);
+      g_sg_opt[i].store((e && *e) ? atoi(e) : kOpts[i].def, std::memory_order_relaxed);
+    }
+    const char* lf = getenv("SG_LAUNCH_LOG");
+    if (lf && *lf) g_sg_launch_log = fopen(lf, "a");
+  }
+} g_opt_init;
+int opt_index(const char* key) {
+  if (!key) return -1;
+  for (int i = 0; i < SG_OPT_COUNT; ++i)
+    if (strcmp(key, kOpts[i].name) == 0) return i;
+  return -1;
+}
+}  // namespace
+
+extern "C" int sg_num_options(void) { return SG_OPT_COUNT; }
+extern "C" const char* sg_option_name(int i) { return (i >= 0 && i < SG_OPT_COUNT) ? kOpts[i].name : nullptr; }
+extern "C" int sg_option_default(int i) { return (i >= 0 && i < SG_OPT_COUNT) ? kOpts[i].def : 0; }
+extern "C" int sg_get_option(const char* key, int* value) {
+  const int i = opt_index(key);
+  if (i < 0 || !value) { sg_set_error("sg_get_option: unknown option '%s'", key ? key : "(null)"); return -1; }
+  *value = sg_opt(i);
+  return 0;
+}
+extern "C" int sg_set_option(const char* key, int value) {
+  const int i = opt_index(key);
+  if (i < 0) { sg_set_error("sg_set_option: unknown option '%s'", key ? key : "(null)"); return -1; }
+  g_sg_opt[i].store(value, std::memory_order_relaxed);
+  return 0;
+}
 
 namespace {
 struct Rec { int kind; hipEvent_t e0, e1; double flops, bytes; };

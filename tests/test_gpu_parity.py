@@ -32,10 +32,11 @@ _CLOSE_LOG = []
 def close(a, b, tol=1e-5, name=''):
     """max|a-b| <= tol * max(1, max|b|)   AND   (an absolute bound scaled by the largest entry lets a
     small-magnitude channel be 100 % wrong) relative-L2 bounds per tensor and per channel:
-        ||a - b||_2 <= 20 tol ||b||_2 + 0.1 tol max(1, max|b|) sqrt(n)
+        ||a - b||_2 <= 20 tol ||b||_2 + 0.25 tol max(1, max|b|) sqrt(n)
     i.e. the rms error of the tensor / of every channel (dim 1 of an (N,C,H,W) map, last dim of a matrix) must be 20 tol
-    of that channel's own rms, plus an absolute rms floor ten times tighter than the max-error bound (a channel that is the
-    result of cancellation cannot be accurate relative to itself)."""
+    of that channel's own rms, plus an absolute rms floor four times tighter than the max-error bound (a channel that is the
+    result of cancellation cannot be accurate relative to itself).  Calibration: the tightest margins of a full GPU run are
+    written to gpurun_out/close_margins.json (r4: worst 0.39 of the bound, a 4-element bias gradient; everything else < 0.15)."""
     a = a.detach().double().cpu()
     b = (torch.from_numpy(np.asarray(b)) if not isinstance(b, torch.Tensor) else b.detach()).double().cpu()
     assert a.shape == b.shape, (name, tuple(a.shape), tuple(b.shape))
@@ -53,7 +54,7 @@ def close(a, b, tol=1e-5, name=''):
         groups.append(('column', d.t(), b.t()))
     for kind, dd, bb in groups:
         en, bn, n = dd.norm(dim=1), bb.norm(dim=1), dd.size(1)
-        lim = 20 * tol * bn + 0.1 * tol * scale * (n ** 0.5)
+        lim = 20 * tol * bn + 0.25 * tol * scale * (n ** 0.5)
         ratio = float((en / lim).max())
         _CLOSE_LOG.append((ratio, kind, name, tol))
         i = int((en / lim).argmax())
@@ -80,9 +81,37 @@ def hip():
 # ------------------------------------------------------------------------------------------
 # GEMM / conv kernels vs torch fp32 CPU
 # ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kernel', ['skinny', 'tiled'])
 @pytest.mark.parametrize('rows,inf,outf,act', [(1, 7, 5, 0), (9, 163, 64, 1), (33, 454, 512, 1), (128, 512, 1152, 1),
-                                               (70, 129, 33, 2), (16, 1024, 172, 0)])
-def test_linear(hip, rows, inf, outf, act):
+                                               (70, 129, 33, 2), (16, 1024, 172, 0), (224, 454, 512, 1), (208, 512, 128, 1),
+                                               (231, 1152, 454, 0), (1056, 512, 512, 1), (3, 2048, 4, 0), (40, 18, 90, 2)])
+def test_linear(hip, rows, inf, outf, act, kernel):
+    """nn.Linear forward / data gradient / weight gradient / bias gradient through BOTH dense kernels: the register-streaming
+    one for small layers (skinny.hip: every operand form -- 16-, 8-, 4-byte K-contiguous loads, row-index-major loads -- K tails,
+    K shorter than one round, ragged 32x32 tiles) and the LDS-tiled one (forced with the ``linear_skinny`` option at 0)."""
+    from scene_generation_amd import _hip
+    prev = _hip.get_option('linear_skinny')
+    _hip.set_option('linear_skinny', (1 << 30) if kernel == 'skinny' else 0)
+    try:
+        _linear_case(hip, rows, inf, outf, act)
+    finally:
+        _hip.set_option('linear_skinny', prev)
+
+
+def test_linear_kernels_are_deterministic_and_route_by_size(hip):
+    """the skinny kernel adds its four k-partials in a fixed order: two runs are bit-identical; the default routing threshold
+    sends the graph-conv shapes of BASELINE configs[1] to it and the 3072-row layers of configs[4] to the tiled kernel"""
+    from scene_generation_amd import _hip
+    assert _hip.get_option('linear_skinny') == 2048
+    x, w, b = det((224, 454), 11).to(DEV), det((512, 454), 12, 0.1).to(DEV), det((512,), 13, 0.1).to(DEV)
+    y1 = hip.linear(x, w, b, act=1)
+    y2 = hip.linear(x, w, b, act=1)
+    assert torch.equal(y1, y2)
+    tiles = lambda M, N: ((M + 31) // 32) * ((N + 31) // 32)
+    assert tiles(224, 1152) <= 2048 < tiles(3072, 1152)
+
+
+def _linear_case(hip, rows, inf, outf, act):
     x, w, b = det((rows, inf), 1), det((outf, inf), 2, 0.1), det((outf,), 3, 0.1)
     gy = det((rows, outf), 4)
     xr, wr, br = [t.clone().requires_grad_() for t in (x, w, b)]
