@@ -207,22 +207,6 @@ int sg_act_fwd(const float* x, float* y, int64_t n, int act, float slope, sgStre
  * entries of a row ordered (pass, t ascending) == the order CPU scatter_add applies them (graph.py:98-101).
  * csr_off[O+1], csr_ent[2T] (t | pass<<30). */
 int sg_build_csr(const int64_t* edges /*T,2*/, int T, int O, int32_t* csr_off, int32_t* csr_ent, sgStream stream);
-/* Fused GraphTripleConv forward (graph.py:79-122), two launches per layer (hidden width H in {128, 256, 512}):
- *  net1: rows [obj[s_t] | pred[t] | obj[o_t]] gathered into LDS -> Linear(K1,H)+ReLU (hidden block stays in LDS) ->
- *        Linear(H,N2)+ReLU -> new_t [T,N2] (N2 = 2H+Dout; its column ranges are the new_s / new_p / new_o split of graph.py:89-91).
- *        pred may be a strided view (pred_ld floats between rows: the new_p columns of the previous layer's new_t).
- *        Optional outputs for autograd: cur_t [T,K1], h1 [T,H].
- *  net2: segmented pool of new_t[:, col_s:col_s+H] (subject pass) and new_t[:, col_o:col_o+H] (object pass) over the CSR of
- *        sg_build_csr in the reference's scatter_add order (bit-exact given new_t), avg or sum (graph.py:94-116) ->
- *        Linear(H,H)+ReLU -> Linear(H,Dout)+ReLU -> out [O,Dout] (graph.py:120).  Optional outputs: pooled [O,H], h2 [O,H].
- * Same MFMA k order as sg_linear_fwd: identical results to the unfused path. */
-int sg_gconv_fused_supported(int Do, int Dp, int H, int Dout);
-int sg_gconv_net1_fwd(const float* obj, const float* pred, int pred_ld, const int64_t* edges, int T, int Do, int Dp,
-                      const float* w1, const float* b1, int H, const float* w2, const float* b2, int N2,
-                      float* cur_t, float* h1, float* new_t, sgStream stream);
-int sg_gconv_net2_fwd(const float* new_t, int ld, int col_s, int col_o, const int32_t* csr_off, const int32_t* csr_ent,
-                      int O, int avg, const float* w3, const float* b3, int H, const float* w4, const float* b4,
-                      int Dout, float* pooled, float* h2, float* out, sgStream stream);
 /* out[t] = [obj[s_t], pred[t], obj[o_t]]  (graph.py:79-84) */
 int sg_gather_concat_fwd(const float* obj, const float* pred, const int64_t* edges, float* out,
                          int T, int Do, int Dp, sgStream stream);

@@ -5,7 +5,7 @@
 # it includes, the compiler flags) differs from the stamp written next to it -- not on mtimes, which do not survive a copy.
 set -e
 cd "$(dirname "$0")"
-UNITS="runtime igemm igemm_kn0 igemm_kn1 igemm_nk skinny smallm norm graph gconv layout loss"
+UNITS="runtime igemm igemm_kn0 igemm_kn1 igemm_nk skinny smallm norm graph layout loss"
 if [ "$1" == "--clean" ]; then
   shift
   rm -f *.o *.stamp libsg2im_hip.so

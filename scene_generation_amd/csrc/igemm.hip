@@ -763,8 +763,12 @@ void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, in
     SgProfScope prof(NB == 16 ? SG_K_WINO_GEMM_128 : SG_K_WINO24_GEMM, s, flops, 0);
     // 128x128 tiles, 32-deep k-tiles, software-pipelined fragment reads, unconditional epilogue (the variants this replaced --
     // 128x64 tiles, 16-deep tiles, the plain loop, the general epilogue -- measured 1.5..9 % slower: profiles/r03_sweep_tiles.txt)
-    launch_cfg<CfgDP128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
-                         EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
+    if (sg_opt(SG_OPT_WINO_PIPE) == 2)
+      launch_cfg<CfgDI128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
+                           EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
+    else
+      launch_cfg<CfgDP128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
+                           EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
   }
   t_batch = BatchInfo{};
 }

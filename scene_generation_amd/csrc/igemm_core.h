@@ -149,11 +149,37 @@ struct LoadKContig {
   static constexpr int PASSES = BX >= 64 ? BX / 64 : 1;
   struct Stage { float r[PASSES * 4]; unsigned ok; };
   int x0_, xr_, kq_;
-  __device__ __forceinline__ void init(int x0, int tid, int*, int, int) { x0_ = x0; xr_ = tid >> 2; kq_ = (tid & 3) * 4; }
+  // vector form: byte offset of (row, kq_) per pass, fixed for the whole k-loop (rows outside the matrix / the tile: 2^31, which
+  // the range check of the buffer load rejects => zeros).  The k advance is wave-uniform and travels in the SGPR offset operand
+  // of the buffer load, so a full k-tile costs NO vector-ALU instruction per load (the f32 MFMA does not overlap with VALU
+  // work; the 64-bit address arithmetic of the plain loads was 0.5 VALU per MFMA in the dense Winograd GEMM)
+  unsigned voff_[PASSES];
+  __device__ __forceinline__ void init(int x0, int tid, int*, int, int) {
+    x0_ = x0; xr_ = tid >> 2; kq_ = (tid & 3) * 4;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int xl = xr_ + p * 64;
+      const int x = x0_ + xl;
+      const bool xok = (BX % 64 == 0 || xl < BX) && x < X;
+      voff_[p] = xok ? ((unsigned)x * (unsigned)ld + (unsigned)kq_) * 4u : 0x80000000u;
+    }
+  }
   __device__ __forceinline__ void set_batch(int b, int stride, int) { base += (size_t)b * (size_t)stride; }
   __device__ __forceinline__ void prefetch(Stage&, int) const {}
   __device__ __forceinline__ void load(Stage& st, int k0, int kend) const {
     st.ok = 0;
+#if SG_BUFLOAD
+    if (VEC && (!MASK || k0 + BK <= kend)) {      // whole k-tile inside [.., kend): wave-uniform test (always true without MASK)
+      const __amdgpu_buffer_rsrc_t rs = sg_rsrc(base);
+      const int so = __builtin_amdgcn_readfirstlane(k0 * 4);
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff_[p], so, 0);
+        __builtin_memcpy(&st.r[p * 4], &v, 16);
+      }
+      return;
+    }
+#endif
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int xl = xr_ + p * 64;
@@ -1147,21 +1173,53 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     if (AL::LDS_INTS > 0 || BL::LDS_INTS > 0) __syncthreads();
     for (int k0 = kbeg; k0 < kend; k0 += BKT) {
       const bool more1 = k0 + BKT < kend, more2 = k0 + 2 * BKT < kend;
-      if (more1) {
+      // PIPE == 2 (dense Winograd GEMMs): the LDS stores of the next tile do not sit in front of the iteration's first MFMA
+      // (8 ds_write_b128 = ~100 cycles during which this wave feeds nothing to the matrix pipe) but BETWEEN the MFMAs of phase 0,
+      // one store call after each group of four: a 64-cycle MFMA covers the 13 cycles a store takes to issue.  The global loads
+      // of the tile after next re-use the staging registers, so they follow the stores (one phase later than with PIPE == 1).
+      constexpr bool INTER = CFG::PIPE == 2 && 2 * NSUB <= 4;
+      auto stage_next = [&]() {
+        if (more2) {
 #pragma unroll
-        for (int u = 0; u < NSUB; ++u) { al.store(sa[u], As[buf ^ 1] + u * BM * LDK); bl.store(sb[u], Bs[buf ^ 1] + u * BN * LDK); }
-      }
-      if (more2) {
+          for (int u = 0; u < NSUB; ++u) { al.load(sa[u], k0 + 2 * BKT + u * BK, kend); bl.load(sb[u], k0 + 2 * BKT + u * BK, kend); }
 #pragma unroll
-        for (int u = 0; u < NSUB; ++u) { al.load(sa[u], k0 + 2 * BKT + u * BK, kend); bl.load(sb[u], k0 + 2 * BKT + u * BK, kend); }
+          for (int u = 0; u < NSUB; ++u) { al.prefetch(sa[u], k0 + 3 * BKT + u * BK); bl.prefetch(sb[u], k0 + 3 * BKT + u * BK); }
+        }
+      };
+      if (!INTER) {
+        if (more1) {
 #pragma unroll
-        for (int u = 0; u < NSUB; ++u) { al.prefetch(sa[u], k0 + 3 * BKT + u * BK); bl.prefetch(sb[u], k0 + 3 * BKT + u * BK); }
+          for (int u = 0; u < NSUB; ++u) { al.store(sa[u], As[buf ^ 1] + u * BM * LDK); bl.store(sb[u], Bs[buf ^ 1] + u * BN * LDK); }
+        }
+        stage_next();
       }
 #pragma unroll
       for (int p = 0; p < P - 1; ++p) {
         read_frag(buf, p + 1, fa[(p + 1) & 1], fb[(p + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);          // keep the reads IN FRONT of the MFMAs that cover their latency
-        mma(fa[p & 1], fb[p & 1]);
+        if (INTER && p == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                const float av = e == 0 ? fa[0][i].x : (e == 1 ? fa[0][i].y : (e == 2 ? fa[0][i].z : fa[0][i].w));
+                const float bv = e == 0 ? fb[0][j].x : (e == 1 ? fb[0][j].y : (e == 2 ? fb[0][j].z : fb[0][j].w));
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+              }
+            __builtin_amdgcn_sched_barrier(0);
+            if (more1 && e < 2 * NSUB) {
+              const int u = e >> 1;
+              if ((e & 1) == 0) al.store(sa[u], As[buf ^ 1] + u * BM * LDK);
+              else bl.store(sb[u], Bs[buf ^ 1] + u * BN * LDK);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          stage_next();
+        } else {
+          mma(fa[p & 1], fb[p & 1]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();
@@ -1249,6 +1307,7 @@ using CfgW64 = TileCfg<64, 64, 2, NSW>;
 using CfgW32 = TileCfg<32, 128, 1, NSW>;
 using CfgW64W = TileCfg<64, 128, 2, NSW>;
 using CfgDP128 = TileCfg<128, 128, 2, 2, 1>; // ... software-pipelined fragment reads, barrier before the last phase
+using CfgDI128 = TileCfg<128, 128, 2, 2, 2>; // ... and the LDS stores of the next tile interleaved with the MFMAs of phase 0
 
 inline int pick_tile(int M, int N) {
   const int force = sg_opt(SG_OPT_TILE);

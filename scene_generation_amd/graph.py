@@ -6,9 +6,9 @@ GraphTripleConv.forward = 7 HIP launches instead of ~25 ATen kernels:
 with the destination-major CSR of the triples built ONCE per forward of the stack (Model / GraphTripleConvNet hand it down).
 The pool walks the CSR in (pass, t) order, i.e. exactly the order CPU scatter_add applies the updates at graph.py:98-101,
 so ``pooled`` is bit-identical to the reference given identical net1 outputs.
-SG_GCONV_FUSED=1 switches to TWO fused launches per layer (csrc/gconv.hip: [row gather -> GEMM -> ReLU -> GEMM -> ReLU] with
-the hidden block resident in LDS, [segmented pool -> GEMM -> ReLU -> GEMM -> ReLU], new_p a column view of new_t) --
-bit-identical results and gradients, but measured slower on MI355X at the benchmark sizes (see ops.GCONV_FUSED), hence opt-in.
+The four per-edge / per-node MLP GEMMs of a layer (a few hundred rows) run on the register-streaming kernel (csrc/skinny.hip).
+(Rounds 2-3 carried a two-launch fused form of the layer -- hidden block resident in LDS -- that was bit-identical but slower
+than the separate launches, 3.0 vs 1.8 ms per step; it was removed in round 4 when the skinny GEMM took the layer to 1.0 ms.)
 """
 import torch.nn as nn
 
@@ -38,11 +38,6 @@ class GraphTripleConv(nn.Module):
         self.net2 = build_mlp([hidden_dim, hidden_dim, output_dim], batch_norm=mlp_normalization)
         self.net2.apply(_init_weights)
 
-    def _fusable(self, obj_vecs, pred_vecs):
-        plain = all([type(m).__name__ for m in net] == ['Linear', 'ReLU', 'Linear', 'ReLU'] for net in (self.net1, self.net2))
-        return (plain and obj_vecs.is_cuda and pred_vecs.dim() == 2 and pred_vecs.stride(-1) == 1
-                and ops.gconv_fused_supported(obj_vecs.size(1), pred_vecs.size(1), self.hidden_dim, self.output_dim))
-
     def forward(self, obj_vecs, pred_vecs, edges, csr=None):
         """obj_vecs (O, D), pred_vecs (T, D), edges (T, 2) int64 -> new_obj_vecs (O, Dout), new_pred_vecs (T, Dout).
         ``csr``: the (offsets, entries) pair of ops.build_csr for these edges (GraphTripleConvNet builds it once)."""
@@ -50,10 +45,6 @@ class GraphTripleConv(nn.Module):
         H, Dout = self.hidden_dim, self.output_dim
         edges = edges if edges.is_contiguous() else edges.contiguous()
         off, ent = csr if csr is not None else ops.build_csr(edges, O)
-        if edges.size(0) > 0 and self._fusable(obj_vecs, pred_vecs):
-            l1, l2, l3, l4 = self.net1[0], self.net1[2], self.net2[0], self.net2[2]
-            return ops.FusedTripleConvFn.apply(obj_vecs, pred_vecs, edges, off, ent, l1.weight, l1.bias, l2.weight, l2.bias,
-                                               l3.weight, l3.bias, l4.weight, l4.bias, self.pooling == 'avg')
         pred_vecs = pred_vecs if pred_vecs.is_contiguous() else pred_vecs.contiguous()
         cur_t = ops.GatherConcatFn.apply(obj_vecs, pred_vecs, edges, off, ent)
         new_t = self.net1(cur_t)

@@ -1118,102 +1118,6 @@ class TriplePoolFn(Function):
         return g, None, None, None, None, None, None, None
 
 
-# GraphTripleConv layers as two fused forward launches (csrc/gconv.hip), bit-identical to the seven separate launches (gather /
-# two GEMMs / pool / split / two GEMMs).  OPT-IN (SG_GCONV_FUSED=1): measured on MI355X the fused pair is SLOWER at the benchmark
-# sizes -- graph-conv GEMMs 1.80 -> 3.03 ms/step at T = 512 triples, 3.4 -> 6.5 ms at T = 3072 -- because a workgroup that
-# keeps a (32 x 512) hidden block and a double-buffered 512-row weight tile in LDS (147 KB) runs alone on its CU and walks 61
-# dependent L2 round trips (29 + 32 k-tiles of 16) with one tile of prefetch, where the small launches overlap 64+ workgroups
-# of 15 k-tiles each.  (What would win: 16 waves per workgroup, 32-deep k-tiles, 2-4 tiles of register prefetch.)
-GCONV_FUSED = os.environ.get('SG_GCONV_FUSED', '0') == '1'
-
-
-def gconv_fused_supported(Do, Dp, H, Dout):
-    return bool(GCONV_FUSED and _L().sg_gconv_fused_supported(int(Do), int(Dp), int(H), int(Dout)))
-
-
-class FusedTripleConvFn(Function):
-    """One GraphTripleConv layer (graph.py:79-122) with mlp_normalization 'none': forward = sg_gconv_net1_fwd +
-    sg_gconv_net2_fwd (the (T, H) / (O, H) hidden blocks and the gathered rows never round-trip through HBM between the
-    GEMMs; they are written once for this backward).  ``pred`` may be the strided new_p view of the previous layer.
-    Backward = the same GEMM / pool-adjoint launches the unfused autograd graph issues, in the same order."""
-
-    @staticmethod
-    def forward(ctx, obj, pred, edges, off, ent, w1, b1, w2, b2, w3, b3, w4, b4, avg):
-        obj = _f32(obj, 'obj_vecs')
-        _dev(pred, 'pred_vecs')
-        assert pred.dtype == torch.float32 and pred.dim() == 2 and pred.stride(1) == 1
-        T, Do, Dp = edges.size(0), obj.size(1), pred.size(1)
-        O, H, N2, Dout = obj.size(0), w1.size(0), w2.size(0), w4.size(0)
-        K1 = 2 * Do + Dp
-        dev, f = obj.device, torch.float32
-        cur_t = torch.empty(T, K1, dtype=f, device=dev)
-        h1 = torch.empty(T, H, dtype=f, device=dev)
-        new_t = torch.empty(T, N2, dtype=f, device=dev)
-        pooled = torch.empty(O, H, dtype=f, device=dev)
-        h2 = torch.empty(O, H, dtype=f, device=dev)
-        out = torch.empty(O, Dout, dtype=f, device=dev)
-        s = _stream()
-        _call('sg_gconv_net1_fwd', _p(obj), _p(pred), pred.stride(0), _p(edges), T, Do, Dp, _p(_f32(w1)), _p(b1), H,
-              _p(_f32(w2)), _p(b2), N2, _p(cur_t), _p(h1), _p(new_t), s)
-        _call('sg_gconv_net2_fwd', _p(new_t), N2, 0, H + Dout, _p(off), _p(ent), O, 1 if avg else 0, _p(_f32(w3)), _p(b3), H,
-              _p(_f32(w4)), _p(b4), Dout, _p(pooled), _p(h2), _p(out), s)
-        ctx.dims = (T, O, Do, Dp, H, N2, Dout, bool(avg))
-        ctx.params = (w1, b1, w2, b2, w3, b3, w4, b4)
-        ctx.set_materialize_grads(False)
-        ctx.save_for_backward(edges, off, ent, cur_t, h1, new_t, pooled, h2, out)
-        new_p = new_t[:, H:H + Dout]           # graph.py:90 -- a view: the next layer's gather reads it in place
-        return out, new_p
-
-    @staticmethod
-    def backward(ctx, g_out, g_new_p):
-        edges, off, ent, cur_t, h1, new_t, pooled, h2, out = ctx.saved_tensors
-        T, O, Do, Dp, H, N2, Dout, avg = ctx.dims
-        w1, b1, w2, b2, w3, b3, w4, b4 = ctx.params
-        dev, f, s = out.device, torch.float32, _stream()
-        K1 = 2 * Do + Dp
-
-        def linear_bwd(gy, x, y, w, b, rows, in_f, out_f, need_x):
-            """gradient of y = relu(x w^T + b): returns g_x (or None); weight / bias gradients go to their sinks"""
-            g = torch.empty_like(gy)
-            _call('sg_act_bwd', _p(y), _p(gy), _p(g), g.numel(), ACT_RELU, 0.0, s)
-            gx = None
-            if need_x:
-                gx = torch.empty(rows, in_f, dtype=f, device=dev)
-                _call('sg_linear_bwd_data', _p(g), _p(_f32(w)), _p(gx), rows, in_f, out_f, s)
-            need_w = w.requires_grad and _wants_grad(w)
-            need_b = b is not None and b.requires_grad and _wants_grad(b)
-            ow = GradOut(w) if need_w else None
-            ob = GradOut(b) if need_b else None
-            if need_w:
-                _call('sg_linear_bwd_weight', _p(g), _p(x), _p(ow.buf), _p(ob.buf) if need_b else None, rows, in_f, out_f, s)
-            elif need_b:
-                _call('sg_channel_sum', _p(g), _p(ob.buf), rows, out_f, 1, None, 0, s)
-            return gx, (ow.finish() if need_w else None), (ob.finish() if need_b else None)
-
-        grads = {}
-        # net2 (graph.py:120) backwards: out = relu(h2 w4^T + b4), h2 = relu(pooled w3^T + b3)
-        g_out = _f32(g_out) if g_out is not None else torch.zeros(O, Dout, dtype=f, device=dev)
-        g_h2, grads['w4'], grads['b4'] = linear_bwd(g_out, h2, out, w4, b4, O, H, Dout, True)
-        g_pooled, grads['w3'], grads['b3'] = linear_bwd(g_h2, pooled, h2, w3, b3, O, H, H, True)
-        # pool adjoint (graph.py:94-116) + the new_p pass-through
-        g_new_t = torch.empty(T, N2, dtype=f, device=dev)
-        gnp = None if g_new_p is None else _f32(g_new_p)
-        _call('sg_pool_bwd', _p(g_pooled), _p(gnp), _p(edges), _p(off), _p(g_new_t), T, H, Dout, 1 if avg else 0, s)
-        # net1 (graph.py:85) backwards: new_t = relu(h1 w2^T + b2), h1 = relu(cur_t w1^T + b1)
-        need_in = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        g_h1, grads['w2'], grads['b2'] = linear_bwd(g_new_t, h1, new_t, w2, b2, T, H, N2, True)
-        g_cur, grads['w1'], grads['b1'] = linear_bwd(g_h1, cur_t, h1, w1, b1, T, K1, H, need_in)
-        g_obj = g_pred = None
-        if ctx.needs_input_grad[0]:            # adjoint of the row gather (graph.py:79-84): deterministic segmented sums
-            g_obj = torch.empty(O, Do, dtype=f, device=dev)
-            _call('sg_segment_sum', _p(g_cur), K1, 0, Do + Dp, Do, _p(off), _p(ent), _p(g_obj), O, 0, s)
-        if ctx.needs_input_grad[1]:
-            g_pred = torch.empty(T, Dp, dtype=f, device=dev)
-            _call('sg_copy_cols', _p(g_cur), K1, Do, _p(g_pred), Dp, 0, T, Dp, s)
-        return (g_obj, g_pred, None, None, None, grads['w1'], grads['b1'], grads['w2'], grads['b2'], grads['w3'], grads['b3'],
-                grads['w4'], grads['b4'], None)
-
-
 class EmbeddingFn(Function):
     @staticmethod
     def forward(ctx, table, idx):

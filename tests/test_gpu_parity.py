@@ -468,41 +468,6 @@ def test_gconvnet_vs_reference_golden(hip, golden):
     close(p2, g['new_pred'], 1e-5, 'gconvnet new_pred')
 
 
-@pytest.mark.parametrize('O_,T_,Din,A,H_,Dout,pooling', [(9, 16, 128, 35, 512, 128, 'avg'), (288, 512, 128, 0, 512, 128, 'avg'),
-                                                         (33, 70, 64, 3, 128, 32, 'sum'), (1056, 3072, 128, 0, 256, 128, 'avg')])
-def test_fused_gconv_layer_equals_unfused(hip, O_, T_, Din, A, H_, Dout, pooling):
-    """csrc/gconv.hip: the two fused forward launches of a GraphTripleConv layer (gather -> GEMM -> ReLU -> GEMM | pool -> GEMM ->
-    GEMM, graph.py:79-122) against the unfused launches (gather, sg_linear_fwd x 4, segmented pool): same MFMA k order, so
-    outputs AND every gradient are bit-identical; also with the strided new_p view of a previous layer as ``pred``."""
-    from scene_generation_amd.graph import GraphTripleConv
-    g = torch.Generator().manual_seed(5)
-    edges = torch.randint(0, O_ - 1, (T_, 2), generator=g).to(DEV)          # node O-1 stays isolated
-    layer = GraphTripleConv(Din, attributes_dim=A, output_dim=Dout, hidden_dim=H_, pooling=pooling).to(DEV)
-    fill_deterministic(layer)
-    obj0, wide = det((O_, Din + A), 191), det((T_, Din + 7), 192)
-    wo, wp = det((O_, Dout), 193).to(DEV), det((T_, Dout), 194).to(DEV)
-    res = []
-    saved = hip.GCONV_FUSED
-    try:
-        hip.GCONV_FUSED = True
-        assert hip.gconv_fused_supported(Din + A, Din, H_, Dout)
-        for fused in (True, False):
-            hip.GCONV_FUSED = fused
-            obj = obj0.to(DEV).requires_grad_()
-            base = wide.to(DEV).requires_grad_()
-            pred = base[:, 3:3 + Din]                                      # a strided view, like new_t[:, H:H+Dout]
-            new_obj, new_p = layer(obj, pred, edges)
-            ((new_obj * wo).sum() + (new_p * wp).sum()).backward()
-            res.append([new_obj.detach().clone(), new_p.detach().clone(), obj.grad.clone(), base.grad.clone()] +
-                       [p.grad.clone() for p in layer.parameters()])
-            for p in layer.parameters():
-                p.grad = None
-    finally:
-        hip.GCONV_FUSED = saved
-    for i, (a, b) in enumerate(zip(res[0], res[1])):
-        assert torch.equal(a, b), 'tensor %d differs between the fused and the unfused layer: %g' % (i, float((a - b).abs().max()))
-
-
 def test_multiscale_discriminators_on_side_streams_are_bit_identical(hip):
     """streams.py (SG_MULTISTREAM=1): the PatchGAN scales on one HIP stream each == all of them on the current stream: outputs
     and every gradient bit-identical (no atomics, one writer per buffer), incl. gradients delivered into a FusedAdam's flat
