@@ -82,8 +82,9 @@ constexpr int BK = 16;     // sub-tile depth: the unit one loader call stages (1
 // before the MFMAs of the current one, so NSUB*~8 global loads per thread stay in flight across 8*NSUB*TM*TN
 // MFMAs (the f32 MFMA is 64 cycles: one sub-tile of work per load round trip left the kernel latency-bound).
 #ifndef SG_PIPE_DEFAULT
-#define SG_PIPE_DEFAULT 1      // software-pipelined main loop for every instantiation (0: the plain loop; measured on MI355X:
-#endif                         // 648 -> 660 images/s, every kernel family +1..6 %)
+#define SG_PIPE_DEFAULT 2      // main loop of every instantiation: 0 = plain; 1 = software-pipelined fragment reads (measured on
+#endif                         // MI355X: 648 -> 660 images/s, every family +1..6 %); 2 = 1 + the LDS stores of the next tile
+                               // interleaved with the MFMAs of phase 0 (855 -> 859 images/s, profiles/r04_ab_sessions.md)
 template <int BM_, int BN_, int WGM_, int NSUB_, int PIPE_ = SG_PIPE_DEFAULT>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = 4 / WGM_, NSUB = NSUB_, BKT = BK * NSUB_, PIPE = PIPE_;
@@ -93,9 +94,13 @@ struct TileCfg {
 };
 
 // LDS tile layout: [x][k] with k contiguous, row pitch LDK = 16 + 4 floats (80 B).  One ds_read_b128 then feeds FOUR
-// MFMA k-steps of a 32x32 fragment row and the pitch makes both the b128 fragment reads (16-lane groups hit 16
-// distinct 4-bank slots) and the b128/b32 stores conflict-free.  MFMA k-step s pairs tile column s (lanes 0-31) with
-// column s+8 (lanes 32-63): any pairing is legal as long as A and B use the same one.
+// MFMA k-steps of a 32x32 fragment row and the pitch makes the b128 fragment READS conflict-free (the 16 lanes of a group
+// hit 16 distinct 4-bank slots).  The b128 staging STORES of the K-contiguous loaders are 2-way conflicted on 4 of the 32
+// banks (8-lane groups cover two rows: floats 20r .. 20r+15 and 20r+20 .. 20r+35, the last four wrap onto the first four):
+// one extra LDS-array cycle per lane group, which is what SQ_LDS_BANK_CONFLICT counts on these kernels (33 % of
+// SQ_LDS_IDX_ACTIVE) and which costs <= 0.6 % because a b128 store is bound by its 13-cycle data transfer, not by the array
+// (profiles/r04_lds_bank_conflict.md).  MFMA k-step s pairs tile column s (lanes 0-31) with column s+8 (lanes 32-63): any
+// pairing is legal as long as A and B use the same one.
 constexpr int LDK = BK + 4;
 
 // ------------------------------------------------------------------------------------------------
@@ -1017,6 +1022,8 @@ struct BatchInfo {
   // batch_major: tiles are numbered batch-major (all tiles of batch 0, then batch 1, ...), so that with the XCD remap
   // below every XCD works on whole batches and their operands stay in ITS L2 (batched Winograd GEMMs)
   int batch_major;
+  // xcd_z: plain split-K launch whose grid.z is a multiple of 8: k-chunk z runs on XCD z % 8 (see the kernel)
+  int xcd_z;
   ParityClasses par;
 };
 // per-class hooks: loaders / epilogues that can run a parity class overload these; everything else ignores the call
@@ -1079,7 +1086,19 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     set_class_b(bl, bi.par, c);
     set_class_ep(ep, bi.par, c);
   }
-  const int zblk = blockIdx.z;
+  int zblk = blockIdx.z;
+  if (bi.xcd_z) {
+    // Weight-gradient GEMMs are split-K launches of FEW output tiles over a LONG k axis (pixels): the tiles of one k-chunk all
+    // read the same gy / x pixels.  Workgroups are handed to the 8 XCDs round-robin in linear (z, x) order, which spreads the
+    // tiles of a chunk over all eight L2s -- each L2 fetched the chunk on its own (5-9x the algorithmic bytes at the fabric,
+    // profiles/r03_pmc_traffic.md).  Re-numbered so that XCD i runs ALL tiles of the chunks i, i+8, ...: the operands of a
+    // chunk are fetched into one L2 once.  (grid.z % 8 == 0, so every XCD gets whole chunks.)
+    const unsigned lin = blockIdx.z * gridDim.x + blockIdx.x, xcd = lin & 7u, idx = lin >> 3;
+    zblk = (int)(xcd + 8u * (idx / gridDim.x));
+    const int t = (int)(idx % gridDim.x);
+    m0 = (t / tiles_n) * BM;
+    n0 = (t % tiles_n) * BN;
+  }
   int kbeg = zblk * kchunk;
   int kend = min(K, kbeg + kchunk);
   if (bi.ksplit > 0) {
@@ -1301,7 +1320,10 @@ using Cfg32 = CfgFor<3>::C32;
 // 54 launches of a step (wgrad +17 %, dgrad +7 %, fwd +4 %).  The weight-gradient GEMMs gain on some shapes (mask_net +31 %)
 // and lose on others (-3..-10 % on the 128-tile ones); over the step it is a wash, so they stay at depth NSW = 1 like the
 // im2col gathers (which LOSE 5-15 % at depth 2: one dword per lane per element, 80 KB of LDS = 2 workgroups per CU).
-constexpr int NSW = 1;
+#ifndef SG_NSW
+#define SG_NSW 1
+#endif
+constexpr int NSW = SG_NSW;
 using CfgW128 = TileCfg<128, 128, 2, NSW>;
 using CfgW64 = TileCfg<64, 64, 2, NSW>;
 using CfgW32 = TileCfg<32, 128, 1, NSW>;
@@ -1328,6 +1350,8 @@ inline int pick_tile(int M, int N) {
 thread_local BatchInfo t_batch = {};
 thread_local int t_grid_z = 0;                // >0: explicit grid.z (per-image k-chunks, see BatchInfo::ksplit)
 thread_local int t_fixed_kchunk = 0;        // >0: grid.z = ceil(K / chunk) with exactly this chunk (one image per z)
+thread_local int t_xcd_z = 0;               // 1: pin the k-chunks of a plain split-K launch to XCDs (weight gradients)
+thread_local int t_min_z = 0;               // >0: at least this many k-chunks (trailing ones may be empty: zero slabs)
 
 template <class CFG, class AL, class BL, class EP>
 int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int splits, hipStream_t s) {
@@ -1338,7 +1362,10 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
   if (splits > 1) kchunk = sg_cdiv(sg_cdiv(K, splits), CFG::BKT) * CFG::BKT;
   if (t_fixed_kchunk > 0) kchunk = t_fixed_kchunk;
   dim3 grid(tiles, 1, t_grid_z > 0 ? t_grid_z : ((splits > 1 || t_fixed_kchunk > 0) ? sg_cdiv(K, kchunk) : 1));
+  if (t_min_z > 0 && (int)grid.z < t_min_z && t_grid_z == 0) grid.z = t_min_z;
   BatchInfo bi = t_batch;
+  bi.xcd_z = (t_xcd_z && t_grid_z == 0 && t_fixed_kchunk == 0 && bi.cols_per_batch == 0 && bi.par.ncls == 0 && bi.ksplit == 0 &&
+              grid.z >= 8 && grid.z % 8 == 0) ? 1 : 0;
   hipLaunchKernelGGL((igemm_kernel<CFG, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, N, K, kchunk, bi);
   FILE* lf = g_sg_launch_log;
   if (lf) { fprintf(lf, "%u %u %d %d %d %.0f\n", grid.x * 256u, grid.z, M, N, K, sgk::t_alg_bytes); fflush(lf); }
@@ -1579,6 +1606,12 @@ inline NkPlan nk_plan(int M, int C, int KS2, int Kpix, bool two) {
   const int maxs = Kpix / (BK * 8) > 0 ? Kpix / (BK * 8) : 1;
   if (s > maxs) s = maxs;
   if (s > 64) s = 64;
+  // XCD-pinned k-chunks (see the kernel) need a multiple of 8 of them
+  if (sg_opt(SG_OPT_WGRAD_XCD) && s >= 6) {
+    int s8 = (s + 7) / 8 * 8;
+    if (s8 > maxs) s8 = maxs / 8 * 8;
+    if (s8 >= 8) s = s8;
+  }
   p.splits = s < 1 ? 1 : s;
   return p;
 }

@@ -160,12 +160,21 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
   SG_ARG_CHECK(!pl.tap || (ws && ws_bytes >= mn * sizeof(float) * (size_t)splits), "wgrad: workspace too small");
   const int kchunk = sp ? PQ : sg_cdiv(sg_cdiv(Kpix, splits), 64) * 64;      // multiple of every BKT
   splits = sg_cdiv(Kpix, kchunk);
+  // XCD-pinned k-chunks (igemm_kernel: xcd_z) need grid.z % 8 == 0: pad with empty chunks (kbeg >= Kpix: they store zero slabs)
+  // when the workspace has room for them
+  int zpad = 0;
+  if (sg_opt(SG_OPT_WGRAD_XCD) && !sp && splits >= 6) {
+    const int z8 = (splits + 7) / 8 * 8;
+    if (ws && ws_bytes >= (mn + (size_t)M) * sizeof(float) * (size_t)z8) { zpad = z8; splits = z8; }
+  }
   // bias gradient from the A loader's row sums: tap-major dense launches whose workspace has room for [splits][M] behind the slabs
   const int fuse_gb = sg_opt(SG_OPT_WGRAD_ROWSUM);
   float* rowsum = nullptr;
   if (fuse_gb && gb && pl.tap && !sp && M == Mtot && ws_bytes >= (mn + (size_t)M) * sizeof(float) * (size_t)splits)
     rowsum = reinterpret_cast<float*>(ws) + mn * (size_t)splits;
   if (sp) { t_fixed_kchunk = PQ; flops = 2.0 * M * (double)Ncols * Kpix; }
+  t_xcd_z = zpad > 0 ? 1 : 0;
+  t_min_z = zpad;
   float* dst = (splits > 1 || sp || pl.tap) ? reinterpret_cast<float*>(ws) : out;
   {
     SgProfScope prof(sg_igemm_kind(2, KS, pl.tile), s, flops, 0);
@@ -187,11 +196,13 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
         case 3: launch_nk_general<3>(pl.tile, A, M, Mtot, PQ, g, Ncols, ep, Kpix, splits, s); break;
         case 4: launch_nk_general<4>(pl.tile, A, M, Mtot, PQ, g, Ncols, ep, Kpix, splits, s); break;
         case 7: launch_nk_general<7>(pl.tile, A, M, Mtot, PQ, g, Ncols, ep, Kpix, splits, s); break;
-        default: t_fixed_kchunk = 0; return -1;
+        default: t_fixed_kchunk = 0; t_xcd_z = 0; t_min_z = 0; return -1;
       }
     }
   }
   t_fixed_kchunk = 0;
+  t_xcd_z = 0;
+  t_min_z = 0;
   const size_t nout = (size_t)M * C * KS2;
   if (sp && sp->gwimg) {
     const size_t n = (size_t)NB * M * sp->L * KS2;

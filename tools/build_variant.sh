@@ -1,18 +1,15 @@
 #!/bin/bash
-# Build a kernel-variant copy of the library for A/B runs on the GPU box (select it with SG_LIB_PATH=<path>):
-#   tools/build_variant.sh NAME [extra hipcc flags, e.g. -DSG_PIPE_DEFAULT=2]
-# Objects go to /tmp/sgvar_NAME, the library to scene_generation_amd/csrc/variants/libsg2im_hip_NAME.so (git-ignored).
+# Build a VARIANT of libsg2im_hip.so with extra compiler flags into scene_generation_amd/csrc/variants/<name>.so (git-ignored;
+# travels to the GPU box with gpurun).  Use with SG_LIB_PATH=<that file> python bench.py ...   Usage: build_variant.sh <name> <flags...>
 set -e
-name=$1; shift
-root=$(cd "$(dirname "$0")/.." && pwd)
-src=$root/scene_generation_amd/csrc
-obj=/tmp/sgvar_$name
-mkdir -p $obj $src/variants
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I$src $*"
-for f in runtime igemm igemm_kn0 igemm_kn1 igemm_nk smallm norm graph gconv layout loss; do
-  ( cd $src && /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $obj/$f.o 2> $obj/$f.log || echo "FAILED $f" ) &
-done
-wait
-if grep -l "error:" $obj/*.log; then exit 1; fi
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $obj/*.o -o $src/variants/libsg2im_hip_$name.so
-echo "built $src/variants/libsg2im_hip_$name.so"
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+NAME="$1"; shift
+W=/tmp/sg_variant_$NAME
+rm -rf "$W"; mkdir -p "$W/scene_generation_amd" "$W/include"
+cp -r "$ROOT/scene_generation_amd/csrc" "$W/scene_generation_amd/csrc"
+cp "$ROOT/include/sg2im_hip.h" "$W/include/"
+rm -rf "$W/scene_generation_amd/csrc/variants"
+bash "$W/scene_generation_amd/csrc/build.sh" --clean "$@" | tail -1
+mkdir -p "$ROOT/scene_generation_amd/csrc/variants"
+cp "$W/scene_generation_amd/csrc/libsg2im_hip.so" "$ROOT/scene_generation_amd/csrc/variants/$NAME.so"
+echo "variant: scene_generation_amd/csrc/variants/$NAME.so"
