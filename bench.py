@@ -38,6 +38,10 @@ def parse():
     p.add_argument('--cpu_steps', type=int, default=3)
     p.add_argument('--no_legs', action='store_true', help='skip the secondary config legs (c4: 256x256, c5: dense graphs)')
     p.add_argument('--no_prof', action='store_true')
+    p.add_argument('--pmc', default='auto', choices=['auto', 'off'],
+                   help="roofline.traffic measured live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over a short child run "
+                        "of this script, restricted to the dominant kernel + the Adam kernel used for calibration ('off': the "
+                        "committed table under profiles/)")
     p.add_argument('--no_secondary', action='store_true', help='skip the secondary passes (default-flags step with the VGG '
                    'loss on; the step with every fast path off)')
     p.add_argument('--vgg', type=float, default=0.0, help='--vgg_features_weight of the HEADLINE pass (SURVEY 8d: 0; the '
@@ -90,11 +94,79 @@ def cpu_baseline(image_size, n_images, n_steps):
                                                                                         n_steps, dt)}
 
 
+PMC_KERNELS = {
+    # profiler kind -> regex of the kernel symbol (the two dense Winograd instantiations: stores at the top / interleaved)
+    'wino_bgemm_t128': r'igemm_kernel.*TileCfg<128, 128, 2, 2, [12]>.*EpRowMajorPlain',
+}
+
+
+def measure_traffic(kind, timeout_s=300):
+    """HBM-side bytes per launch of the kernel behind profiler kind ``kind``, measured NOW: two child runs of this script under
+    ``rocprofv3 --pmc <counter> --kernel-trace`` (FETCH_SIZE and WRITE_SIZE need separate passes), counters restricted to that
+    kernel and adam_kernel.  Corrections exactly as /opt/skills/guides/MI355X_MICROARCH.md prescribes (tools/pmc_db_summary.py):
+    the counters are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads (x2); WRITE_SIZE is
+    calibrated on the largest adam_kernel launch, whose traffic is known exactly (12 B written per parameter).
+    Returns (dict | None, note)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    rx = PMC_KERNELS.get(kind)
+    rp = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if rx is None or not os.path.exists(rp):
+        return None, 'no live measurement: %s' % ('kind %s has no kernel pattern' % kind if rx is None else 'rocprofv3 not found')
+    per = {}
+    t_start = time.perf_counter()
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='sg_pmc_', dir='/tmp')
+        cmd = [rp, '--pmc', ctr, '--kernel-trace', '--kernel-include-regex', '%s|adam_kernel' % rx, '-d', d, '-o', 'pmc', '--',
+               sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '3', '--no_legs', '--no_secondary',
+               '--no_prof', '--cpu_baseline', 'off', '--pmc', 'off']
+        env = dict(os.environ, TMPDIR='/tmp', SG_GRAPHS='0')      # eager launches: every dispatch is visible to the counters
+        try:
+            r = subprocess.run(cmd, cwd='/tmp', env=env, timeout=timeout_s, capture_output=True, text=True)
+        except Exception as e:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, 'no live measurement: rocprofv3 %s pass failed: %r' % (ctr, e)
+        dbs = glob.glob(os.path.join(d, '**', '*.db'), recursive=True)
+        if r.returncode != 0 or not dbs:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, 'no live measurement: rocprofv3 %s pass rc=%d: %s' % (ctr, r.returncode, (r.stderr or '')[-300:])
+        rows = sqlite3.connect(dbs[0]).execute('select kernel_name, grid_size, value from counters_collection where '
+                                              'counter_name = ?', (ctr,)).fetchall()
+        shutil.rmtree(d, ignore_errors=True)
+        agg = {}
+        for name, grid, val in rows:
+            key = ('adam' if 'adam_kernel' in name else 'gemm', grid)
+            a = agg.setdefault(key, [0, 0.0])
+            a[0] += 1
+            a[1] += val * 1024.0
+        per[ctr] = agg
+    try:
+        f, w = per['FETCH_SIZE'], per['WRITE_SIZE']
+        k_adam = max((k for k in w if k[0] == 'adam'), key=lambda k: k[1])          # the generator's flat buffer
+        wcal = 12.0 * k_adam[1] / (w[k_adam][1] / w[k_adam][0])
+        fcal = 16.0 * k_adam[1] / (2.0 * f[k_adam][1] / f[k_adam][0])
+        k_gemm = max((k for k in f if k[0] == 'gemm'), key=lambda k: f[k][0])        # most frequent grid = the F(2x2,3x3) GEMMs
+        fetch = 2.0 * f[k_gemm][1] / f[k_gemm][0]
+        write = wcal * w[k_gemm][1] / max(w[k_gemm][0], 1)
+        return ({'bytes_per_launch': fetch + write, 'fetch_bytes_per_launch': fetch, 'write_bytes_per_launch': write,
+                 'launches_sampled': f[k_gemm][0], 'grid': k_gemm[1], 'write_calibration': wcal,
+                 'fetch_check_on_adam': fcal, 'seconds': round(time.perf_counter() - t_start, 1)},
+                'MEASURED IN THIS RUN: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two child passes of bench.py --steps 2, eager '
+                'launches), FETCH x2 (gfx950), WRITE calibrated on adam_kernel (x%.3f; the x2 FETCH rule reproduces its 16 B / '
+                'parameter to x%.3f)' % (wcal, fcal))
+    except Exception as e:
+        return None, 'no live measurement: could not reduce the counter tables: %r' % (e,)
+
+
 # what the profiler kinds are, as template instantiations (include/sg2im_hip.h, csrc/igemm.hip)
 KERNEL_INSTANTIATIONS = {
-    'wino_bgemm_t128': 'igemm_kernel<TileCfg<128,128,2,2,1>, LoadKContig<128,true,false>, LoadKContig<128,true,false>, EpRowMajorPlain>: '
+    'wino_bgemm_t128': 'igemm_kernel<TileCfg<128,128,2,2,2>, LoadKContig<128,true,false>, LoadKContig<128,true,false>, EpRowMajorPlain>: '
                        'the 16 batched dense GEMMs of a Winograd F(2x2,3x3) conv (ResnetBlock / VGG19 convs), batch-major '
-                       'tile order, 32-deep k-tiles, software-pipelined fragment reads',
+                       'tile order, 32-deep k-tiles, buffer loads with the k advance in the SGPR offset, software-pipelined '
+                       'fragment reads, LDS stores of the next tile interleaved with the MFMAs of phase 0',
     'wino24_bgemm_t128': 'the same instantiation as wino_bgemm_t128: the 25 (x k-chunks) batched dense GEMMs of a Winograd F(2x2,4x4) '
                          'conv (stride-1 4x4 convs of the PatchGANs, K = 256 / 512 channels)',
     'wino_bgemm_t64': 'igemm_kernel<TileCfg<64,64,2,1>, LoadKContig<64,true,false>, LoadKContig<64,true,false>, EpRowMajor>: '
@@ -271,17 +343,32 @@ def main():
         if mm:
             name, v = max(mm.items(), key=lambda kv: kv[1]['ms'])
             ach = v['flops'] / (v['ms'] * 1e-3) / 1e12 if v['ms'] > 0 else 0.0
-            traffic, tsrc = None, None
-            for tname in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json'):
-                tpath = os.path.join(ROOT, 'profiles', tname)
-                if os.path.isfile(tpath):
-                    tab = json.load(open(tpath)).get(name)
-                    if tab:
-                        traffic = tab.get('bytes_per_launch')
-                        tsrc = 'STATIC (not measured in this run): profiles/%s -- %s' % (tname, tab.get('source'))
-                        break
+            traffic, tsrc, tdetail = None, None, None
+            if a.pmc == 'auto' and world == 1:
+                tdetail, tsrc = measure_traffic(name)
+                if tdetail:
+                    traffic = tdetail['bytes_per_launch']
+            if traffic is None:
+                live_note = tsrc
+                for tname in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json'):
+                    tpath = os.path.join(ROOT, 'profiles', tname)
+                    if os.path.isfile(tpath):
+                        tab = json.load(open(tpath)).get(name)
+                        if tab:
+                            traffic = tab.get('bytes_per_launch')
+                            tsrc = 'STATIC (not measured in this run%s): profiles/%s -- %s' % (
+                                '; ' + live_note if live_note else '', tname, tab.get('source'))
+                            break
+            # algorithmic bytes of one launch of the dominant kernel (operands read once + result written once): the 16
+            # batched GEMMs of a ResnetBlock conv, C = 64 << 4 channels both sides, P = B (S / 32)^2 tiles of 2x2 outputs
+            alg = None
+            if name == 'wino_bgemm_t128':
+                Cc, P = 64 << 4, B * (S // 32) ** 2
+                alg = 4.0 * 16 * (Cc * Cc + P * Cc + Cc * P)
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': ach / F32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': tsrc,
+                               'traffic_detail': tdetail, 'algorithmic_bytes_per_launch': alg,
+                               'traffic_over_algorithmic': (traffic / alg) if (traffic and alg) else None,
                                'kernel': name, 'instantiation': KERNEL_INSTANTIATIONS.get(name, name),
                                'flops_counted': 'MACs of the non-padding tiles the launch computes (useful work)',
                                'launches': v['launches'], 'avg_us': 1e3 * v['ms'] / v['launches'],
