@@ -345,6 +345,11 @@ int sg_scale(float* p, float alpha, int64_t n, sgStream stream);
 /* y += alpha * x : a second gradient contribution to a parameter slice of the flat gradient buffer (the first one is
  * written in place by the weight-gradient kernels; replaces autograd's AccumulateGrad add, trainer.py:262,278,299,324) */
 int sg_axpy(float* y, const float* x, float alpha, int64_t n, sgStream stream);
+/* y += x ; x = 0 : folds a SPILL gradient buffer into the flat gradient buffer and clears it for the next step.  The k-th
+ * (k >= 2) contribution a parameter receives between zero_grad() and step() -- the real / wrong-texture passes of a
+ * discriminator, trainer.py:281-325 -- is written by its weight-gradient kernel straight into spill buffer k-2 (same layout as
+ * the gradient buffer); one launch per spill buffer and optimiser step replaces one temporary + sg_axpy per parameter and pass */
+int sg_add_clear(float* y, float* x, int64_t n, sgStream stream);
 /* out = a + b : the shortcut add of build_cnn's 'R' residual blocks (reference layers.py:84-118);
  * out = alpha * a * b : nn.Dropout's mask multiply (layers.py:230, build_mlp(dropout=...)); the mask itself is drawn by the host
  * framework's device RNG.  Neither is on the benchmark path. */

@@ -136,6 +136,21 @@ __global__ void axpy4_kernel(float4* __restrict__ y, const float4* __restrict__ 
   y[i] = u;
 }
 
+// y += x ; x = 0 (float4 form: the flat gradient buffers are 256-byte aligned and 64-element padded)
+__global__ void add_clear4_kernel(float4* __restrict__ y, float4* __restrict__ x, size_t n4) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 u = y[i];
+  const float4 v = x[i];
+  u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
+  y[i] = u;
+  x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ void add_clear_kernel(float* __restrict__ y, float* __restrict__ x, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { y[i] += x[i]; x[i] = 0.f; }
+}
+
 // total = sum_i w[i] * *term[i] in index order (one thread: <= 32 terms), and its dual g[i] = w[i] * gout
 struct WsumArgs { const float* term[SG_WSUM_MAX]; float w[SG_WSUM_MAX]; int n; };
 __global__ void wsum_fwd_kernel(WsumArgs a, float* __restrict__ out) {
@@ -232,6 +247,18 @@ extern "C" int sg_axpy(float* y, const float* x, float alpha, int64_t n, sgStrea
   else
     hipLaunchKernelGGL(axpy_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, s, y, x, alpha, (size_t)n);
   SG_LAUNCH_CHECK("sg_axpy");
+  return 0;
+}
+
+extern "C" int sg_add_clear(float* y, float* x, int64_t n, sgStream stream) {
+  SG_ARG_CHECK(y && x && n >= 0, "sg_add_clear: bad arguments");
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (n % 4 == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x)) & 15) == 0)
+    hipLaunchKernelGGL(add_clear4_kernel, dim3(sg_cdiv(n / 4, 256)), dim3(256), 0, s, (float4*)y, (float4*)x, (size_t)(n / 4));
+  else
+    hipLaunchKernelGGL(add_clear_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, s, y, x, (size_t)n);
+  SG_LAUNCH_CHECK("sg_add_clear");
   return 0;
 }
 

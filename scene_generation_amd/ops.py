@@ -95,8 +95,9 @@ def _call(name, *args):
 # A parameter owned by a FusedAdam lives in a flat buffer and so does its gradient (optim.FlatParams).  Returning a
 # gradient tensor from backward makes autograd ADD it into that slice with one ATen launch per parameter per backward
 # (~300 launches and 3 passes over the 765 MB generator gradient per step).  Instead the weight-gradient kernels write
-# straight into the slice: the first contribution after zero_grad() overwrites (the slice is zero), later ones go through a
-# temporary + sg_axpy.  backward then returns None for that input and notifies the optimiser (touched flag, DP reducer).
+# straight into the slice: the first contribution after zero_grad() overwrites (the slice is zero), the k-th goes to the same
+# slice of the optimiser's spill buffer k-2 (folded in by optimizer.step(); inside a hipGraph capture: temporary + sg_axpy).
+# backward then returns None for that input and notifies the optimiser (touched flag, DP reducer).
 _SINKS = {}
 
 
@@ -155,6 +156,10 @@ class GradOut(object):
             self.buf, self.mode = torch.empty_like(param), 2
         elif (_CAPTURE[0] == 0) if _CAPTURE is not None else (not sk.opt()._touched[sk.i]):
             self.buf, self.mode = sk.view, 0               # first contribution since zero_grad(): write in place
+        elif _CAPTURE is None and hasattr(sk.opt(), 'spill_view'):
+            # k-th contribution (k >= 2: a discriminator's real / wrong-texture pass): written in place into the optimiser's
+            # spill buffer k-2, which optimizer.step() folds into the gradient with ONE launch (optim.FusedAdam._fold_spill)
+            self.buf, self.mode = sk.opt().spill_view(sk.i), 3
         else:
             self.buf, self.mode = torch.empty_like(param), 1
 
@@ -162,9 +167,10 @@ class GradOut(object):
         if self.mode == 2:
             return self.buf
         sk = self.sink
-        if self.mode == 1:
+        if self.mode in (1, 3):
             for f in getattr(sk.opt(), 'late_listeners', ()):      # e.g. GradReducer.late_contribution: may refuse
                 f(sk.i)
+        if self.mode == 1:
             _call('sg_axpy', _p(sk.view), _p(self.buf), 1.0, self.buf.numel(), _stream())
         if _CAPTURE is not None:
             _CAPTURE[1].append((sk.opt(), sk.i))
@@ -1661,6 +1667,13 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
 def fill_(t, value):
     _call('sg_fill', _p(t), float(value), t.numel(), _stream())
     return t
+
+
+def add_clear_(y, x):
+    """y += x ; x = 0 (optim.FusedAdam._fold_spill)"""
+    assert y.numel() == x.numel()
+    _call('sg_add_clear', _p(y), _p(x), y.numel(), _stream())
+    return y
 
 
 def scale_(t, alpha):

@@ -69,6 +69,10 @@ class FusedAdam:
         n = len(self.fp.params)
         self.steps = [0] * n
         self._touched = [False] * n
+        # spill buffers: gradient contributions 2, 3, ... a parameter receives between zero_grad() and step() (ops.GradOut),
+        # same layout as the gradient buffer, all-zero outside a step
+        self._contrib = [0] * n
+        self._spill, self._spill_used, self._fold_queued = [], 0, False
         self.pre_step_hooks = []          # e.g. GradReducer.wait
         self.zero_grad_hooks = []         # e.g. GradReducer.begin_step
         self.grad_listeners = []          # callables(i): parameter i just received (a contribution to) its gradient
@@ -87,8 +91,32 @@ class FusedAdam:
 
     def _on_grad(self, i):
         self._touched[i] = True
+        self._contrib[i] += 1
         for f in self.grad_listeners:
             f(i)
+
+    def spill_view(self, i):
+        """where the NEXT contribution to parameter ``i`` (which already has at least one) is written.  Only valid while a
+        backward is running (ops.GradOut calls it from inside autograd Functions)."""
+        k = max(self._contrib[i], 1) - 1
+        while len(self._spill) <= k:
+            self._spill.append(torch.zeros_like(self.fp.grad))
+        self._spill_used = max(self._spill_used, k + 1)
+        if not self._fold_queued:
+            # fold when the backward that is running right now ends: ``p.grad`` is complete as soon as ``.backward()`` returns
+            # (gradient clipping, logging between backward and step see what torch would show them)
+            from torch.autograd import Variable
+            self._fold_queued = True
+            Variable._execution_engine.queue_callback(self._fold_spill)
+        p, o = self.fp.params[i], self.fp.offsets[i]
+        return self._spill[k][o:o + p.numel()].view(p.shape)
+
+    def _fold_spill(self):
+        """grad = ((grad + spill[0]) + spill[1]) + ...: the order the per-parameter adds had; clears the spill buffers"""
+        self._fold_queued = False
+        for k in range(self._spill_used):
+            ops.add_clear_(self.fp.grad, self._spill[k])
+        self._spill_used = 0
 
     @property
     def step_count(self):
@@ -101,9 +129,14 @@ class FusedAdam:
 
     def zero_grad(self, set_to_none=False):
         streams.join_all(self.fp.grad.device)      # weight-gradient kernels of side streams write this buffer (streams.py)
+        if self._spill_used:                        # contributions of a backward whose step never came: dropped with the rest
+            for k in range(self._spill_used):
+                ops.fill_(self._spill[k], 0.0)
+            self._spill_used = 0
         ops.fill_(self.fp.grad, 0.0)
         self.fp.attach_grads()
         self._touched = [False] * len(self.fp.params)
+        self._contrib = [0] * len(self.fp.params)
         for h in self.zero_grad_hooks:
             h()
 
@@ -113,6 +146,7 @@ class FusedAdam:
 
     def step(self):
         streams.join_all(self.fp.grad.device)      # (see zero_grad)
+        self._fold_spill()
         for h in self.pre_step_hooks:
             h()
         self.fp.attach_grads()
