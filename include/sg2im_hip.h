@@ -5,7 +5,7 @@
  * The reference (ashual/scene_generation) has no FFI: its hot path dispatches PyTorch ops.  Each entry
  * point below replaces the op group a reference call site dispatches (cited per function, paths
  * relative to /root/reference/scene_generation/).  The only caller is the Python host layer
- * (scene_generation_amd/ops.py, ctypes); INTEGRATION.md shows the binding.
+ * (scene_generation_amd/ops/, ctypes); INTEGRATION.md shows the binding.
  *
  * Conventions
  *   - caller owns every buffer (incl. workspace); no allocation, no host sync, no stream creation inside
