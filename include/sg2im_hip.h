@@ -127,13 +127,19 @@ size_t sg_conv2d_wino_ws_bytes(const sgConvDesc* d);
    roles swapped -- what sg_conv2d_wino_dgrad of the SAME conv multiplies with (ut_saved): the weights are transformed once
    per step instead of once per direction. */
 size_t sg_conv2d_wino_ut_floats(const sgConvDesc* d);
+/* v_save / ytp_save (optional, sg_conv2d_wino_v_floats(d) / sg_conv2d_wino_ytp_floats(d) floats; 0 = not applicable to this
+   desc): the forward keeps its input transform V[16][P][C1], the data gradient its gradient transform Ytp[16][P][Cout], and
+   sg_conv2d_wino_wgrad of the SAME conv in the same step, given both (v_saved, ytp_saved), runs its 16 GEMMs straight on them
+   instead of transforming x and gy a second time. */
+size_t sg_conv2d_wino_v_floats(const sgConvDesc* d);
+size_t sg_conv2d_wino_ytp_floats(const sgConvDesc* d);
 int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                       float slope, float* ut_save, void* ws, size_t ws_bytes, sgStream stream);
-int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, void* ws, size_t ws_bytes,
-                         sgStream stream);
+                       float slope, float* ut_save, float* v_save, void* ws, size_t ws_bytes, sgStream stream);
+int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, const float* v_saved,
+                         const float* ytp_saved, void* ws, size_t ws_bytes, sgStream stream);
 /* gx [N, C1, H, W] (all input channels): Winograd on the padded gradient grid + reflection fold */
 int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, const float* ut_saved,
-                         void* ws, size_t ws_bytes, sgStream stream);
+                         float* ytp_save, void* ws, size_t ws_bytes, sgStream stream);
 /* Winograd F(2x2, 4x4) for the stride-1 4x4 convs of the PatchGANs (reference discriminators.py:221-228:
    nn.Conv2d(nf_prev, nf, kernel_size=4, stride=1, padding=2), 256 -> 512 channels: the largest layer of the discriminator steps):
    KS 4, stride 1, zero padding 0..3, one source, C1 and Cout multiples of 128, >= 256 output tiles.  25 multiplies per 2x2

@@ -774,6 +774,21 @@ void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, in
 }
 
 
+// T[m][xi*Cc + c] = sum_p Ytp[xi][p][m] * V[xi][p][c]: the Winograd weight gradient straight from the operands the forward (V) and
+// the adjoint data gradient (Ytp) of the same conv already built -- both tile-major, i.e. x-contiguous for a GEMM over p
+// (LoadXContigS): no second input / gradient transform (2 launches and 2 x 41 MB per ResnetBlock conv saved)
+void wino_bgemm_x(const float* Ytp, const float* V, float* T, int M, int Cc, int P, double flops, hipStream_t s) {
+  sgk::t_alg_bytes = 4.0 * 16 * ((double)M * P + (double)Cc * P + (double)M * Cc);
+  t_batch = BatchInfo{}; t_batch.cols_per_batch = Cc; t_batch.nbatch = 16; t_batch.a_stride = P * M; t_batch.b_stride = P * Cc;
+  t_batch.batch_major = 1;
+  {
+    SgProfScope prof(SG_K_WINO_GEMM_128, s, flops, 0);
+    launch_cfg<CfgDI128>(LoadXContigS<128>{Ytp, M, 0}, LoadXContigS<128>{V, Cc, Cc}, EpRowMajorPlain{T, 16 * Cc}, M, 16 * Cc, P, 1, s);
+  }
+  t_batch = BatchInfo{};
+}
+
+
 // ================================================================================================
 // Winograd F(2x2, 4x4) for the stride-1 4x4 convs of the PatchGANs (discriminators.py:221-228: Conv2d(256, 512, 4, 1, 2), the
 // largest single layer of the discriminator steps): 25 multiplies per 2x2 output tile and channel pair instead of 64.
@@ -1143,8 +1158,19 @@ extern "C" size_t sg_conv2d_wino_ut_floats(const sgConvDesc* d) {
   return (wino_adjoint_shape(d) && d->C1 % 32 == 0 && d->Cout % 32 == 0) ? (size_t)16 * d->C1 * d->Cout : 0;
 }
 
+// floats of the input transform V / the gradient transform Ytp a conv can hand from its forward / data gradient to its weight
+// gradient (0: that conv's weight gradient rebuilds its operands)
+extern "C" size_t sg_conv2d_wino_v_floats(const sgConvDesc* d) {
+  if (!sg_opt(SG_OPT_WINO_REUSE) || !wino_adjoint_shape(d)) return 0;
+  return (size_t)16 * d->N * (d->H / 2) * (d->W / 2) * d->C1;
+}
+extern "C" size_t sg_conv2d_wino_ytp_floats(const sgConvDesc* d) {
+  if (!sg_opt(SG_OPT_WINO_REUSE) || !wino_adjoint_shape(d)) return 0;
+  return (size_t)16 * d->N * (d->H / 2) * (d->W / 2) * d->Cout;
+}
+
 extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, const float* ut_saved,
-                                    void* ws, size_t ws_bytes, sgStream stream) {
+                                    float* ytp_save, void* ws, size_t ws_bytes, sgStream stream) {
   SG_ARG_CHECK(wino_ok(d), "sg_conv2d_wino_dgrad: unsupported desc");
   SG_ARG_CHECK(gy && w && gx && ws && ws_bytes >= sg_conv2d_wino_ws_bytes(d), "sg_conv2d_wino_dgrad: bad arguments");
   hipStream_t s = (hipStream_t)stream;
@@ -1156,8 +1182,9 @@ extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const 
     const int HW = d->H * d->W;
     const size_t P = (size_t)d->N * (d->H / 2) * (d->W / 2);
     float* UTw = reinterpret_cast<float*>(ws);      // [16][C1][Cout]
-    float* Ytp = UTw + 16 * (size_t)M * K;          // [16][P][Cout]
-    float* G = Ytp + 16 * P * K;                    // [P][16][C1]
+    float* Ytp_ws = UTw + 16 * (size_t)M * K;       // [16][P][Cout]
+    float* G = Ytp_ws + 16 * P * K;                 // [P][16][C1]
+    float* Ytp = ytp_save ? ytp_save : Ytp_ws;      // kept for the weight gradient of the same conv when the caller wants it
     const float* UT = ut_saved;                     // built by the forward pass of this step (same weights) when given
     if (UT == nullptr) {
       SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 25.0 * (double)M * K);
@@ -1179,6 +1206,7 @@ extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const 
     SG_LAUNCH_CHECK("sg_conv2d_wino_dgrad");
     return 0;
   }
+  SG_ARG_CHECK(ytp_save == nullptr, "sg_conv2d_wino_dgrad: ytp_save given but this desc does not run the adjoint form");
   const int TH = LH / 2 + (refl ? 1 : 0), TW = LW / 2 + (refl ? 1 : 0);
   const size_t Pd = wino_dgrad_tiles(d);
   float* U = reinterpret_cast<float*>(ws);          // [16][C1][Cout]
@@ -1197,7 +1225,7 @@ extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const 
 }
 
 extern "C" int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const float* w, const float* bias, float* y, int act,
-                                  float slope, float* ut_save, void* ws, size_t ws_bytes, sgStream stream) {
+                                  float slope, float* ut_save, float* v_save, void* ws, size_t ws_bytes, sgStream stream) {
   SG_ARG_CHECK(wino_ok(d), "sg_conv2d_wino_fwd: unsupported desc");
   SG_ARG_CHECK(x && w && y && ws && ws_bytes >= sg_conv2d_wino_ws_bytes(d), "sg_conv2d_wino_fwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
@@ -1205,8 +1233,10 @@ extern "C" int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const flo
   const int LH = d->H * d->upsample, LW = d->W * d->upsample;
   const size_t P = (size_t)d->N * (LH / 2) * (LW / 2);
   float* U = reinterpret_cast<float*>(ws);
-  float* V = U + 16 * (size_t)M * C;
-  float* Mx = V + 16 * P * C;
+  float* V_ws = U + 16 * (size_t)M * C;
+  float* Mx = V_ws + 16 * P * C;
+  SG_ARG_CHECK(v_save == nullptr || sg_conv2d_wino_v_floats(d) > 0, "sg_conv2d_wino_fwd: v_save given but unused by this desc");
+  float* V = v_save ? v_save : V_ws;               // [16][P][C1]: kept for the weight gradient when the caller wants it
   SG_ARG_CHECK(ut_save == nullptr || sg_conv2d_wino_ut_floats(d) > 0, "sg_conv2d_wino_fwd: ut_save given but unused by this desc");
   { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * (25.0 + (ut_save ? 16.0 : 0.0)) * (double)M * C);
     const bool wrote = wino_weight(w, U, M, C, 0, s, ut_save);
@@ -1219,8 +1249,8 @@ extern "C" int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const flo
   return 0;
 }
 
-extern "C" int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, void* ws, size_t ws_bytes,
-                                    sgStream stream) {
+extern "C" int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const float* x, float* gw, const float* v_saved,
+                                    const float* ytp_saved, void* ws, size_t ws_bytes, sgStream stream) {
   SG_ARG_CHECK(wino_ok(d), "sg_conv2d_wino_wgrad: unsupported desc");
   SG_ARG_CHECK(gy && x && gw && ws && ws_bytes >= sg_conv2d_wino_ws_bytes(d), "sg_conv2d_wino_wgrad: bad arguments");
   hipStream_t s = (hipStream_t)stream;
@@ -1228,6 +1258,14 @@ extern "C" int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const 
   const int LH = d->H * d->upsample, LW = d->W * d->upsample;
   const size_t P = (size_t)d->N * (LH / 2) * (LW / 2);
   float* T = reinterpret_cast<float*>(ws);          // [M][16][C]
+  if (v_saved && ytp_saved) {
+    // operands already built by the forward (V) and the adjoint data gradient (Ytp) of this conv in this step
+    SG_ARG_CHECK(sg_conv2d_wino_v_floats(d) > 0 && P % 32 == 0, "sg_conv2d_wino_wgrad: saved operands given but unused by this desc");
+    wino_bgemm_x(ytp_saved, v_saved, T, M, C, (int)P, 2.0 * M * (double)C * 16.0 * P, s);
+    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 25.0 * (double)M * C); hipLaunchKernelGGL(wino_wgrad_output_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, (const float*)T, gw, M, C); }
+    SG_LAUNCH_CHECK("sg_conv2d_wino_wgrad");
+    return 0;
+  }
   float* Vp = T + 16 * (size_t)M * C;               // [16][C][P]
   float* Yt = Vp + 16 * P * C;                      // [16][M][P]
   { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * C * d->H * d->W + 16.0 * (double)P * C)); hipLaunchKernelGGL(wino_input_kernel<1>, dim3(sg_cdiv(P * C, 256)), dim3(256), 0, s, x, Vp, d->N, C, LH, LW, LH / 2, LW / 2, -1,

@@ -279,6 +279,38 @@ struct LoadXContig {
   __device__ __forceinline__ void store(const Stage& st, float* T) const { store_krun<ROWS>(T, xl_, kr_, st.r, st.ok); }
 };
 
+// The same operand form (x contiguous: elem(x, k) = base[k*ld + x]) for FULL tiles (X % BX == 0, K % 16 == 0), all addressing
+// out of the vector ALU: the lane's byte offset x*4 is fixed for the whole k-loop and the k row -- wave-uniform, because the 64
+// lanes of a wave own 64 consecutive x of the same ROWS k rows -- travels in the SGPR offset operand of the buffer load.  Batched
+// launches (Winograd weight gradient from the forward's V[xi][p][c] and the data gradient's Ytp[xi][p][m]: both "pixel-major",
+// i.e. x-contiguous for a GEMM whose k axis is the tile index p): batch b starts b*stride floats further and ``cols`` columns
+// later on the x axis.
+template <int BX>
+struct LoadXContigS {
+  const float* base; int ld; int cols;          // cols: columns per batch when the x axis is the batched (B operand) one, else 0
+  static constexpr int LDS_INTS = 0;
+  static constexpr int ROWS = BX * BK / 256;
+  struct Stage { float r[ROWS]; };
+  int xl_, kr_, xsub_ = 0;
+  unsigned voff_, ld4_;
+  __device__ __forceinline__ void set_batch(int b, int stride, int) { base += (size_t)b * (size_t)stride; xsub_ = b * cols; }
+  __device__ __forceinline__ void init(int x0, int tid, int*, int, int) {
+    xl_ = tid % BX;
+    kr_ = __builtin_amdgcn_readfirstlane((tid / BX) * ROWS);
+    voff_ = (unsigned)(x0 - xsub_ + xl_) * 4u;
+    ld4_ = (unsigned)ld * 4u;
+  }
+  __device__ __forceinline__ void prefetch(Stage&, int) const {}
+  __device__ __forceinline__ void load(Stage& st, int k0, int) const {
+    const __amdgpu_buffer_rsrc_t rs = sg_rsrc(base);
+    const unsigned sb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(k0 + kr_) * ld4_));
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i)
+      st.r[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff_, (int)(sb + (unsigned)i * ld4_), 0));
+  }
+  __device__ __forceinline__ void store(const Stage& st, float* T) const { store_krun<ROWS, false>(T, xl_, kr_, st.r, 0u); }
+};
+
 // offset of tap (kh, kw) inside one stored channel plane for anchor (ah, aw); -1 = contributes zero
 template <int MODE>
 __device__ __forceinline__ int tap_offset(const Gather& g, int ah, int aw, int kh, int kw) {

@@ -49,8 +49,12 @@ class Conv2dFn(Function):
             # pass over the weights (they do not change between this forward and its backward)
             utn = _q(d, 'sg_conv2d_wino_ut_floats') if ctx.needs_input_grad[0] else 0
             ctx.wino_ut = torch.empty(utn, dtype=torch.float32, device=x1.device) if utn else None
+            # ... and the weight gradient multiplies with the input transform this forward builds anyway: keep it (33.5 MB per
+            # ResnetBlock conv at the benchmark shape) instead of transforming x a second time in the backward
+            vn = _q(d, 'sg_conv2d_wino_v_floats') if (ctx.needs_input_grad[0] and ctx.needs_input_grad[2]) else 0
+            ctx.wino_v = torch.empty(vn, dtype=torch.float32, device=x1.device) if vn else None
             _call('sg_conv2d_wino_fwd', d._ref, _p(x1), _p(weight), _p(bias), _p(y), act, slope, _p(ctx.wino_ut),
-                  _p(workspace(wsb, x1.device)), wsb, _stream())
+                  _p(ctx.wino_v), _p(workspace(wsb, x1.device)), wsb, _stream())
         elif ctx.smallm:              # <= 4 output channels (the RGB head): direct vector-ALU kernel, no MFMA tile waste
             _call('sg_conv2d_smallm_fwd', d._ref, _p(x1), _p(weight), _p(bias), _p(y), act, slope, _stream())
         elif sparse is not None:    # (chan_list [N, L] int32, chan_cnt [N] int32): see sg_conv2d_fwd_sparse
@@ -92,6 +96,7 @@ class Conv2dFn(Function):
         need_b = has_bias and ctx.needs_input_grad[3] and _wants_grad(ctx.bias_ref)
         gx1 = gx2 = gw = gb = None
         dev = gy.device
+        wino_keep = {'ytp': None}
         if need_x1 or need_x2:
             wsb = _q(d, 'sg_conv2d_ws_bytes', 1)
             ws = workspace(wsb, dev)
@@ -114,8 +119,11 @@ class Conv2dFn(Function):
                 if ctx.wino and c0 == 0 and c1 == d.C1:     # Winograd on the padded gradient grid + reflection fold
                     out = torch.empty(d.N, d.C1, d.H, d.W, dtype=torch.float32, device=dev)
                     fb = _q(d, 'sg_conv2d_wino_ws_bytes')
+                    # the gradient transform is the other operand of this conv's weight gradient: keep it when that follows
+                    yn = _q(d, 'sg_conv2d_wino_ytp_floats') if (need_w and getattr(ctx, 'wino_v', None) is not None) else 0
+                    wino_keep['ytp'] = torch.empty(yn, dtype=torch.float32, device=dev) if yn else None
                     _call('sg_conv2d_wino_dgrad', d._ref, _p(gy), _p(weight), _p(out), _p(getattr(ctx, 'wino_ut', None)),
-                          _p(workspace(fb, dev)), fb, s)
+                          _p(wino_keep['ytp']), _p(workspace(fb, dev)), fb, s)
                     return out
                 if folded:       # ReflectionPad(1)+3x3: gradient straight on the H x W grid (no padded grid, no fold pass)
                     out = torch.empty(d.N, c1 - c0, d.H, d.W, dtype=torch.float32, device=dev)
@@ -164,7 +172,9 @@ class Conv2dFn(Function):
                 elif ctx.wino:
                     wsb = max(_q(d, 'sg_conv2d_wino_ws_bytes'), _L().sg_channel_sum_ws_bytes(d.Cout))
                     ws = workspace(wsb, dev)
-                    _call('sg_conv2d_wino_wgrad', d._ref, _p(gy), _p(x1), _p(gw), _p(ws), wsb, s)
+                    ytp = wino_keep['ytp']
+                    _call('sg_conv2d_wino_wgrad', d._ref, _p(gy), _p(x1), _p(gw),
+                          _p(ctx.wino_v) if ytp is not None else None, _p(ytp), _p(ws), wsb, s)
                     if gb is not None:
                         _call('sg_channel_sum', _p(gy), _p(gb), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb, s)
                 elif ctx.smallm:
