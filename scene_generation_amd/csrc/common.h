@@ -54,6 +54,7 @@ enum SgOpt {
   SG_OPT_INSTNORM_REG,    // register-resident InstanceNorm
   SG_OPT_WGRAD_XCD,       // weight-gradient GEMMs: k-chunks pinned to XCDs (their tiles share the chunk's pixels in ONE L2)
   SG_OPT_WINO_REUSE,      // Winograd weight gradient from the forward's V and the data gradient's Ytp (no second transforms)
+  SG_OPT_WINO_FOLD_CELLS, // four-wave cell-gather form of the adjoint Winograd output fold (0: one thread per channel walks the tiles)
   SG_OPT_WINO_PIPE,       // main loop of the dense Winograd GEMMs: 1 = stores at the top of the iteration, 2 = interleaved with phase 0
   SG_OPT_COUNT
 };

@@ -690,6 +690,78 @@ __global__ void __launch_bounds__(64) wino_patch_fold_kernel(const float* __rest
   }
 }
 
+// The same result from the receiving side, four waves per workgroup: thread (channel c, group g) owns the 2x2 CELLS g, g+4, ...
+// of the padded plane (cell (ci, cj) = padded rows 2ci..2ci+1, columns 2cj..2cj+1) and gathers each cell from the <= 4 tiles
+// whose 4x4 patch covers it -- tile (ti, tj) contributes the sub-block (2(ci-ti), 2(cj-tj)) of B G B^T -- in ascending tile
+// order, i.e. with exactly the additions, in exactly the order, of the overlap-add above (bit-identical).  No two threads
+// touch the same accumulator, so the tiles need not be walked serially by ONE thread per channel: 4x the waves per workgroup
+// and 3 workgroups per CU instead of 2 single-wave ones (the kernel is latency-bound: 22 -> ~8 us at 8x8 planes).  Every
+// tile is read by its four cells (L1 / L2 hits).
+__global__ void __launch_bounds__(256) wino_patch_fold_cells_kernel(const float* __restrict__ G, float* __restrict__ gx, int N, int C,
+                                                                   int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int HW = H * W, PW = W + 2, PP = (H + 2) * PW, TH = H / 2, TW = W / 2, CW = TW + 1, NCELL = (TH + 1) * CW;
+  const int n = blockIdx.y, c0 = blockIdx.x * 64, c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  float* acc = lds + c * (PP + 1);
+  float* stage = lds + 64 * (PP + 1);              // [64][HW + 1]
+  const size_t ld = (size_t)16 * C;
+  const float* base = G + (size_t)n * TH * TW * ld + c0 + c;
+  for (int q = g; q < NCELL; q += 4) {
+    const int ci = q / CW, cj = q - ci * CW;
+    float o[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+    for (int dti = 1; dti >= 0; --dti) {
+#pragma unroll
+      for (int dtj = 1; dtj >= 0; --dtj) {
+        const int ti = ci - dti, tj = cj - dtj;
+        if (ti < 0 || ti >= TH || tj < 0 || tj >= TW) continue;          // (wave-uniform: q depends on the wave only)
+        const float* src = base + (size_t)(ti * TW + tj) * ld;
+        float v[4][4];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i >> 2][i & 3] = src[(size_t)i * C];
+        float r[2][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (dti == 0) { r[0][u] = v[0][u]; r[1][u] = v[1][u] - v[2][u] + v[3][u]; }           // patch rows 0, 1
+          else { r[0][u] = -v[0][u] + v[1][u] + v[2][u]; r[1][u] = -v[3][u]; }                  // patch rows 2, 3
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          if (dtj == 0) { o[a][0] += r[a][0]; o[a][1] += r[a][1] - r[a][2] + r[a][3]; }         // patch columns 0, 1
+          else { o[a][0] += -r[a][0] + r[a][1] + r[a][2]; o[a][1] += -r[a][3]; }                // patch columns 2, 3
+        }
+      }
+    }
+    float* dst = acc + (2 * ci) * PW + 2 * cj;
+    dst[0] = o[0][0]; dst[1] = o[0][1]; dst[PW] = o[1][0]; dst[PW + 1] = o[1][1];
+  }
+  __syncthreads();
+  float* so = stage + c * (HW + 1);
+  for (int a = g; a < H; a += 4) {
+    for (int b = 0; b < W; ++b) {
+      float v = acc[(a + 1) * PW + b + 1];
+      const int ra = a == 1 ? 0 : -1, rb = a == H - 2 ? H + 1 : -1;        // padded rows folded onto row a
+      const int ca = b == 1 ? 0 : -1, cb = b == W - 2 ? W + 1 : -1;        // padded columns folded onto column b
+      if (ra >= 0) v += acc[ra * PW + b + 1];
+      if (rb >= 0) v += acc[rb * PW + b + 1];
+      if (ca >= 0) v += acc[(a + 1) * PW + ca];
+      if (cb >= 0) v += acc[(a + 1) * PW + cb];
+      if (ra >= 0 && ca >= 0) v += acc[ra * PW + ca];
+      if (ra >= 0 && cb >= 0) v += acc[ra * PW + cb];
+      if (rb >= 0 && ca >= 0) v += acc[rb * PW + ca];
+      if (rb >= 0 && cb >= 0) v += acc[rb * PW + cb];
+      so[a * W + b] = v;
+    }
+  }
+  __syncthreads();
+  float* dstg = gx + ((size_t)n * C + c0) * HW;
+  for (int i = threadIdx.x * 4; i < 64 * HW; i += 1024) {
+    const int ch = i / HW, px = i - ch * HW;
+    const float* sp = stage + ch * (HW + 1) + px;
+    *reinterpret_cast<float4*>(dstg + i) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+  }
+}
+
 // gw[m][c][3][3] = G^T T G,  T[m][xi*C + c]
 __global__ void wino_wgrad_output_kernel(const float* __restrict__ T, float* __restrict__ gw, int M, int C) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1202,7 +1274,13 @@ extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const 
       const size_t lds = (size_t)64 * ((d->H + 2) * (d->W + 2) + 1 + HW + 1) * sizeof(float);
       if (lds > 48 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_patch_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(wino_patch_fold_kernel, dim3(M / 64, d->N), dim3(64), lds, s, (const float*)G, gx, d->N, M, d->H, d->W); }
+      if (sg_opt(SG_OPT_WINO_FOLD_CELLS)) {
+        if (lds > 48 * 1024)
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_patch_fold_cells_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(wino_patch_fold_cells_kernel, dim3(M / 64, d->N), dim3(256), lds, s, (const float*)G, gx, d->N, M, d->H, d->W);
+      } else {
+        hipLaunchKernelGGL(wino_patch_fold_kernel, dim3(M / 64, d->N), dim3(64), lds, s, (const float*)G, gx, d->N, M, d->H, d->W);
+      } }
     SG_LAUNCH_CHECK("sg_conv2d_wino_dgrad");
     return 0;
   }
