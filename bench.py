@@ -100,7 +100,7 @@ PMC_KERNELS = {
 }
 
 
-def measure_traffic(kind, timeout_s=300):
+def measure_traffic(kind, timeout_s=150):
     """HBM-side bytes per launch of the kernel behind profiler kind ``kind``, measured NOW: two child runs of this script under
     ``rocprofv3 --pmc <counter> --kernel-trace`` (FETCH_SIZE and WRITE_SIZE need separate passes), counters restricted to that
     kernel and adam_kernel.  Corrections exactly as /opt/skills/guides/MI355X_MICROARCH.md prescribes (tools/pmc_db_summary.py):
@@ -125,14 +125,25 @@ def measure_traffic(kind, timeout_s=300):
                '--no_prof', '--cpu_baseline', 'off', '--pmc', 'off']
         env = dict(os.environ, TMPDIR='/tmp', SG_GRAPHS='0')      # eager launches: every dispatch is visible to the counters
         try:
-            r = subprocess.run(cmd, cwd='/tmp', env=env, timeout=timeout_s, capture_output=True, text=True)
+            # own process group: on a timeout the whole tree (rocprofv3 AND the python it started) is killed, nothing is left
+            # running on the GPU next to the legs that follow
+            pr = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                                  start_new_session=True)
+            try:
+                _, err = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.communicate()
+                raise
+            rc = pr.returncode
         except Exception as e:
             shutil.rmtree(d, ignore_errors=True)
             return None, 'no live measurement: rocprofv3 %s pass failed: %r' % (ctr, e)
         dbs = glob.glob(os.path.join(d, '**', '*.db'), recursive=True)
-        if r.returncode != 0 or not dbs:
+        if rc != 0 or not dbs:
             shutil.rmtree(d, ignore_errors=True)
-            return None, 'no live measurement: rocprofv3 %s pass rc=%d: %s' % (ctr, r.returncode, (r.stderr or '')[-300:])
+            return None, 'no live measurement: rocprofv3 %s pass rc=%d: %s' % (ctr, rc, (err or '')[-300:])
         rows = sqlite3.connect(dbs[0]).execute('select kernel_name, grid_size, value from counters_collection where '
                                               'counter_name = ?', (ctr,)).fetchall()
         shutil.rmtree(d, ignore_errors=True)

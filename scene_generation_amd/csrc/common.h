@@ -37,6 +37,8 @@ enum SgOpt {
   SG_OPT_T128_MIN,        // 128x128 tiles from this many tiles on
   SG_OPT_TILE3,           // allow 64x128 tiles
   SG_OPT_TILE3_MIN,       // ... from this many tiles on
+  SG_OPT_SPLIT_TARGET,    // conv-shaped GEMMs on 64-row tiles: split K until about this many workgroups are in flight
+  SG_OPT_SPLIT_KMIN,      // ... but only reductions at least this long (chunks stay >= half of it)
   SG_OPT_SPLITS,          // force the split-K count of the conv-shaped GEMMs; -1 = chosen per shape
   SG_OPT_FIXEDTAP,        // LoadFixedKN loaders (taps in VGPRs, channel offset in the SGPR operand)
   SG_OPT_WINO_WT,         // LDS-staged Winograd filter transform (0: one thread per filter)

@@ -1530,11 +1530,12 @@ inline int kn_splits(int M, int Npix, int K) {
   if (force > 0) return force;
   const int tiles = kn_tiles(M, Npix);
   // workgroups wanted in flight: ~6 per CU of the 64x64 / 32x128 kernels, 3 per CU (the register limit) of 128x128
-  const int target = pick_tile(M, Npix) == 0 ? 1024 : 1536;
-  if (tiles * 4 >= target * 3 || K < 2048) return 1;
+  const int target = pick_tile(M, Npix) == 0 ? 1024 : sg_opt(SG_OPT_SPLIT_TARGET);
+  const int kmin = sg_opt(SG_OPT_SPLIT_KMIN);
+  if (tiles * 4 >= target * 3 || K < kmin) return 1;
   int sp = (target + tiles / 2) / tiles;
   if (sp > 2 && (sp & 1)) ++sp;                 // odd split counts measured 10 % slower than their even neighbours
-  if (sp > K / 1024) sp = K / 1024;
+  if (sp > K / (kmin / 2)) sp = K / (kmin / 2);
   if (sp > 8) sp = 8;
   return sp < 2 ? 1 : sp;
 }
