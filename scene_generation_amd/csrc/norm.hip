@@ -216,6 +216,9 @@ struct BnIter {             // walks i -> (n, p) without a division per element
   __device__ __forceinline__ void step(int d) { p += d; while (p >= HW) { p -= HW; ++n; } }
 };
 
+// slices of up to BN_REG * 256 elements stay in registers between the mean and the variance pass: x is read ONCE (the two-pass
+// form read every slice twice; slices are ~1-10 K elements: bn_slices)
+constexpr int BN_REG = 40;
 __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int N, int C,
                                                       int HW, int S) {
   __shared__ float red[16];
@@ -224,6 +227,34 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__
   const long chunk = (cnt + S - 1) / S;
   const long beg = z * chunk, end = beg + chunk < cnt ? beg + chunk : cnt;
   const float m = (float)(end > beg ? end - beg : 0);
+  if (end - beg <= (long)BN_REG * 256) {
+    float v[BN_REG];
+    float s = 0.f;
+    {
+      BnIter it(beg + threadIdx.x, HW);
+#pragma unroll
+      for (int e = 0; e < BN_REG; ++e) {
+        const bool ok = beg + threadIdx.x + (long)e * 256 < end;
+        v[e] = ok ? x[((size_t)it.n * C + c) * HW + it.p] : 0.f;
+        s += v[e];
+        if (ok) it.step(256);
+      }
+    }
+    s = sg_block_sum(s, red);
+    const float mean = m > 0.f ? s / m : 0.f;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < BN_REG; ++e) {
+      const float d = v[e] - mean;
+      q += (beg + threadIdx.x + (long)e * 256 < end) ? d * d : 0.f;
+    }
+    q = sg_block_sum(q, red);
+    if (threadIdx.x == 0) {
+      float* o = part + ((size_t)c * S + z) * 3;
+      o[0] = m; o[1] = mean; o[2] = q;
+    }
+    return;
+  }
   float s = 0.f;
   {
     BnIter it(beg + threadIdx.x, HW);
@@ -257,14 +288,23 @@ __global__ void bn_final_kernel(const float* __restrict__ part, float* __restric
     return;
   }
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int z = 0; z < S; ++z) {
-    const float* p = part + ((size_t)c * S + z) * 3;
-    const float nb = p[0];
-    if (nb <= 0.f) continue;
-    const float d = p[1] - mean, nt = n + nb;
-    mean += d * (nb / nt);
-    m2 += p[2] + d * d * (n * nb / nt);
-    n = nt;
+  // (the partials of 8 slices are fetched together: one thread walking S <= 64 dependent round trips took 10 us)
+  for (int z0 = 0; z0 < S; z0 += 8) {
+    float pn[8], pm[8], pq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float* p = part + ((size_t)c * S + min(z0 + e, S - 1)) * 3;
+      pn[e] = z0 + e < S ? p[0] : 0.f; pm[e] = p[1]; pq[e] = p[2];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float nb = pn[e];
+      if (nb <= 0.f) continue;
+      const float d = pm[e] - mean, nt = n + nb;
+      mean += d * (nb / nt);
+      m2 += pq[e] + d * d * (n * nb / nt);
+      n = nt;
+    }
   }
   const float var = m2 / n;
   save_mean[c] = mean;
@@ -330,7 +370,16 @@ __global__ void bn_bwd_final_kernel(const float* __restrict__ part, float* __res
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float s1 = 0.f, s2 = 0.f;
-  for (int z = 0; z < S; ++z) { s1 += part[((size_t)c * S + z) * 2]; s2 += part[((size_t)c * S + z) * 2 + 1]; }
+  for (int z0 = 0; z0 < S; z0 += 8) {
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const size_t i = ((size_t)c * S + min(z0 + e, S - 1)) * 2;
+      a[e] = z0 + e < S ? part[i] : 0.f; b[e] = z0 + e < S ? part[i + 1] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1 += a[e]; s2 += b[e]; }
+  }
   sums[2 * c] = s1; sums[2 * c + 1] = s2;
   if (gbeta) gbeta[c] = s1;
   if (ggamma) ggamma[c] = s2;
