@@ -102,7 +102,7 @@ def main():
                 out[kind] = {'bytes_per_launch': (t[1] + t[2]) / t[0], 'fetch_bytes_per_launch': t[1] / t[0],
                              'write_bytes_per_launch': t[2] / t[0], 'launches_sampled': t[0],
                              'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 (gfx950), WRITE '
-                                       'calibrated on adam_kernel: tools/pmc_db_summary.py, profiles/r03_pmc_traffic.md'}
+                                       'calibrated on adam_kernel: tools/pmc_db_summary.py, profiles/r04_pmc_traffic.md'}
         json.dump(out, open(sys.argv[sys.argv.index('--json') + 1], 'w'), indent=1)
 
 
