@@ -142,7 +142,9 @@ class Model(nn.Module):
             f_wrong = ops.FactoredLayout(Z, objs, wrong_layout_vecs[:, self.num_objs:].detach(), self.num_objs, obj_to_img,
                                          pidx, counts, seg)
             f_wrong._lists = f_gt._lists          # same objects: share the list cache
-            ops.set_hints(gt_layout, factored=f_gt)
+            # 'wrong_twin': the image discriminator sees (layout, real image) and (wrong layout, real image) -- same planes, same
+            # objects, other appearance vectors -- and can run the two passes as ONE batch (Trainer.train_generator)
+            ops.set_hints(gt_layout, factored=f_gt, wrong_twin=f_wrong)
             ops.set_hints(wrong_layout, factored=f_wrong)
         imgs_pred = self.layout_to_image(gt_layout)
         return imgs_pred, boxes_pred, masks_pred, gt_layout, pred_layout, wrong_layout

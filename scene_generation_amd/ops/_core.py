@@ -259,7 +259,7 @@ def skip_state_key():
 # ``.detach()`` keeps the storage but drops attributes.  An entry holds a strong reference to its tensor, so the address
 # cannot be recycled while the entry exists; Model.forward clears the table at the start of every iteration.
 _HINT_TABLE = {}
-_HINT_KEYS = ('sparse', 'sparse_cat', 'grad_from', 'factored', 'keep_grad', 'pending')
+_HINT_KEYS = ('sparse', 'sparse_cat', 'grad_from', 'factored', 'keep_grad', 'pending', 'wrong_twin')
 
 
 def clear_hints():

@@ -154,6 +154,19 @@ class FactoredLayout(object):
         f._lists = self._lists
         return f
 
+    @staticmethod
+    def stacked(a, b):
+        """The batch concatenation [a ; b] of two factored layouts over the SAME planes and objects (the ground-truth layout and its
+        wrong-texture twin, model.py:119-124: only the appearance vectors differ): images N.. are b's.  Appearance vectors enter
+        detached (the only consumer is a discriminator pass that must not reach the generator)."""
+        assert a.Z is b.Z and a.objs is b.objs and a.counts_host == b.counts_host and a.num_objs == b.num_objs
+        N = a.Z.size(0)
+        f = FactoredLayout(torch.cat([a.Z, a.Z], 0), torch.cat([a.objs, a.objs], 0),
+                           torch.cat([a.repr.detach(), b.repr.detach()], 0), a.num_objs,
+                           torch.cat([a.img_idx, a.img_idx + N], 0), torch.cat([a.plane_idx, a.plane_idx], 0),
+                           a.counts_host + a.counts_host)
+        return f
+
     def lists(self, extra):
         """(chan_list [N, L], chan_cnt [N], extra_pos [N, extra]) for the gather: the image's planes, then ``extra``
         channels of a concatenated second source (they sit at channel ids J.. and list positions cnt[n]..)"""

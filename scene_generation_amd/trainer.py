@@ -102,6 +102,8 @@ class Trainer:
         # runs it once more per discriminator step (trainer.py:281-325)
         self._shareable = {'mask': not _has_batchnorm(self.mask_discriminator), 'img': not _has_batchnorm(self.netD)}
         self.share_d_forward = True
+        # the real and wrong-texture passes of the image discriminator as one 2N batch (_real_and_wrong_pass; A/B: SG_BATCH_REAL_WRONG=0)
+        self.batch_real_wrong = os.environ.get('SG_BATCH_REAL_WRONG', '1') != '0'
         self.reducers = []
         if distributed:
             control_group()                      # collective: create the host-side agreement group on every rank now
@@ -306,10 +308,12 @@ class Trainer:
                     shared['img_fake'] = img_pred_fake
                 L.add_loss(self.criterionGAN(img_pred_fake, True), 'g_gan_img_loss', args.d_img_weight)
                 if args.d_img_features_weight > 0:
-                    with (contextlib.nullcontext() if share_img else torch.no_grad()):
-                        pred_real = self.netD(lay, imgs)        # "train textures" pass
-                    if share_img:
-                        shared['img_real'] = pred_real
+                    pred_real = self._real_and_wrong_pass(lay, imgs, shared) if share_img else None
+                    if pred_real is None:
+                        with (contextlib.nullcontext() if share_img else torch.no_grad()):
+                            pred_real = self.netD(lay, imgs)        # "train textures" pass
+                        if share_img:
+                            shared['img_real'] = pred_real
                     L.add_loss(self.calculate_features_loss(img_pred_fake, pred_real), 'g_gan_features_loss_img',
                                args.d_img_features_weight)
 
@@ -324,6 +328,26 @@ class Trainer:
                     r.flush()
         else:
             self.optimizer.step()
+
+    def _real_and_wrong_pass(self, lay, imgs, shared):
+        """(layout, real images) and (wrong-texture layout, real images) -- the "real" and "wrong" passes of the image
+        discriminator (trainer.py:250,304-308) -- as ONE forward over 2N images: the two layouts share planes and objects
+        (model.py:119-124), InstanceNorm is per sample, so the batch halves are exactly the two passes; every layer then runs one
+        launch twice the size instead of two (these launches are occupancy-starved at N = 32) and the discriminator step gets
+        the weight gradients of both passes from one GEMM per layer.  Needs the factored layouts (``wrong_twin`` hint set by
+        Model.forward) and ``share_d_forward``; returns the real pass (list of feature lists) or None when not applicable."""
+        if not getattr(self, 'batch_real_wrong', True) or not ops.FACTORED_LAYOUT:
+            return None
+        f_gt, f_wrong = ops.hint(lay, 'factored'), ops.hint(lay, 'wrong_twin')
+        if f_gt is None or f_wrong is None or f_gt.Z is not f_wrong.Z:
+            return None
+        N = imgs.size(0)
+        f2 = ops.FactoredLayout.stacked(f_gt, f_wrong)
+        ghost = lay.new_empty((1,)).expand((2 * N,) + tuple(lay.shape[1:]))      # never read: the convs run on the factored form
+        both = self.netD(ops.set_hints(ghost, factored=f2), torch.cat([imgs, imgs], 0))
+        shared['img_real'] = [[t[:N] for t in scale] for scale in both]
+        shared['img_wrong'] = [[t[N:] for t in scale] for scale in both]
+        return shared['img_real']
 
     def train_obj_discriminator(self, imgs, imgs_pred, objs, boxes, boxes_pred, obj_to_img):
         if self.obj_discriminator is not None:
@@ -367,8 +391,11 @@ class Trainer:
             pred_real = shared.pop('img_real', None)
             if pred_real is None:
                 pred_real = self.discriminate(layout, imgs)
+            pred_wrong = shared.pop('img_wrong', None)      # batched with the real pass in the generator step, when possible
+            if pred_wrong is None:
+                pred_wrong = self.discriminate(layout_wrong, imgs)
             L.add_loss(self.criterionGAN(pred_fake, False), 'fake_image_loss', alpha)
-            L.add_loss(self.criterionGAN(self.discriminate(layout_wrong, imgs), False), 'wrong_texture_loss', alpha)
+            L.add_loss(self.criterionGAN(pred_wrong, False), 'wrong_texture_loss', alpha)
             L.add_loss(self.criterionGAN(pred_real, True), 'd_img_gan_real_loss', 0.5)
             self.optimizer_d_img.zero_grad()
             torch.autograd.backward(L.total_loss, inputs=list(self.netD.parameters()))

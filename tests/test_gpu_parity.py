@@ -1565,6 +1565,43 @@ def test_step_is_bit_reproducible(hip):
     assert torch.equal(res[0][3], res[1][3])
 
 
+def test_batched_real_and_wrong_discriminator_passes_equal_separate_passes(hip):
+    """Trainer._real_and_wrong_pass: the image discriminator's real and wrong-texture passes run as one 2N batch over the stacked
+    factored layouts.  Same step from the same state with the batch on and off: every named loss, the discriminator gradients and
+    the updated parameters agree to fp32 summation order (InstanceNorm is per sample, so the batch halves ARE the two passes)."""
+    from scene_generation_amd.trainer import Trainer
+    args = parser.parse_args(['--image_size', '64,64', '--batch_size', '4', '--vgg_features_weight', '0', '--output_dir', '/tmp/o'])
+    b = batch_to(make_batch(N=4, min_objs=3, max_objs=6, size=64, seed=19), DEV)
+    res = []
+    for batched in (True, False):
+        torch.manual_seed(0)
+        tr = Trainer(args, make_vocab())
+        tr.batch_real_wrong = batched
+        for m in (tr.model, tr.netD, tr.obj_discriminator, tr.mask_discriminator):
+            fill_deterministic(m)
+        tr.model.noise_override = det((1, 64), 133).to(DEV)
+        grads = {}
+        tr.optimizer_d_img.pre_step_hooks.append(lambda o=tr.optimizer_d_img: grads.__setitem__('d_img', o.fp.grad.clone()))
+        calls0 = hip.CALLS[0]
+        random.seed(3)
+        tr.step(b, use_gt=True)
+        calls = hip.CALLS[0] - calls0
+        losses = {}
+        for L in (tr.generator_losses, tr.d_img_losses, tr.d_obj_losses, tr.d_mask_losses):
+            losses.update(dict(L.items()))
+        res.append((losses, grads['d_img'], tr.optimizer_d_img.fp.flat.detach().clone(), tr.optimizer.fp.flat.detach().clone(), calls))
+        del tr
+    (la, ga, pa, gpa, ca), (lb, gb, pb, gpb, cb) = res
+    assert set(la) == set(lb)
+    for k in lb:
+        assert abs(la[k] - lb[k]) <= 2e-6 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+    close(ga, gb, 2e-5, 'image-discriminator flat gradient')
+    cos = float((ga.double() @ gb.double()) / (ga.double().norm() * gb.double().norm()))
+    assert cos > 0.999999, cos
+    close(gpa, gpb, 1e-6, 'generator parameters (untouched by the batching)')
+    assert ca < cb, 'the batched form issues fewer launches (%d vs %d)' % (ca, cb)
+
+
 def test_reference_training_loop_through_the_alias(hip):
     """train.py:190-215 re-stated statement by statement against the ``scene_generation.*`` names that
     install_as() provides -- plain ``.detach()`` on the layouts, the one-hot channel slices, the four trainer calls -- gives
