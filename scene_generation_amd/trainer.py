@@ -8,6 +8,8 @@ Same attributes and step functions as the reference Trainer; differences in HOW 
   * the image discriminator receives (layout, image) as two tensors; the concat is folded into its first conv
   * losses stay on the device (LossManager is lazy); nothing in a step forces a host sync except VectorPool's
     class-id copy
+  * the image discriminator's real and wrong-texture passes (trainer.py:250,304-308) run as ONE 2N batch over the stacked
+    factored layouts (_real_and_wrong_pass): the launches of the discriminators are occupancy-starved at N = 32
   * optional data parallelism: per-optimiser GradReducer (RCCL all-reduce of the flat gradient buffers)
 TensorBoard / image logging of the reference (trainer.py:342-397) is glue outside the hot path: ``write_losses``
 prints; checkpoints keep the reference schema (trainer.py:136-203, train.py:132-162).
