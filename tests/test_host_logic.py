@@ -216,6 +216,28 @@ def test_factored_layout_lists_host_logic():
     assert g.lists(3) is f.lists(3) and not g.repr.requires_grad
 
 
+def test_factored_layout_stacked_is_the_batch_concatenation():
+    """ops.FactoredLayout.stacked (the image discriminator's real + wrong-texture passes as one 2N batch): same planes and
+    objects twice, images N.. carry the second layout's appearance vectors; everything detached."""
+    from scene_generation_amd.ops import FactoredLayout
+    Z = torch.arange(3 * 4 * 2 * 2, dtype=torch.float32).view(3, 4, 2, 2)
+    objs, o2i, pidx = torch.tensor([1, 2, 3, 4, 5, 6, 7]), torch.tensor([0, 0, 1, 1, 1, 1, 2]), torch.tensor([0, 1, 0, 1, 2, 3, 0])
+    ra, rb = torch.rand(7, 2, requires_grad=True), torch.rand(7, 2)
+    a = FactoredLayout(Z, objs, ra, 10, o2i, pidx, [2, 4, 1])
+    b = FactoredLayout(Z, objs, rb, 10, o2i, pidx, [2, 4, 1], a.seg)
+    f = FactoredLayout.stacked(a, b)
+    assert f.Z.shape == (6, 4, 2, 2) and torch.equal(f.Z[:3], Z) and torch.equal(f.Z[3:], Z)
+    assert f.objs.tolist() == objs.tolist() * 2 and f.counts_host == [2, 4, 1, 2, 4, 1]
+    assert f.img_idx.tolist() == o2i.tolist() + (o2i + 3).tolist() and f.plane_idx.tolist() == pidx.tolist() * 2
+    assert f.seg.tolist() == [0, 2, 6, 7, 9, 13, 14]
+    assert torch.equal(f.repr[:7], ra.detach()) and torch.equal(f.repr[7:], rb) and not f.repr.requires_grad
+    cl, cc, ep, L = f.lists(3)
+    cl1, cc1, ep1, L1 = a.lists(3)
+    assert L == L1 and cc.tolist() == cc1.tolist() * 2 and torch.equal(cl[:3], cl1) and torch.equal(cl[3:], cl1)
+    with pytest.raises(AssertionError):
+        FactoredLayout.stacked(a, FactoredLayout(Z.clone(), objs, rb, 10, o2i, pidx, [2, 4, 1]))      # other planes: not a twin
+
+
 def test_weighted_sum_and_lazy_loss_manager():
     from scene_generation_amd.utils import weighted_sum
     a, b, c = torch.tensor(1.5, requires_grad=True), torch.tensor(-2.0, requires_grad=True), torch.tensor(0.25)
