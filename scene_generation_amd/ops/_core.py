@@ -161,7 +161,7 @@ class GradOut(object):
             self.buf, self.mode = torch.empty_like(param), 2
         elif (_CAPTURE[0] == 0) if _CAPTURE is not None else (not sk.opt()._touched[sk.i]):
             self.buf, self.mode = sk.view, 0               # first contribution since zero_grad(): write in place
-        elif _CAPTURE is None and hasattr(sk.opt(), 'spill_view'):
+        elif _CAPTURE is None and getattr(sk.opt(), 'use_spill', False):
             # k-th contribution (k >= 2: a discriminator's real / wrong-texture pass): written in place into the optimiser's
             # spill buffer k-2, which optimizer.step() folds into the gradient with ONE launch (optim.FusedAdam._fold_spill)
             self.buf, self.mode = sk.opt().spill_view(sk.i), 3

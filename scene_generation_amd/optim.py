@@ -73,6 +73,10 @@ class FusedAdam:
         # same layout as the gradient buffer, all-zero outside a step
         self._contrib = [0] * n
         self._spill, self._spill_used, self._fold_queued = [], 0, False
+        # False: later contributions are added into the gradient slice at once (temporary + axpy).  A reducer that sends
+        # buckets to the all-reduce DURING the backward needs that: a spilled contribution only reaches the slice when the
+        # backward ends, after the bucket may have left (parallel.GradReducer(overlap=True), Trainer)
+        self.use_spill = True
         self.pre_step_hooks = []          # e.g. GradReducer.wait
         self.zero_grad_hooks = []         # e.g. GradReducer.begin_step
         self.grad_listeners = []          # callables(i): parameter i just received (a contribution to) its gradient

@@ -116,6 +116,7 @@ class Trainer:
                     # the bucket all-reduces overlap the backward; discriminator parameters collect several
                     # contributions per step (fake / real / wrong passes) and are reduced in wait() (<= 24 MB each)
                     r = GradReducer(opt.fp, optimizer=opt, overlap=opt is self.optimizer)
+                    opt.use_spill = not r.overlap      # (spilled contributions are folded in after the buckets have left)
                     opt.grad_listeners.append(r.param_ready)
                     opt.late_listeners.append(r.late_contribution)
                     opt.zero_grad_hooks.append(r.begin_step)

@@ -51,6 +51,8 @@ def _worker(rank, world, port, q, backend):
     torch.cuda.set_device(dev)
     dist.init_process_group(backend, rank=rank, world_size=world)
     tr, grads = _make(True, dev)
+    # buckets leave during the generator's backward: nothing may be parked in a spill buffer until the backward ends
+    assert tr.optimizer.use_spill is False and tr.optimizer_d_img.use_spill is True
     if rank == 1:                                    # the broadcast at construction already happened: perturbing now would
         pass                                         # desynchronise on purpose; nothing to do
     shard = batch_to(shard_batch(_batch(), rank, world), dev)
