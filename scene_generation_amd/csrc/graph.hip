@@ -175,7 +175,7 @@ __global__ void embedding_fwd_kernel(const float* __restrict__ table, const int6
 }
 
 // one block per table row; rows of g accumulated in ascending i (== CPU index_add order).  The matching rows are listed
-// once (thread 0, ascending) so the column loop only touches them: the scan over all n indices per column made this the
+// once (wave 0, ascending) so the column loop only touches them: the scan over all n indices per column made this the
 // slowest small kernel of the factored layout convs (dim = Cout*KS*KS = 3136).
 __global__ void embedding_bwd_kernel(const float* __restrict__ g, const int64_t* __restrict__ idx,
                                      float* __restrict__ gt, int n, int dim) {
@@ -185,12 +185,17 @@ __global__ void embedding_bwd_kernel(const float* __restrict__ g, const int64_t*
   const int row = blockIdx.x;
   for (int base = 0; base < n; base += CAP) {            // chunks of CAP indices (one chunk in practice)
     __syncthreads();
-    if (threadIdx.x == 0) {
-      int c = 0;
+    if (threadIdx.x < 64) {                            // wave 0: ordered compaction, 64 indices per round (one thread
+      int c = 0;                                       // walking the n dependent loads took ~50 us at n = 250)
       const int end = base + CAP < n ? base + CAP : n;
-      for (int i = base; i < end; ++i)
-        if (idx[i] == row) hits[c++] = i;
-      nhit = c;
+      for (int i0 = base; i0 < end; i0 += 64) {
+        const int i = i0 + (int)threadIdx.x;
+        const bool hit = i < end && idx[i] == row;
+        const unsigned long long m = __ballot(hit);
+        if (hit) hits[c + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = i;
+        c += __popcll(m);
+      }
+      if (threadIdx.x == 0) nhit = c;
     }
     __syncthreads();
     const int c = nhit;

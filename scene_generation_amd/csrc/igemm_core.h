@@ -1410,9 +1410,35 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 __global__ void slab_reduce_kernel(const float* ws, float* out, size_t n, int S) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float v = 0.f;
-  for (int z = 0; z < S; ++z) v += ws[(size_t)z * n + i];
-  out[i] = v;
+  out[i] = sg_sum_strided(ws + i, n, S);
+}
+
+// the same for MANY slabs of a SMALL result (weight gradient of a few-channel conv: 64 x 48 outputs, up to 256 k-chunks): a
+// workgroup = 16 columns x 16 slab groups, every thread sums S / 16 consecutive slabs (loads issued eight at a time), the groups
+// meet in LDS in ascending order.  One thread per column walking S dependent round trips took 16 us at S = 64.
+__global__ void __launch_bounds__(256) slab_reduce_wide_kernel(const float* __restrict__ ws, float* __restrict__ out, size_t n, int S) {
+  __shared__ float red[16][17];
+  const int j = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + j;
+  const int per = (S + 15) / 16, zb = q * per, ze = zb + per < S ? zb + per : S;
+  float acc = 0.f;
+  if (i < n) {
+    for (int z0 = zb; z0 < ze; z0 += 8) {
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = z0 + e < ze ? ws[(size_t)(z0 + e) * n + i] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += t[e];
+    }
+  }
+  red[q][j] = acc;
+  __syncthreads();
+  if (q == 0 && i < n) {
+    float v = red[0][j];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) v += red[g][j];
+    out[i] = v;
+  }
 }
 
 // split-K epilogue of the conv-shaped GEMMs: out[i] = act(sum_z ws[z][i] + bias[channel(i)])
@@ -1638,7 +1664,10 @@ inline NkPlan nk_plan(int M, int C, int KS2, int Kpix, bool two) {
   int s = (int)((target + tiles - 1) / tiles);
   const int maxs = Kpix / (BK * 8) > 0 ? Kpix / (BK * 8) : 1;
   if (s > maxs) s = maxs;
-  if (s > 64) s = 64;
+  // (tap-major launches have many tiles; the few-channel (c, tap) form has 1..4 of them and only its k-chunks to fill the chip
+  // with: 64 chunks left the first conv of the crop discriminator on 64 workgroups for 93 us)
+  const int cap = p.tap ? 64 : 256;
+  if (s > cap) s = cap;
   // XCD-pinned k-chunks (see the kernel) need a multiple of 8 of them
   if (sg_opt(SG_OPT_WGRAD_XCD) && s >= 6) {
     int s8 = (s + 7) / 8 * 8;

@@ -223,6 +223,8 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
                        M, C, KS2, pl.cpad, splits, (const float*)rowsum, rowsum ? gb : nullptr);
     if (rowsum && gb_done) *gb_done = true;
   }
+  else if (splits >= 32)
+    hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3(sg_cdiv(mn, 16)), dim3(256), 0, s, (const float*)ws, out, mn, splits);
   else if (splits > 1)
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(sg_cdiv(mn, 256)), dim3(256), 0, s, (const float*)ws, out, mn, splits);
   return 0;

@@ -658,13 +658,13 @@ __device__ __forceinline__ int reflect_sources(int l, int L, int p, int (&a)[3])
   return n;
 }
 
-__global__ void pad_upsample_bwd_kernel(const float* __restrict__ gp, float* __restrict__ gx, size_t total, int H, int W,
-                                        int pad, int ups) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int w = i % W;
-  const int h = (i / W) % H;
-  const size_t nc = i / ((size_t)W * H);
+// grid (ceil(H W / 256), N C): 32-bit index arithmetic (the flat size_t form spent most of its time in the emulated 64-bit
+// divisions: 147 us for the 134 MB gradient of the RGB head's reflection pad)
+__global__ void pad_upsample_bwd_kernel(const float* __restrict__ gp, float* __restrict__ gx, int H, int W, int pad, int ups) {
+  const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= (unsigned)(H * W)) return;
+  const size_t nc = blockIdx.y;
+  const int h = (int)(j / (unsigned)W), w = (int)(j - (unsigned)h * (unsigned)W);
   const int LH = H * ups, LW = W * ups, PH = LH + 2 * pad, PW = LW + 2 * pad;
   const float* g = gp + nc * PH * PW;
   float s = 0.f;
@@ -675,10 +675,10 @@ __global__ void pad_upsample_bwd_kernel(const float* __restrict__ gp, float* __r
       int aw[3];
       const int nw = reflect_sources(w * ups + dw, LW, pad, aw);
       for (int a = 0; a < nh; ++a)
-        for (int b = 0; b < nw; ++b) s += g[(size_t)ah[a] * PW + aw[b]];
+        for (int b = 0; b < nw; ++b) s += g[ah[a] * PW + aw[b]];
     }
   }
-  gx[i] = s;
+  gx[nc * H * W + j] = s;
 }
 
 __global__ void concat_channels_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
@@ -994,8 +994,13 @@ extern "C" int sg_replicate_pad_bwd(const float* gp, float* gx, int NC, int H, i
 extern "C" int sg_pad_upsample_bwd(const float* gp, float* gx, int NC, int H, int W, int pad, int upsample,
                                    sgStream stream) {
   SG_ARG_CHECK(gp && gx && (upsample == 1 || upsample == 2) && pad >= 0, "sg_pad_upsample_bwd: bad arguments");
-  const size_t total = (size_t)NC * H * W;
-  hipLaunchKernelGGL(pad_upsample_bwd_kernel, grid1d(total), dim3(256), 0, (hipStream_t)stream, gp, gx, total, H, W, pad, upsample);
+  if (NC == 0 || H * W == 0) return 0;
+  for (int n0 = 0; n0 < NC; n0 += 65535) {                  // (grid.y limit)
+    const int nn = NC - n0 < 65535 ? NC - n0 : 65535;
+    const size_t PP = (size_t)(H * upsample + 2 * pad) * (W * upsample + 2 * pad);
+    hipLaunchKernelGGL(pad_upsample_bwd_kernel, dim3(sg_cdiv(H * W, 256), nn), dim3(256), 0, (hipStream_t)stream,
+                       gp + (size_t)n0 * PP, gx + (size_t)n0 * H * W, H, W, pad, upsample);
+  }
   SG_LAUNCH_CHECK("sg_pad_upsample_bwd");
   return 0;
 }

@@ -23,7 +23,9 @@ __global__ void __launch_bounds__(512) smallm_fwd_kernel(const float* __restrict
   constexpr int NE = (RH * RW + 255) / 256;
   static_assert(2 * 2 * RH * PITCH >= 256 * MO * 4, "the exchange of the partial sums re-uses the staging tiles");
   __shared__ __attribute__((aligned(16))) float tile[2][2][RH * PITCH];       // [group][buffer]
-  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, tx = tid & 15, ty = tid >> 4;
+  // (readfirstlane: the group is the same for the 64 lanes of a wave, but the compiler only believes that when told -- without
+  //  it the 21 weight rows of every channel came through VECTOR loads, each waited for on the spot)
+  const int grp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)), tid = threadIdx.x & 255, tx = tid & 15, ty = tid >> 4;
   const int n = blockIdx.z, oh0 = blockIdx.y * TH, ow0 = blockIdx.x * TW;
   const size_t HW = (size_t)H * W;
   const float* xn = x + (size_t)n * C * HW;
@@ -42,6 +44,13 @@ __global__ void __launch_bounds__(512) smallm_fwd_kernel(const float* __restrict
 #pragma unroll
     for (int p = 0; p < 4; ++p) acc[m][p] = 0.f;
   const int iters = (C + 1) / 2;
+  // the plane of the NEXT channel is fetched into registers while this one is multiplied: the loads used to be issued and waited
+  // for at the top of every iteration (~1.5 us of exposed latency per channel, 32 channels per workgroup)
+  float pre[NE];
+  if (grp < C) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) pre[e] = goff[e] >= 0 ? xn[(size_t)grp * HW + goff[e]] : 0.f;
+  }
   for (int it = 0; it < iters; ++it) {
     const int c = 2 * it + grp;
     const bool live = c < C;                      // (odd C: the second group idles through the last iteration's barrier)
@@ -49,9 +58,13 @@ __global__ void __launch_bounds__(512) smallm_fwd_kernel(const float* __restrict
     if (live) {
 #pragma unroll
       for (int e = 0; e < NE; ++e)
-        if (goff[e] >= 0) T[loff[e]] = xn[(size_t)c * HW + goff[e]];
+        if (goff[e] >= 0) T[loff[e]] = pre[e];
     }
     __syncthreads();
+    if (c + 2 < C) {
+#pragma unroll
+      for (int e = 0; e < NE; ++e) pre[e] = goff[e] >= 0 ? xn[(size_t)(c + 2) * HW + goff[e]] : 0.f;
+    }
     if (live) {
       const float* wc = w + (size_t)c * KS * KS;
 #pragma unroll
@@ -63,15 +76,16 @@ __global__ void __launch_bounds__(512) smallm_fwd_kernel(const float* __restrict
           const float4 t4 = *reinterpret_cast<const float4*>(row + 4 * v);
           in[4 * v] = t4.x; in[4 * v + 1] = t4.y; in[4 * v + 2] = t4.z; in[4 * v + 3] = t4.w;
         }
+        // rows m >= M (MO is the next instantiated size) repeat row M - 1 and are never stored: no branch in here, so the
+        // scalar weight loads of a whole filter row are issued together
 #pragma unroll
         for (int m = 0; m < MO; ++m) {
-          if (m < M) {
+          const float* wm = wc + (size_t)(m < M ? m : M - 1) * C * KS * KS + kh * KS;
 #pragma unroll
-            for (int kw = 0; kw < KS; ++kw) {
-              const float wv = wc[(size_t)m * C * KS * KS + kh * KS + kw];       // wave-uniform
+          for (int kw = 0; kw < KS; ++kw) {
+            const float wv = wm[kw];                                             // wave-uniform: scalar load
 #pragma unroll
-              for (int p = 0; p < 4; ++p) acc[m][p] = fmaf(wv, in[p + kw], acc[m][p]);
-            }
+            for (int p = 0; p < 4; ++p) acc[m][p] = fmaf(wv, in[p + kw], acc[m][p]);
           }
         }
       }
@@ -187,9 +201,7 @@ __global__ void __launch_bounds__(256) smallm_wgrad_kernel(const float* __restri
 __global__ void smallm_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int S) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float v = 0.f;
-  for (int z = 0; z < S; ++z) v += part[(size_t)z * n + i];
-  out[i] = v;
+  out[i] = sg_sum_strided(part + i, n, S);
 }
 
 bool smallm_ok(const sgConvDesc* d) {
@@ -212,7 +224,10 @@ extern "C" int sg_conv2d_smallm_fwd(const sgConvDesc* d, const float* x, const f
   hipStream_t s = (hipStream_t)stream;
   SgProfScope prof(sg_igemm_kind(0, 7, 2), s, 2.0 * d->Cout * d->C1 * 49.0 * d->N * d->H * d->W, 0);
   const dim3 grid(sg_cdiv(d->W, 64), sg_cdiv(d->H, 16), d->N);
-  hipLaunchKernelGGL((smallm_fwd_kernel<7, 4>), grid, dim3(512), 0, s, x, w, bias, y, d->C1, d->H, d->W, d->Cout, act, slope);
+  if (d->Cout == 3)        // (the RGB head: no instructions for the fourth row)
+    hipLaunchKernelGGL((smallm_fwd_kernel<7, 3>), grid, dim3(512), 0, s, x, w, bias, y, d->C1, d->H, d->W, d->Cout, act, slope);
+  else
+    hipLaunchKernelGGL((smallm_fwd_kernel<7, 4>), grid, dim3(512), 0, s, x, w, bias, y, d->C1, d->H, d->W, d->Cout, act, slope);
   SG_LAUNCH_CHECK("sg_conv2d_smallm_fwd");
   return 0;
 }
@@ -322,7 +337,7 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(const float* __restrict__
   const int chunk = blockIdx.x, n = blockIdx.y, c0 = chunk * g.CH, nc = min(g.CH, g.C - c0);
   head_stage(x + (size_t)n * g.C * g.H * g.W, pl, c0, nc, 0, g.PH, g.dPP, g);
   __syncthreads();
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: see smallm_fwd)
   for (int p = lane; p < OP; p += 64) {
     const int oh = (int)g.dOW.div((unsigned)p), ow = p - oh * g.OW;
     const float* base = pl + oh * g.PW + ow;

@@ -163,6 +163,8 @@ CONV_CASES = [
     (8, 128, 0, 17, 17, 128, 4, 1, 2, False, 1, 2),    # Winograd F(2x2,4x4): PatchGAN k4 s1 p2 (17 -> 18), fused LeakyReLU
     (8, 128, 0, 20, 14, 256, 4, 1, 1, False, 1, 0),    # F(2x2,4x4): pad 1, odd 19x13 output (clipped edge tiles), Cin != Cout
     (8, 256, 0, 19, 19, 128, 4, 1, 0, False, 1, 1),    # F(2x2,4x4): valid conv, data gradient with padding 3, k-chunked wgrad
+    (6, 3, 0, 64, 64, 64, 4, 2, 1, False, 1, 2),       # crop-D first conv: few-channel wgrad in 48 k-chunks (wide slab reduce)
+    (40, 3, 0, 64, 64, 64, 4, 2, 1, False, 1, 2),      # the same at ~200 crops: the 256-chunk cap, XCD-padded chunk count
 ]
 
 
@@ -516,6 +518,16 @@ def test_embedding_onehot_concat(hip):
     yg.backward(gy.to(DEV))
     assert torch.equal(yg.cpu(), yr.detach())
     close(tg.grad, tr.grad, 1e-6)
+    # several 64-index rounds of the ordered row search, rows hit 0..30 times, a row width that is not a multiple of 64
+    table2 = det((20, 130), 76)
+    idx2 = torch.randint(0, 19, (300,), generator=torch.Generator().manual_seed(5))        # row 19 never hit: stays zero
+    tr2 = table2.clone().requires_grad_()
+    gy2 = det((300, 130), 77)
+    F.embedding(idx2, tr2).backward(gy2)
+    tg2 = table2.to(DEV).requires_grad_()
+    hip.embedding(tg2, idx2.to(DEV)).backward(gy2.to(DEV))
+    close(tg2.grad, tr2.grad, 1e-6)
+    assert float(tg2.grad[19].abs().max()) == 0.0
     oh = hip.one_hot(idx.to(DEV), 12).cpu()
     assert torch.equal(oh, F.one_hot(idx, 12).float())
     a, b = det((6, 5), 73), det((6, 3), 74)
