@@ -400,11 +400,20 @@ __global__ void __launch_bounds__(256) wino_input_small_kernel(const float* __re
   const int HW = H * W, pitch = HW + 1;
   const int n = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
   const float* src = x + ((size_t)n * C + c0) * HW;
-  for (int i = tid * 4; i < 64 * HW; i += 1024) {
-    const float4 v = *reinterpret_cast<const float4*>(src + i);
-    const int ch = i / HW, px = i - ch * HW;
-    float* d = pl + ch * pitch + px;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  for (int i0 = tid * 4; i0 < 64 * HW; i0 += 4096) {          // four float4 loads in flight before the first LDS store
+    float4 v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i0 + e * 1024 < 64 * HW) v[e] = *reinterpret_cast<const float4*>(src + i0 + e * 1024);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = i0 + e * 1024;
+      if (i < 64 * HW) {
+        const int ch = i / HW, px = i - ch * HW;
+        float* d = pl + ch * pitch + px;
+        d[0] = v[e].x; d[1] = v[e].y; d[2] = v[e].z; d[3] = v[e].w;
+      }
+    }
   }
   __syncthreads();
   const int c = tid & 63, g = tid >> 6;
@@ -607,11 +616,20 @@ __global__ void __launch_bounds__(256) wino_gy_small_kernel(const float* __restr
   const int HW = H * W, pitch = HW + 1, TH = H / 2, TW = W / 2;
   const int n = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
   const float* src = gy + ((size_t)n * M + c0) * HW;
-  for (int i = tid * 4; i < 64 * HW; i += 1024) {
-    const float4 v = *reinterpret_cast<const float4*>(src + i);
-    const int ch = i / HW, px = i - ch * HW;
-    float* d = pl + ch * pitch + px;
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  for (int i0 = tid * 4; i0 < 64 * HW; i0 += 4096) {          // four float4 loads in flight before the first LDS store
+    float4 v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i0 + e * 1024 < 64 * HW) v[e] = *reinterpret_cast<const float4*>(src + i0 + e * 1024);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = i0 + e * 1024;
+      if (i < 64 * HW) {
+        const int ch = i / HW, px = i - ch * HW;
+        float* d = pl + ch * pitch + px;
+        d[0] = v[e].x; d[1] = v[e].y; d[2] = v[e].z; d[3] = v[e].w;
+      }
+    }
   }
   __syncthreads();
   const int c = tid & 63, g = tid >> 6;
@@ -1145,10 +1163,13 @@ __global__ void w24_wgrad_output_kernel(const float* __restrict__ T, float* __re
   const float* src = T + (size_t)m * 25 * S * C + c;
   float q[5][5];
 #pragma unroll
-  for (int i = 0; i < 25; ++i) {
-    float v = 0.f;
-    for (int z = 0; z < S; ++z) v += src[((size_t)i * S + z) * C];
-    q[i / 5][i % 5] = v;
+  for (int i = 0; i < 25; ++i) q[i / 5][i % 5] = 0.f;
+  for (int z = 0; z < S; ++z) {                 // the 25 values of k-chunk z are fetched together; every sum still adds in ascending z
+    float t[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) t[i] = src[((size_t)i * S + z) * C];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) q[i / 5][i % 5] += t[i];
   }
   float t[4][5];
 #pragma unroll

@@ -19,7 +19,9 @@ __global__ void permute_sub_kernel(const float* W, float* A, int Rdim, int B, in
   for (int q = 1; q < 4; ++q) c += (q < pc.ncls && i >= pc.off[q]) ? 1 : 0;
   const int nt = pc.tl[c].n;
   const size_t K = (size_t)Rdim * nt, j = i - pc.off[c];
-  const int m = (int)(j / K);
+  // (32-bit division whenever the packed matrices hold fewer than 2^32 elements -- always, in practice: the emulated 64-bit one
+  //  was most of this kernel's 6.5 us)
+  const int m = pc.off[pc.ncls] <= 0xffffffffull ? (int)((unsigned)j / (unsigned)K) : (int)(j / K);
   const int k = (int)(j - (size_t)m * K);
   const int r = k / nt, ti = k - r * nt;
   int tap = pc.tl[c].t[0];

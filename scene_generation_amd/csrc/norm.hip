@@ -354,11 +354,26 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const float* __restri
   const float mu = mean[c], rs = rstd[c], ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
   float s1 = 0.f, s2 = 0.f;
   BnIter it(beg + threadIdx.x, HW);
-  for (long i = beg + threadIdx.x; i < end; i += 256, it.step(256)) {
-    const size_t off = ((size_t)it.n * C + c) * HW + it.p;
-    const float zv = (x[off] - mu) * rs;
-    const float g = gy[off] * act_grad_from_pre(zv * ga + be, act, slope);
-    s1 += g; s2 += g * zv;
+  // four (x, gy) pairs are fetched before the first is used -- same sums in the same order; the one-pair-per-iteration loop waited
+  // for every load in turn (4..40 dependent round trips per thread)
+  for (long i = beg + threadIdx.x; i < end; i += 1024) {
+    float xv[4], gv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool ok = i + (long)e * 256 < end;
+      const size_t off = ((size_t)it.n * C + c) * HW + it.p;
+      xv[e] = ok ? x[off] : 0.f;
+      gv[e] = ok ? gy[off] : 0.f;
+      if (ok) it.step(256);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (i + (long)e * 256 < end) {
+        const float zv = (xv[e] - mu) * rs;
+        const float g = gv[e] * act_grad_from_pre(zv * ga + be, act, slope);
+        s1 += g; s2 += g * zv;
+      }
+    }
   }
   s1 = sg_block_sum(s1, red);
   s2 = sg_block_sum(s2, red);
@@ -476,9 +491,19 @@ __global__ void channel_sum_kernel(const float* __restrict__ g, float* __restric
   const int c = blockIdx.x;
   const int cnt = N * HW;
   float s = 0.f;
-  for (int i = threadIdx.x; i < cnt; i += blockDim.x) {       // (small tensors: HW is often 1..64, where stepping an (n, p)
-    const int n = i / HW, p = i - n * HW;                      //  pair by 256 costs more than this 32-bit division -- measured)
-    s += g[((size_t)n * C + c) * HW + p];
+  // (small tensors: HW is often 1..64, where stepping an (n, p) pair by 256 costs more than a 32-bit division -- measured.
+  //  Eight loads are in flight before the first add: same sum, same order, an eighth of the dependent round trips)
+  for (int i0 = threadIdx.x; i0 < cnt; i0 += 8 * blockDim.x) {
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = min(i0 + e * (int)blockDim.x, cnt - 1);           // (clamped: an unconditional load; the tail is not added)
+      const int n = i / HW, p = i - n * HW;
+      t[e] = g[((size_t)n * C + c) * HW + p];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (i0 + e * (int)blockDim.x < cnt) s += t[e];
   }
   s = sg_block_sum(s, red);
   if (threadIdx.x == 0) out[c] = s;

@@ -141,18 +141,39 @@ __global__ void __launch_bounds__(256) smallm_wgrad_kernel(const float* __restri
     for (int k = 0; k < KS; ++k) acc[m][k] = 0.f;
   for (int ow0 = 0; ow0 < W; ow0 += CB) {
     for (int oh0 = 0; oh0 < H; oh0 += RB) {
-      __syncthreads();
-      for (int i = tid; i < XR * XW; i += 256) {
+      // staging: every global load of the tile is issued before the first LDS store (the plain "load, store" loops compiled to
+      // a wait per element: ~12 + 6 dependent round trips per tile)
+      constexpr int NX = (XR * XW + 255) / 256, NG = (MO * RB * (CB / 4) + 255) / 256;
+      float xv[NX];
+      float4 gv[NG];
+#pragma unroll
+      for (int e = 0; e < NX; ++e) {
+        const int i = tid + e * 256;
         const int r = i / XW, q = i - r * XW;
         const int ih = reflect_idx(min(oh0 + r - PAD, 2 * H - 2), H), iw = reflect_idx(min(ow0 + q - PAD, 2 * W - 2), W);
-        xs[r * XP + q] = xc[(size_t)ih * W + iw];
+        xv[e] = i < XR * XW ? xc[(size_t)ih * W + iw] : 0.f;
       }
-      for (int i = tid; i < MO * RB * (CB / 4); i += 256) {
+#pragma unroll
+      for (int e = 0; e < NG; ++e) {
+        const int i = tid + e * 256;
         const int q4 = i % (CB / 4), r = (i / (CB / 4)) % RB, m = i / (RB * (CB / 4));
         const int oh = oh0 + r, ow = ow0 + 4 * q4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M && oh < H && ow < W) v = *reinterpret_cast<const float4*>(gn + (size_t)m * HW + (size_t)oh * W + ow);
-        *reinterpret_cast<float4*>(gs + (m * RB + r) * CB + 4 * q4) = v;
+        gv[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < MO * RB * (CB / 4) && m < M && oh < H && ow < W)
+          gv[e] = *reinterpret_cast<const float4*>(gn + (size_t)m * HW + (size_t)oh * W + ow);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < NX; ++e) {
+        const int i = tid + e * 256;
+        const int r = i / XW, q = i - r * XW;
+        if (i < XR * XW) xs[r * XP + q] = xv[e];
+      }
+#pragma unroll
+      for (int e = 0; e < NG; ++e) {
+        const int i = tid + e * 256;
+        const int q4 = i % (CB / 4), r = (i / (CB / 4)) % RB, m = i / (RB * (CB / 4));
+        if (i < MO * RB * (CB / 4)) *reinterpret_cast<float4*>(gs + (m * RB + r) * CB + 4 * q4) = gv[e];
       }
       __syncthreads();
       if (kh < KS) {
