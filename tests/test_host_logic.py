@@ -464,3 +464,26 @@ def test_library_options_table_and_no_stray_getenv():
     out = subprocess.run([sys.executable, '-c', 'from scene_generation_amd import _hip; print(_hip.get_option("bn_blocks"))'],
                          env=dict(os.environ, SG_BN_BLOCKS='123'), cwd=ROOT, capture_output=True, text=True)
     assert out.stdout.strip() == '123', out.stderr
+
+
+def test_library_kernels_fit_their_register_budget():
+    """Static check of the built gfx950 code objects (tools/isa_report.py; no GPU): no product kernel spills registers to
+    scratch -- three instantiations of the register-resident InstanceNorm for 256x256 planes excepted -- and the GEMM tile
+    classes keep the resident-wave counts the launch plans are built around."""
+    import shutil
+    from tools import isa_report
+    if not (os.path.isfile(isa_report.DEFAULT_LIB) and shutil.which('objcopy')
+            and os.path.isfile(os.path.join(isa_report.LLVM, 'clang-offload-bundler'))):
+        pytest.skip('needs the built library and the ROCm LLVM tools')
+    ks = isa_report.kernels()
+    assert len(ks) > 300
+    allowed = ('instnorm_fwd_reg_kernel<1024, 64>', 'instnorm_bwd_reg_kernel<1024, 32>', 'instnorm_bwd_reg_kernel<1024, 64>')
+    spills = [(k['name'], k['scratch']) for k in ks if k['scratch'] and not k['name'].startswith(allowed)]
+    assert not spills, spills
+    dense = [k for k in ks if k['name'].startswith('igemm_kernel<T128x128')]
+    assert dense and all(k['waves_per_simd'] >= 2 and k['lds'] <= 80 * 1024 for k in dense)      # two workgroups per CU
+    t64 = [k for k in ks if k['name'].startswith('igemm_kernel<T64x64')]
+    assert t64 and all(k['waves_per_simd'] >= 3 for k in t64)
+    assert sum(1 for k in t64 if k['waves_per_simd'] >= 5) >= 0.8 * len(t64)       # the fixed-tap / K-contiguous forms: 6
+    head = [k for k in ks if k['name'].startswith('smallm_fwd_kernel<7, 3>')]
+    assert head and head[0]['vgpr'] <= 128                                          # 512 threads: two workgroups per CU
