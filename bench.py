@@ -298,7 +298,7 @@ def main():
     # DP observability: isolated all-reduce time per bucket and how long the step was exposed to the collectives
     comm = None
     if world > 1:
-        comm = {}
+        comm = {'world': world}
         for r in tr.reducers:
             r.profile = True
         d_obs = timed(tr, 3, a.warmup + 2 * a.steps + 3)
@@ -429,6 +429,25 @@ def main():
             sec['default_flags_vgg_on'] = {'images_per_s': B * n2 / d2, 'ms_per_step': 1e3 * d2 / n2, 'steps': n2,
                                            'note': '--vgg_features_weight 10 (args.py:73), He-normal VGG19 weights'}
             del tr2
+        # (1b) the boundary as the reference's loop has it (train.py:190-193): every step is handed a HOST batch.  The K host
+        # batches go through pipeline.DeviceBatchPrefetcher INSIDE the timed region (validation, host summaries, pinned
+        # staging, H2D on the copy stream one batch ahead) -- the PCIe-inclusive rate; never the headline ``value``
+        nh = max(4, min(a.steps, 10))
+        hbs = [host_batches[i % 2] for i in range(nh + 1)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        it = DeviceBatchPrefetcher(hbs[:nh], dev)
+        for i, db in enumerate(it):
+            tr.model.objs_host, tr.model.obj_to_img_host = db.objs_host, db.obj_to_img_host
+            tr.step(db.batch, use_gt=tr.draw_use_gt())
+        torch.cuda.synchronize()
+        dh = time.perf_counter() - t0
+        hb_bytes = sum(t.numel() * t.element_size() for t in host_batches[0])
+        sec['host_buffers'] = {'images_per_s': B * nh / dh, 'ms_per_step': 1e3 * dh / nh, 'steps': nh,
+                               'host_bytes_per_batch': hb_bytes,
+                               'note': 'headline configuration fed from pageable HOST batches through DeviceBatchPrefetcher '
+                                       'inside the timed loop (collate-contract validation + pinned staging + H2D on a copy '
+                                       'stream, one batch ahead); includes the first batch\'s exposed copy'}
         # (2) Trainer.step's own defaults: fast paths on AND the three dense (N,204,H,W) layouts of Model.forward written
         tr.dense_layout_outputs = True
         one_step(tr, 0)

@@ -37,6 +37,8 @@ enum { SG_LOSS_MSE_CONST = 0, SG_LOSS_MSE = 1, SG_LOSS_L1 = 2, SG_LOSS_BCE_LOGIT
        SG_LOSS_MSE_SIGMOID_CONST = 5,  /* (sigmoid(a_i) - target)^2    (lsgan_*_loss, losses.py:115-132) */
        SG_LOSS_BCE_PROB_CONST = 6 };   /* nn.BCELoss vs a constant     (GANLoss(use_lsgan=False), losses.py:147) */
 #define SG_WSUM_MAX 32
+/* return code of an index operand outside its range (the reference raises IndexError: graph.py:79-80, model.py:131) */
+#define SG_ERR_INDEX (-2)
 
 int sg_version(void);
 const char* sg_last_error_string(void);
@@ -213,6 +215,13 @@ int sg_act_fwd(const float* x, float* y, int64_t n, int act, float slope, sgStre
  * entries of a row ordered (pass, t ascending) == the order CPU scatter_add applies them (graph.py:98-101).
  * csr_off[O+1], csr_ent[2T] (t | pass<<30). */
 int sg_build_csr(const int64_t* edges /*T,2*/, int T, int O, int32_t* csr_off, int32_t* csr_ent, sgStream stream);
+/* Range check of an index operand on the device: 0 if lo <= idx[i] < hi for every i < n, else SG_ERR_INDEX with the first
+ * offending position and value in sg_last_error_string() -- what the reference's indexing raises as IndexError
+ * (obj_vecs[s_idx], graph.py:79-80; nn.Embedding, model.py:131-132; feats[bbox_to_feats], bilinear.py:36).  Synchronises the
+ * stream (a debugging aid, not part of the hot path); inside a stream capture it returns 0 unchecked.  The kernels
+ * themselves do NOT validate indices: with the option check_indices = 1 (sg_set_option / SG_CHECK_INDICES=1) sg_build_csr
+ * checks its edges this way, and the host mirror checks objs / obj_to_img / bbox_to_feats before the launches that use them. */
+int sg_check_indices(const int64_t* idx, int64_t n, int64_t lo, int64_t hi, const char* what, sgStream stream);
 /* out[t] = [obj[s_t], pred[t], obj[o_t]]  (graph.py:79-84) */
 int sg_gather_concat_fwd(const float* obj, const float* pred, const int64_t* edges, float* out,
                          int T, int Do, int Dp, sgStream stream);
@@ -343,9 +352,11 @@ int sg_cross_entropy_fwd(const float* logits, const int64_t* target, int rows, i
                          float* out, sgStream stream);
 int sg_cross_entropy_bwd(const float* logits, const int64_t* target, int rows, int classes, const float* gout,
                          float* glogits, sgStream stream);
-/* torch.optim.Adam step (no weight decay / amsgrad) over one flat fp32 buffer */
+/* torch.optim.Adam step (no weight decay / amsgrad) over one flat fp32 buffer.  The gradient enters as g * grad_scale:
+ * 1 on one GPU; 1 / world under data parallelism, where g holds the all-reduced SUM (the mean's scaling pass over the flat
+ * gradient buffer -- 8 B per parameter -- is folded into this kernel's read) */
 int sg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                 float eps, float bias_corr1, float bias_corr2_sqrt, sgStream stream);
+                 float eps, float bias_corr1, float bias_corr2_sqrt, float grad_scale, sgStream stream);
 int sg_fill(float* p, float value, int64_t n, sgStream stream);
 int sg_scale(float* p, float alpha, int64_t n, sgStream stream);
 /* y += alpha * x : a second gradient contribution to a parameter slice of the flat gradient buffer (the first one is

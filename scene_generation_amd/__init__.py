@@ -7,7 +7,12 @@ The compute path lives in csrc/libsg2im_hip.so (hand-written gfx950 HIP behind i
 CPU fallback.
 """
 import importlib
+import os
 import sys
+
+# dmabuf IPC: the host driver of the MI355X boxes supports no legacy IPC handles, and ROCr reads this variable when the runtime
+# initialises -- so the default must be in the environment before the first torch.cuda call (parallel.first_contact)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 __version__ = '0.1.0'
 _SUBMODULES = ('args', 'utils', 'layers', 'graph', 'layout', 'bilinear', 'generators', 'discriminators', 'losses',

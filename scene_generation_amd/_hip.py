@@ -108,10 +108,26 @@ def check(rc, name):
 
 
 # ---- tuning / debugging switches of the library (include/sg2im_hip.h: sg_set_option) --------------------------------
+OPTION_GENERATION = 0
+
+
 def set_option(name, value):
     """Change a launch-plan switch of the library at run time (they are otherwise fixed when the library is loaded: compiled-in
     default, or the environment variable SG_<NAME>)."""
     check(lib().sg_set_option(name.encode(), int(value)), 'sg_set_option')
+    global OPTION_GENERATION
+    OPTION_GENERATION += 1          # shape-only queries memoised on the conv descs (ops/_core._q) may depend on an option
+
+
+_opt_cache = {}
+
+
+def option_cached(name):
+    """current value of a switch, re-read from the library only after a set_option (per-launch callers)"""
+    hit = _opt_cache.get(name)
+    if hit is None or hit[0] != OPTION_GENERATION:
+        hit = _opt_cache[name] = (OPTION_GENERATION, get_option(name))
+    return hit[1]
 
 
 def get_option(name):

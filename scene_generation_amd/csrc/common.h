@@ -9,6 +9,8 @@
 #define SG_WAVE 64
 
 void sg_set_error(const char* fmt, ...);
+// range check of an index operand when the option check_indices is on (graph.hip); 0 or SG_ERR_INDEX
+int sg_check_indices_if_enabled(const int64_t* idx, int64_t n, int64_t lo, int64_t hi, const char* what, hipStream_t s);
 
 #define SG_ARG_CHECK(cond, ...)                 \
   do {                                          \
@@ -58,6 +60,7 @@ enum SgOpt {
   SG_OPT_WINO_REUSE,      // Winograd weight gradient from the forward's V and the data gradient's Ytp (no second transforms)
   SG_OPT_WINO_FOLD_CELLS, // four-wave cell-gather form of the adjoint Winograd output fold (0: one thread per channel walks the tiles)
   SG_OPT_WINO_PIPE,       // main loop of the dense Winograd GEMMs: 1 = stores at the top of the iteration, 2 = interleaved with phase 0
+  SG_OPT_CHECK_INDICES,   // debugging: range-check index operands on the device (one stream synchronisation per check); sg_check_indices
   SG_OPT_COUNT
 };
 extern std::atomic<int> g_sg_opt[SG_OPT_COUNT];

@@ -225,14 +225,57 @@ __global__ void one_hot_kernel(const int64_t* __restrict__ idx, float* __restric
   out[(size_t)r * ld + col_off + c] = (idx[r] == c) ? 1.f : 0.f;
 }
 
+// first position whose value is outside [lo, hi): atomicMin on the position => deterministic
+__global__ void index_check_kernel(const int64_t* __restrict__ idx, int64_t n, int64_t lo, int64_t hi, int* __restrict__ first) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = idx[i];
+  if (v < lo || v >= hi) atomicMin(first, (int)(i < 0x7fffffff ? i : 0x7ffffffe));
+}
+
 inline int row_threads(int width) { int t = ((width + 63) / 64) * 64; return t > 256 ? 256 : (t < 64 ? 64 : t); }
 
 }  // namespace
+
+extern "C" int sg_check_indices(const int64_t* idx, int64_t n, int64_t lo, int64_t hi, const char* what, sgStream stream) {
+  SG_ARG_CHECK(n >= 0 && (idx || n == 0), "sg_check_indices: bad arguments");
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return 0;
+  int* flag = nullptr;                                  // 4 bytes, allocated per call: this is a debugging path
+  if (hipMalloc((void**)&flag, sizeof(int)) != hipSuccess) { sg_set_error("sg_check_indices: hipMalloc failed"); return -1; }
+  int first = 0x7fffffff;
+  hipMemcpyAsync(flag, &first, sizeof(int), hipMemcpyHostToDevice, s);
+  hipLaunchKernelGGL(index_check_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, s, idx, n, lo, hi, flag);
+  hipMemcpyAsync(&first, flag, sizeof(int), hipMemcpyDeviceToHost, s);
+  hipError_t e = hipStreamSynchronize(s);
+  long long bad = 0;
+  if (e == hipSuccess && first != 0x7fffffff) {
+    int64_t v = 0;
+    hipMemcpy(&v, idx + first, sizeof(int64_t), hipMemcpyDeviceToHost);
+    bad = (long long)v;
+  }
+  hipFree(flag);
+  if (e != hipSuccess) { sg_set_error("sg_check_indices: %s", hipGetErrorString(e)); return (int)e; }
+  if (first != 0x7fffffff) {
+    sg_set_error("index out of range: %s[%d] = %lld is not in [%lld, %lld)", what ? what : "index", first, bad, (long long)lo,
+                 (long long)hi);
+    return SG_ERR_INDEX;
+  }
+  return 0;
+}
+
+int sg_check_indices_if_enabled(const int64_t* idx, int64_t n, int64_t lo, int64_t hi, const char* what, hipStream_t s) {
+  return sg_opt(SG_OPT_CHECK_INDICES) ? sg_check_indices(idx, n, lo, hi, what, (sgStream)s) : 0;
+}
 
 extern "C" int sg_build_csr(const int64_t* edges, int T, int O, int32_t* csr_off, int32_t* csr_ent, sgStream stream) {
   SG_ARG_CHECK(edges && csr_off && csr_ent && T >= 0 && O > 0, "sg_build_csr: bad arguments");
   SG_ARG_CHECK(T < (1 << PASS_SHIFT), "sg_build_csr: too many triples");
   hipStream_t s = (hipStream_t)stream;
+  // the (s, o) columns index LDS counters / object rows unchecked in every kernel that follows (graph.py:79-80 raises there)
+  if (const int rc = sg_check_indices_if_enabled(edges, 2 * (int64_t)T, 0, O, "edges (subject / object node ids)", s)) return rc;
   if (O <= CSR_LDS_NODES) {
     hipLaunchKernelGGL(csr_build_kernel, dim3(1), dim3(256), 0, s, edges, T, O, csr_off, csr_ent);
     SG_LAUNCH_CHECK("sg_build_csr");

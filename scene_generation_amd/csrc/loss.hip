@@ -114,16 +114,34 @@ __global__ void __launch_bounds__(256) ce_bwd_kernel(const float* __restrict__ l
   for (int c = lane; c < classes; c += 64) gl[(size_t)row * classes + c] = g * (expf(x[c] - m) / s - (c == t ? 1.f : 0.f));
 }
 
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            size_t n, float step_size, float beta1, float beta2, float eps, float bc2_sqrt) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float gi = g[i];
-  const float mi = m[i] + (1.f - beta1) * (gi - m[i]);        // exp_avg.lerp_(grad, 1-beta1)
-  const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;    // mul_(beta2).addcmul_(g, g, 1-beta2)
-  m[i] = mi; v[i] = vi;
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float gscale, float step_size, float beta1,
+                                         float beta2, float eps, float bc2_sqrt) {
+  const float gi = g * gscale;                               // 1 / world under data parallelism (the all-reduce SUMs), else 1
+  const float mi = m + (1.f - beta1) * (gi - m);             // exp_avg.lerp_(grad, 1-beta1)
+  const float vi = v * beta2 + (1.f - beta2) * gi * gi;      // mul_(beta2).addcmul_(g, g, 1-beta2)
+  m = mi; v = vi;
   const float denom = sqrtf(vi) / bc2_sqrt + eps;
-  p[i] = p[i] - step_size * (mi / denom);                      // addcdiv_(exp_avg, denom, value=-step_size)
+  p = p - step_size * (mi / denom);                          // addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+// four parameters per thread through 16-byte loads / stores (n4 = n / 4 float4 groups); the < 4 tail elements go to the
+// last threads of the grid one by one.  Same arithmetic per element as the scalar form.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t n, size_t n4, float gscale, float step_size, float beta1, float beta2, float eps,
+                            float bc2_sqrt) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) {
+    float4 pi = ((const float4*)p)[i], mi = ((const float4*)m)[i], vi = ((const float4*)v)[i];
+    const float4 gi = ((const float4*)g)[i];
+    adam_one(pi.x, gi.x, mi.x, vi.x, gscale, step_size, beta1, beta2, eps, bc2_sqrt);
+    adam_one(pi.y, gi.y, mi.y, vi.y, gscale, step_size, beta1, beta2, eps, bc2_sqrt);
+    adam_one(pi.z, gi.z, mi.z, vi.z, gscale, step_size, beta1, beta2, eps, bc2_sqrt);
+    adam_one(pi.w, gi.w, mi.w, vi.w, gscale, step_size, beta1, beta2, eps, bc2_sqrt);
+    ((float4*)m)[i] = mi; ((float4*)v)[i] = vi; ((float4*)p)[i] = pi;
+  } else {
+    const size_t j = 4 * n4 + (i - n4);
+    if (j < n) adam_one(p[j], g[j], m[j], v[j], gscale, step_size, beta1, beta2, eps, bc2_sqrt);
+  }
 }
 
 __global__ void fill_kernel(float* __restrict__ p, float value, size_t n) {
@@ -225,12 +243,15 @@ extern "C" int sg_cross_entropy_bwd(const float* logits, const int64_t* target, 
 }
 
 extern "C" int sg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                            float eps, float bias_corr1, float bias_corr2_sqrt, sgStream stream) {
+                            float eps, float bias_corr1, float bias_corr2_sqrt, float grad_scale, sgStream stream) {
   SG_ARG_CHECK(p && g && m && v && n > 0 && bias_corr1 > 0.f && bias_corr2_sqrt > 0.f, "sg_adam_step: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   SgProfScope prof(SG_K_ADAM, s, 0, 28.0 * (double)n);
-  hipLaunchKernelGGL(adam_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, s, p, g, m, v, (size_t)n, lr / bias_corr1, beta1, beta2,
-                     eps, bias_corr2_sqrt);
+  const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  const size_t n4 = vec ? (size_t)n / 4 : 0;
+  const size_t threads = n4 + ((size_t)n - 4 * n4);
+  hipLaunchKernelGGL(adam_kernel, dim3(sg_cdiv(threads, 256)), dim3(256), 0, s, p, g, m, v, (size_t)n, n4, grad_scale,
+                     lr / bias_corr1, beta1, beta2, eps, bias_corr2_sqrt);
   SG_LAUNCH_CHECK("sg_adam_step");
   return 0;
 }

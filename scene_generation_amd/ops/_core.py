@@ -91,7 +91,21 @@ def _call(name, *args):
         fn = _fn_cache[name] = getattr(_L(), name)
     rc = fn(*args)
     if rc != 0:
+        if rc == SG_ERR_INDEX:          # an index operand outside its range: what the reference's indexing raises
+            raise IndexError('%s: %s' % (name, _hip.last_error()))
         raise RuntimeError('%s failed (rc=%d): %s' % (name, rc, _hip.last_error()))
+
+
+SG_ERR_INDEX = -2
+
+
+def check_indices(idx, lo, hi, what):
+    """With the library option ``check_indices`` on (``_hip.set_option('check_indices', 1)`` / SG_CHECK_INDICES=1): range-check
+    an int64 index operand on the device and raise IndexError like the reference's indexing does (graph.py:79-80,
+    model.py:131, bilinear.py:36).  The kernels themselves read indices unchecked.  One stream synchronisation per check."""
+    if idx is not None and idx.is_cuda and _hip.option_cached('check_indices'):
+        idx = idx if idx.is_contiguous() else idx.contiguous()
+        _call('sg_check_indices', _p(idx), idx.numel(), int(lo), int(hi), what.encode(), _stream())
 
 
 # =============================================================================================
@@ -210,7 +224,9 @@ def _conv_desc(N, C1, C2, H, W, Cout, KS, stride, pad, reflect, upsample, OH, OW
 
 def _q(d, name, *extra):
     """memoised shape-only query ``name(desc, *extra)`` of the library"""
-    key = (name,) + extra
+    # (the answers depend on run-time options -- wino_reuse, wino24, w24_pmin, ...: the generation counter of
+    # _hip.set_option is part of the key, so a changed option is never answered from a stale memo: ADVICE r4)
+    key = (name, _hip.OPTION_GENERATION) + extra
     v = d._memo.get(key)
     if v is None:
         v = d._memo[key] = getattr(_L(), name)(d._ref, *extra)
@@ -320,10 +336,11 @@ UPCONV = os.environ.get('SG_UPCONV', '1') != '0'
 # optimiser / misc
 # =============================================================================================
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step):
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0):
     bc1 = 1.0 - beta1 ** step
     bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
-    _call('sg_adam_step', _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, bc1, bc2_sqrt, _stream())
+    _call('sg_adam_step', _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, bc1, bc2_sqrt, float(grad_scale),
+          _stream())
 
 
 def fill_(t, value):

@@ -36,6 +36,7 @@ class GatherConcatFn(Function):
     def forward(ctx, obj, pred, edges, off, ent):
         obj, pred = _f32(obj), _f32(pred)
         T, Do, Dp = edges.size(0), obj.size(1), pred.size(1)
+        _core.check_indices(edges, 0, obj.size(0), 'edges (subject / object node ids)')      # graph.py:79-80
         out = torch.empty(T, 2 * Do + Dp, dtype=torch.float32, device=obj.device)
         _call('sg_gather_concat_fwd', _p(obj), _p(pred), _p(edges), _p(out), T, Do, Dp, _stream())
         ctx.dims = (obj.size(0), T, Do, Dp)
@@ -92,6 +93,7 @@ class EmbeddingFn(Function):
     @staticmethod
     def forward(ctx, table, idx):
         table, idx = _f32(table), _i64(idx)
+        _core.check_indices(idx, 0, table.size(0), 'embedding index')                         # model.py:131-132
         out = torch.empty(idx.numel(), table.size(1), dtype=torch.float32, device=table.device)
         _call('sg_embedding_fwd', _p(table), _p(idx), _p(out), idx.numel(), table.size(1), _stream())
         ctx.rows = table.size(0)

@@ -17,6 +17,7 @@ from .graph import (one_hot)
 
 def segment_offsets(obj_to_img, N):
     obj_to_img = _i64(obj_to_img, 'obj_to_img')
+    _core.check_indices(obj_to_img, 0, N, 'obj_to_img')
     off = torch.empty(N + 1, dtype=torch.int32, device=obj_to_img.device)
     _call('sg_segment_offsets', _p(obj_to_img), obj_to_img.numel(), N, _p(off), _stream())
     return off
@@ -319,6 +320,7 @@ class CropBBoxFn(Function):
     @staticmethod
     def forward(ctx, feats, boxes, idx, HH, WW):
         feats, boxes, idx = _f32(feats, 'feats'), _f32(boxes, 'bbox'), _i64(idx, 'bbox_to_feats')
+        _core.check_indices(idx, 0, feats.size(0), 'bbox_to_feats')                           # bilinear.py:36
         N, C, H, W = feats.shape
         B = boxes.size(0)
         out = torch.empty(B, C, HH, WW, dtype=torch.float32, device=feats.device)

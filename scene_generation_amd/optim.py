@@ -73,10 +73,15 @@ class FusedAdam:
         # same layout as the gradient buffer, all-zero outside a step
         self._contrib = [0] * n
         self._spill, self._spill_used, self._fold_queued = [], 0, False
+        self._spill_k, self._spill_dirty = [0] * n, False     # per parameter: spilled contributions since the last fold
         # False: later contributions are added into the gradient slice at once (temporary + axpy).  A reducer that sends
         # buckets to the all-reduce DURING the backward needs that: a spilled contribution only reaches the slice when the
         # backward ends, after the bucket may have left (parallel.GradReducer(overlap=True), Trainer)
         self.use_spill = True
+        # the gradient enters the update as grad * grad_scale; a data-parallel reducer whose all-reduce SUMs sets 1 / world for
+        # the step that follows (GradReducer.wait(defer_scale=True)) instead of scaling the flat buffer in place: after such a
+        # step() ``p.grad`` holds the sum over ranks, not the mean.  Reset to 1 by step().
+        self.grad_scale = 1.0
         self.pre_step_hooks = []          # e.g. GradReducer.wait
         self.zero_grad_hooks = []         # e.g. GradReducer.begin_step
         self.grad_listeners = []          # callables(i): parameter i just received (a contribution to) its gradient
@@ -101,10 +106,14 @@ class FusedAdam:
 
     def spill_view(self, i):
         """where the NEXT contribution to parameter ``i`` (which already has at least one) is written.  Only valid while a
-        backward is running (ops.GradOut calls it from inside autograd Functions)."""
-        k = max(self._contrib[i], 1) - 1
+        backward is running (ops.GradOut calls it from inside autograd Functions).  The index counts contributions since the
+        last FOLD (every backward folds and clears the buffers when it ends), not since the last zero_grad(): gradient
+        accumulation over micro-batches re-uses spill buffer 0 instead of growing one buffer per backward."""
+        k = self._spill_k[i]
+        self._spill_k[i] = k + 1
+        self._spill_dirty = True
         while len(self._spill) <= k:
-            self._spill.append(torch.zeros_like(self.fp.grad))
+            self._new_spill_buffer()
         self._spill_used = max(self._spill_used, k + 1)
         if not self._fold_queued:
             # fold when the backward that is running right now ends: ``p.grad`` is complete as soon as ``.backward()`` returns
@@ -115,12 +124,29 @@ class FusedAdam:
         p, o = self.fp.params[i], self.fp.offsets[i]
         return self._spill[k][o:o + p.numel()].view(p.shape)
 
+    def _new_spill_buffer(self):
+        """A zeroed buffer that kernels of ANY stream may write slices of behind autograd's back.  With side streams on
+        (streams.py) a zero fill still in flight on the allocating stream could wipe a slice another stream has already
+        written, so the fill is completed before the buffer is handed out: one host synchronisation per buffer
+        per optimiser, in the first step only (the buffers live as long as the optimiser)."""
+        buf = torch.zeros_like(self.fp.grad)
+        if streams.ENABLED and buf.is_cuda:
+            torch.cuda.current_stream(buf.device).synchronize()
+        self._spill.append(buf)
+
     def _fold_spill(self):
-        """grad = ((grad + spill[0]) + spill[1]) + ...: the order the per-parameter adds had; clears the spill buffers"""
+        """grad = ((grad + spill[0]) + spill[1]) + ...: the order the per-parameter adds had; clears the spill buffers.
+        Runs as an end-of-backward callback (and from step()): weight-gradient kernels of side streams write the gradient and
+        spill slices behind autograd's back, so the reader joins them first (streams.py's rule for these buffers)."""
         self._fold_queued = False
+        if self._spill_used:
+            streams.join_all(self.fp.grad.device)
         for k in range(self._spill_used):
             ops.add_clear_(self.fp.grad, self._spill[k])
         self._spill_used = 0
+        if self._spill_dirty:
+            self._spill_k = [0] * len(self.fp.params)
+            self._spill_dirty = False
 
     @property
     def step_count(self):
@@ -141,6 +167,7 @@ class FusedAdam:
         self.fp.attach_grads()
         self._touched = [False] * len(self.fp.params)
         self._contrib = [0] * len(self.fp.params)
+        self._spill_k, self._spill_dirty = [0] * len(self.fp.params), False
         for h in self.zero_grad_hooks:
             h()
 
@@ -165,10 +192,11 @@ class FusedAdam:
                 j += 1
             lo, hi = fp.offsets[i], fp.offsets[j] + fp.params[j].numel()
             ops.adam_step(fp.flat[lo:hi], fp.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
-                          self.betas[0], self.betas[1], self.eps, st + 1)
+                          self.betas[0], self.betas[1], self.eps, st + 1, self.grad_scale)
             for q in range(i, j + 1):
                 self.steps[q] = st + 1
             i = j + 1
+        self.grad_scale = 1.0
 
     # ---- torch.optim.Adam-compatible (de)serialisation ----
     def state_dict(self):

@@ -112,6 +112,10 @@ def first_contact(device, timeout_s=120.0):
 
 def init_distributed(backend=None):
     """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  Returns (rank, world)."""
+    # dmabuf IPC (see first_contact).  ROCr reads the variable when the runtime initialises, so the default has to be in the
+    # environment BEFORE the first torch.cuda call of the process -- the package's __init__ sets it at import too; a launcher
+    # should export it (ADVICE r4: setting it after torch.cuda.is_available() is too late for this process)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world == 1:
@@ -121,7 +125,6 @@ def init_distributed(backend=None):
     if backend == 'nccl':
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (see first_contact)
     if not dist.is_initialized():
         import datetime
         dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
@@ -155,6 +158,11 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.overlap = overlap
         self.optimizer = optimizer
+        if overlap and optimizer is not None and hasattr(optimizer, 'use_spill'):
+            # a spilled (2nd, 3rd, ...) contribution only reaches the gradient slice when the backward ends -- after this
+            # reducer may have sent the slice's bucket away: with overlap the optimiser must add late contributions at once,
+            # where late_contribution() can see them
+            optimizer.use_spill = False
         self.buckets = []            # (start, end, [param indices])
         esz = self.fp.grad.element_size()
         cur, cur_end = [], None
@@ -236,8 +244,15 @@ class GradReducer:
             while self._next < len(self.buckets):
                 self._launch(self._next)
 
-    def wait(self):
-        """Complete the mean all-reduce of every bucket; disarms the reducer until the next begin_step()."""
+    def wait_deferred_scale(self):
+        """``wait(defer_scale=True)``: the pre-step hook the Trainer registers on the owning FusedAdam"""
+        self.wait(defer_scale=True)
+
+    def wait(self, defer_scale=False):
+        """Complete the mean all-reduce of every bucket; disarms the reducer until the next begin_step().
+        ``defer_scale``: leave the SUM in the gradient buffer and hand the 1 / world factor to the owning optimiser's next
+        step() (FusedAdam.grad_scale: the Adam kernel multiplies while it reads the gradient) -- saves one read + write pass
+        over the flat gradient buffer and one launch per optimiser and step (1.5 GB of HBM traffic for the generator)."""
         if self.world > 1 and self.active:
             while self._next < len(self.buckets):        # (also when nobody armed the reducer: hooks were ignored)
                 self._launch(self._next)
@@ -250,8 +265,11 @@ class GradReducer:
             if timed:
                 e1.record()
                 self._stall_events.append((e0, e1))
-            self.fp.grad.mul_(1.0 / self.world)
             opt = self.optimizer
+            if defer_scale and opt is not None and hasattr(opt, 'grad_scale'):
+                opt.grad_scale = 1.0 / self.world
+            else:
+                self.fp.grad.mul_(1.0 / self.world)
             if opt is not None:                          # every rank must update the same parameters
                 flags = agree([1.0 if t else 0.0 for t in opt._touched], dist.ReduceOp.MAX, self.fp.grad.device) \
                     if self.group is None else self._agree_in_group(opt._touched)

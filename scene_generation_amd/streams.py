@@ -114,3 +114,4 @@ def join_all(device=None):
     for s in live:
         if s != cur:
             cur.wait_stream(s)
+

@@ -114,13 +114,15 @@ class Trainer:
                     broadcast_params(opt.fp)
                     # every generator parameter is used once per step, so its gradient is final when it is delivered and
                     # the bucket all-reduces overlap the backward; discriminator parameters collect several
-                    # contributions per step (fake / real / wrong passes) and are reduced in wait() (<= 24 MB each)
+                    # contributions per step (fake / real / wrong passes): their one bucket (<= 24 MB each) leaves when
+                    # their backward has ended (flush() in _finish_d_step) and runs under the steps that follow
                     r = GradReducer(opt.fp, optimizer=opt, overlap=opt is self.optimizer)
                     opt.use_spill = not r.overlap      # (spilled contributions are folded in after the buckets have left)
                     opt.grad_listeners.append(r.param_ready)
                     opt.late_listeners.append(r.late_contribution)
                     opt.zero_grad_hooks.append(r.begin_step)
-                    opt.pre_step_hooks.append(r.wait)
+                    # the 1 / world of the mean is applied by the Adam kernel while it reads the gradient (no scaling pass)
+                    opt.pre_step_hooks.append(r.wait_deferred_scale)
                     self.reducers.append(r)
 
     def _adam(self, module, lr):
@@ -323,14 +325,22 @@ class Trainer:
             L.set_value('total_loss', L.total_loss)
             self.optimizer.zero_grad()
             L.total_loss.backward(retain_graph=bool(shared))
+        self._step_or_defer(self.optimizer)
+
+    def _step_or_defer(self, opt):
+        """``opt.step()`` -- or, data parallel inside Trainer.step: send the remaining buckets of its gradient to the all-reduce
+        now (no wait) and take the Adam step at the end of the iteration.  Nothing between here and there reads the
+        parameters ``opt`` owns (the generator's: every later sub-step consumes tensors computed before; a discriminator's: the
+        generator step has already used it, the other discriminator steps never do), so the result is the same while the
+        collective runs under the sub-steps that follow instead of stalling the stream.  The collectives are issued in
+        program order, the same on every rank."""
         if getattr(self, '_defer_g_step', False):
-            # data parallel, inside Trainer.step: start the all-reduce of the generator gradients now and take the Adam step
-            # after the discriminator steps (which read no generator parameter): the collective runs under them
             for r in self.reducers:
-                if r.optimizer is self.optimizer:
+                if r.optimizer is opt:
                     r.flush()
+            self._deferred_steps.append(opt)
         else:
-            self.optimizer.step()
+            opt.step()
 
     def _real_and_wrong_pass(self, lay, imgs, shared):
         """(layout, real images) and (wrong-texture layout, real images) -- the "real" and "wrong" passes of the image
@@ -363,7 +373,7 @@ class Trainer:
             L.add_loss(ac_loss_fake, 'd_ac_loss_fake')
             self.optimizer_d_obj.zero_grad()
             L.total_loss.backward()
-            self.optimizer_d_obj.step()
+            self._step_or_defer(self.optimizer_d_obj)
 
     def train_mask_discriminator(self, masks, masks_pred, objs):
         if self.mask_discriminator is not None:
@@ -381,7 +391,7 @@ class Trainer:
             self.optimizer_d_mask.zero_grad()
             # inputs=: a shared forward still hangs off the generator's graph; only the discriminator leaves are wanted
             torch.autograd.backward(L.total_loss, inputs=list(self.mask_discriminator.parameters()))
-            self.optimizer_d_mask.step()
+            self._step_or_defer(self.optimizer_d_mask)
 
     def train_image_discriminator(self, imgs, imgs_pred, layout, layout_wrong):
         if self.netD is not None:
@@ -402,7 +412,7 @@ class Trainer:
             L.add_loss(self.criterionGAN(pred_real, True), 'd_img_gan_real_loss', 0.5)
             self.optimizer_d_img.zero_grad()
             torch.autograd.backward(L.total_loss, inputs=list(self.netD.parameters()))
-            self.optimizer_d_img.step()
+            self._step_or_defer(self.optimizer_d_img)
             self._shared = {}
 
     def discriminate(self, input_label, test_image):
@@ -441,19 +451,21 @@ class Trainer:
         finally:
             self.model.lazy_layouts = False
         imgs_pred, boxes_pred, masks_pred, layout, layout_pred, layout_wrong = model_out
-        # Under data parallelism the generator's Adam step moves behind the discriminator steps (they consume only tensors
-        # computed above and no generator parameter, so the result is the same): its 765 MB gradient all-reduce then overlaps
-        # their compute instead of stalling the stream.  (train.py's own loop calls the four functions itself: unchanged.)
+        # Under data parallelism the four Adam steps move to the end of the iteration (_step_or_defer): the generator's
+        # 765 MB gradient all-reduce and the discriminators' buckets then overlap the sub-steps that follow them instead of
+        # stalling the stream.  (train.py's own loop calls the four functions itself: unchanged.)
         self._defer_g_step = bool(self.reducers) and getattr(self, 'overlap_g_reduce', True)
+        self._deferred_steps = []
         try:
             self.train_generator(imgs, imgs_pred, masks, masks_pred, layout, objs, boxes, boxes_pred, obj_to_img, use_gt)
             self.train_mask_discriminator(masks, masks_pred.detach(), objs)
             self.train_obj_discriminator(imgs, imgs_pred.detach(), objs, boxes, boxes.detach(), obj_to_img)
             self.train_image_discriminator(imgs, imgs_pred.detach(), layout.detach(), layout_wrong.detach())
-            if self._defer_g_step:
-                self.optimizer.step()
+            for opt in self._deferred_steps:      # in the order the reduces were issued: G, mask D, object D, image D
+                opt.step()
         finally:
             self._defer_g_step = False
+            self._deferred_steps = []
         if getattr(self, 'dense_layout_outputs', True):
             for lay in (layout, layout_pred, layout_wrong):
                 ops.ensure_dense(lay)

@@ -11,6 +11,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: a full-size case whose CPU oracle needs minutes (still part of -m gpu)')
 
 
 def pytest_collection_modifyitems(config, items):

@@ -33,7 +33,9 @@ def _make(distributed, device='cuda:0'):
     grads = {}
     for n in OPTS:
         o = getattr(tr, n)
-        o.pre_step_hooks.append(lambda o=o, n=n: grads.setdefault(n, o.fp.grad.detach().cpu().clone()))   # first step only
+        # first step only.  Under data parallelism the buffer holds the all-reduced SUM here and the optimiser's grad_scale
+        # the 1 / world the Adam kernel applies while reading it (this hook runs after the reducer's)
+        o.pre_step_hooks.append(lambda o=o, n=n: grads.setdefault(n, (o.fp.grad.detach() * o.grad_scale).cpu().clone()))
     return tr, grads
 
 
@@ -117,38 +119,45 @@ def test_two_rank_hip_trainer_matches_sequential_shards(backend):
         assert np.array_equal(res[0][2][n], res[1][2][n]), '%s: ranks diverged after two steps' % n
 
 
-def test_bench_dp_leg_executes_two_ranks_on_one_gpu():
+@pytest.mark.parametrize('world,per_gpu,steps', [(2, 8, 2), (8, 2, 1)])
+def test_bench_dp_leg_executes_two_ranks_on_one_gpu(world, per_gpu, steps):
     """bench.py's multi-GPU leg exactly as the driver launches it (``python -m torch.distributed.run --nproc-per-node N bench.py
-    --gpus N``), with two ranks sharing this box's one GPU over gloo (SG_DIST_BACKEND=gloo SG_SHARE_GPU=1): first-contact check,
-    Trainer(distributed=True) at FULL widths (ten >= 64 MB generator buckets), the deferred generator step, ``time_buckets``,
-    ``exposed_ms`` and the JSON contract.  VERDICT r3: the first 8-GPU run must not be the first execution of this code."""
+    --gpus N``), with N = 2 and N = 8 ranks sharing this box's one GPU over gloo (SG_DIST_BACKEND=gloo SG_SHARE_GPU=1):
+    first-contact check, Trainer(distributed=True) at FULL widths (ten >= 64 MB generator buckets), the Adam steps deferred
+    behind the reduces, ``time_buckets``, ``exposed_ms`` and the JSON contract.  VERDICT r3 / r4: the first 8-GPU run must not be
+    the first execution of this code -- the world-8 case is the process count, rank arithmetic and bucket schedule of
+    configs[2] with everything but the transport (gloo through host memory instead of RCCL over xGMI)."""
     import json
     import subprocess
     env = dict(os.environ, SG_DIST_BACKEND='gloo', SG_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '3',
-           '--batch_per_gpu', '8', '--no_secondary', '--no_legs', '--cpu_baseline', 'off']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps',
+           str(steps), '--warmup', '3', '--batch_per_gpu', str(per_gpu), '--no_secondary', '--no_legs', '--cpu_baseline', 'off']
+    if world > 2:
+        cmd.append('--no_prof')            # (eight ranks time-slice one GPU: the per-launch event pass adds nothing here)
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, 'bench.py --gpus 2 failed:\n%s\n%s' % (r.stdout[-3000:], r.stderr[-6000:])
+    assert r.returncode == 0, 'bench.py --gpus %d failed:\n%s\n%s' % (world, r.stdout[-3000:], r.stderr[-6000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
     assert len(lines) == 1, 'exactly ONE JSON line from rank 0, got %d:\n%s' % (len(lines), r.stdout[-3000:])
     out = json.loads(lines[0])
     try:
         d = os.path.join(ROOT, 'gpurun_out')
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, 'bench_dp2_gloo.json'), 'w') as f:
+        with open(os.path.join(d, 'bench_dp%d_gloo.json' % world), 'w') as f:
             json.dump(out, f, indent=1, sort_keys=True)
     except OSError:
         pass
-    assert out['n_gpus'] == 2 and out['rccl_ranks'] == 2 and out['dist_backend'] == 'gloo'
-    assert out['scaling'] == 'weak' and out['config']['global_batch'] == 16 and out['config']['parallelism'] == 'dp2'
-    assert out['steps'] == 2 and out['warmup'] == 3 and out['value'] > 0 and out['ms_per_step'] > 0
-    assert abs(out['value'] - 16 * 2 / (out['ms_per_step'] * 2e-3)) < 1e-6 * out['value']       # whole-job images / max-rank time
+    assert out['n_gpus'] == world and out['rccl_ranks'] == world and out['dist_backend'] == 'gloo'
+    assert out['scaling'] == 'weak' and out['config']['global_batch'] == 16 and out['config']['parallelism'] == 'dp%d' % world
+    assert out['steps'] == steps and out['warmup'] == 3 and out['value'] > 0 and out['ms_per_step'] > 0
+    assert abs(out['value'] - 16 * steps / (out['ms_per_step'] * steps * 1e-3)) < 1e-6 * out['value']   # whole-job images / max-rank time
     ar = out['allreduce']
+    assert ar['world'] == world
     # 764.7 MB of generator gradient in 64 MB buckets that close at parameter boundaries: 10 of them
     assert ar['G']['buckets'] >= 8 and ar['G']['bytes'] > 700e6 and ar['G']['overlap_mode'] is True
     for name in ('D_img', 'D_obj', 'D_mask'):
         assert ar[name]['buckets'] >= 1 and ar[name]['isolated_allreduce_ms'] > 0
     assert ar['overlap_fraction'] is not None and ar['overlap_fraction'] == ar['overlap_fraction']      # finite, not NaN
     assert ar['isolated_ms_per_step'] > 0 and ar['exposed_ms_per_step'] >= 0
-    assert 'roofline' in out and out['roofline']['frac'] > 0
+    if world == 2:
+        assert 'roofline' in out and out['roofline']['frac'] > 0

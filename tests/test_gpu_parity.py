@@ -1418,18 +1418,24 @@ def _dump(name, obj):
         pass
 
 
-def _assert_step_metrics(m, tag, out_tol, loss_tol):
+def _assert_step_metrics(m, tag, out_tol, loss_tol, cos_min=0.9995, worst_tol=3e-2):
     bad = []
     for k, v in m.items():
         if k.startswith('out_') and not v <= out_tol:
             bad.append((k, v))
         elif k.startswith('loss_') and not v <= loss_tol:
             bad.append((k, v))
-        elif k.startswith('cos_') and not v > 0.9995:
+        elif k.startswith('cos_') and not v > cos_min:
             bad.append((k, v))
-        elif k.startswith('worst_tensor_rel_') and not v <= 3e-2:
+        elif k.startswith('worst_tensor_rel_') and not v <= worst_tol:
             bad.append((k, v))
     assert not bad, '%s: %s' % (tag, bad)
+
+
+# Whole-step bounds of the full-size cases, ~2.5x the deviations measured on MI355X (profiles/r04_parity_headline_n32.json,
+# r04_parity_config5_step.json: imgs_pred 4.2e-5, losses 1.9e-7, generator gradient cosine 0.999982..0.999997, worst tensor
+# 8.7e-3 / 1.15e-2) -- VERDICT r4: the round-2 bounds (3e-4 / 2e-3 / 0.9995 / 3e-2) let a 5x accuracy regression pass
+FULL_SIZE_BOUNDS = dict(out_tol=1e-4, loss_tol=1e-6, cos_min=0.9999, worst_tol=2.5e-2)
 
 
 def test_full_step_at_benchmark_shape_vs_oracle(hip):
@@ -1516,7 +1522,7 @@ def test_full_step_n32_vs_oracle(hip):
     out = tr.step(batch_to(batch, DEV), use_gt=True)
     m = _step_metrics(tr, ref, out, out_ref, snaps)
     _dump('parity_headline_n32.json', m)
-    _assert_step_metrics(m, 'headline_n32', 3e-4, 2e-3)
+    _assert_step_metrics(m, 'headline_n32', **FULL_SIZE_BOUNDS)
 
 
 def test_config5_step_vs_oracle(hip):
@@ -1540,7 +1546,67 @@ def test_config5_step_vs_oracle(hip):
     out = tr.step(batch_to(b, DEV), use_gt=True)
     m = _step_metrics(tr, ref, out, out_ref, snaps)
     _dump('parity_config5_step.json', m)
-    _assert_step_metrics(m, 'config5', 3e-4, 2e-3)
+    _assert_step_metrics(m, 'config5', **FULL_SIZE_BOUNDS)
+
+
+@pytest.mark.slow
+def test_config5_step_n32_vs_oracle(hip):
+    """BASELINE configs[4] at ITS size: 32 objects + __image__ and 96 triples per image, N = 32 -- O = 1056,
+    T = 3072, the shape of bench.py's c5 leg -- one full G+D step against the oracle at default widths.  The oracle needs
+    a minute or two on the GPU box's host cores (1056 crops / masks through the object-side networks)."""
+    from scene_generation_amd.synthetic import make_config_batch
+    argv = ['--image_size', '128,128', '--batch_size', '32', '--vgg_features_weight', '0', '--output_dir', '/tmp/o']
+    args, ref, tr = _trainer_pair(argv, make_vocab(), False)
+    _sync_state(ref, tr)
+    tr.model.layout_objects_hint = 33
+    snaps, _ = _grad_snapshots(ref, tr)
+    b = make_config_batch('c5', seed=2000)                 # the first host batch of bench.py's c5 leg
+    assert b.objs.numel() == 1056 and b.triples.size(0) == 3072
+    noise = det((1, args.mask_noise_dim), 191)
+    ref.model.noise_override = tr.model.noise_override = noise
+    random.seed(29)
+    out_ref = ref.step(b, use_gt=True)
+    random.seed(29)
+    out = tr.step(batch_to(b, DEV), use_gt=True)
+    m = _step_metrics(tr, ref, out, out_ref, snaps)
+    _dump('parity_config5_step_n32.json', m)
+    _assert_step_metrics(m, 'config5_n32', **FULL_SIZE_BOUNDS)
+
+
+def test_check_indices_option_raises_index_error(hip):
+    """``sg_set_option("check_indices", 1)``: a triple that names a node outside the batch, an object class outside the
+    vocabulary and a crop that names an image outside the batch raise IndexError -- what the reference's indexing does at
+    graph.py:79-80, model.py:131-132 and bilinear.py:36 -- instead of reading / corrupting memory; valid operands pass; with
+    the option off (the default) nothing is checked and nothing synchronises."""
+    from scene_generation_amd import _hip
+    from scene_generation_amd.graph import GraphTripleConv
+    assert _hip.get_option('check_indices') == 0
+    m = GraphTripleConv(16, output_dim=16, hidden_dim=32).to(DEV)
+    obj, pred = torch.randn(6, 16, device=DEV), torch.randn(4, 16, device=DEV)
+    good = torch.tensor([[0, 1], [2, 3], [4, 5], [5, 0]], device=DEV)
+    bad = good.clone()
+    bad[2, 1] = 6                                          # one past the last node
+    neg = good.clone()
+    neg[0, 0] = -1
+    table = torch.randn(5, 8, device=DEV)
+    feats, boxes = torch.randn(2, 3, 8, 8, device=DEV), torch.tensor([[0., 0., 1., 1.]] * 3, device=DEV)
+    _hip.set_option('check_indices', 1)
+    try:
+        m(obj, pred, good)
+        for e in (bad, neg):
+            with pytest.raises(IndexError, match='edges'):
+                m(obj, pred, e)
+            with pytest.raises(IndexError, match='edges'):
+                hip.build_csr(e.clone(), 6)                # the C entry point itself (sg_build_csr returns SG_ERR_INDEX)
+        hip.embedding(table, torch.tensor([0, 4, 2], device=DEV))
+        with pytest.raises(IndexError, match=r'\[1\] = 5 is not in \[0, 5\)'):
+            hip.embedding(table, torch.tensor([0, 5, 2], device=DEV))
+        hip.CropBBoxFn.apply(feats, boxes, torch.tensor([0, 1, 1], device=DEV), 4, 4)
+        with pytest.raises(IndexError, match='bbox_to_feats'):
+            hip.CropBBoxFn.apply(feats, boxes, torch.tensor([0, 2, 1], device=DEV), 4, 4)
+    finally:
+        _hip.set_option('check_indices', 0)
+    m(obj, pred, good)                                     # unchecked path still runs
 
 
 def test_step_is_bit_reproducible(hip):
