@@ -142,6 +142,12 @@ int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const float* x, f
 /* gx [N, C1, H, W] (all input channels): Winograd on the padded gradient grid + reflection fold */
 int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const float* w, float* gx, const float* ut_saved,
                          float* ytp_save, void* ws, size_t ws_bytes, sgStream stream);
+/* The GEMM stage of the Winograd convs on its own (the transforms of layers.py:251-270's convs aside):
+ *   c[m][z*cols + j] = sum_k a[z][m][k] * b[z*cols + j][k],   z < nbatch   (both operands K-contiguous, fp32 MFMA)
+ * tile: 0 = 128x128 (the product path), 1 = 64x128, 2 = 64x64; M, cols multiples of the tile, K of 32.  Exposed for
+ * micro-benchmarks of candidate Winograd forms (tools/bench_wino_gemm.py: the F(4x4,3x3) study) and for tests. */
+int sg_batched_gemm_nt(const float* a, const float* b, float* c, int nbatch, int M, int cols, int K, int tile,
+                       sgStream stream);
 /* Winograd F(2x2, 4x4) for the stride-1 4x4 convs of the PatchGANs (reference discriminators.py:221-228:
    nn.Conv2d(nf_prev, nf, kernel_size=4, stride=1, padding=2), 256 -> 512 channels: the largest layer of the discriminator steps):
    KS 4, stride 1, zero padding 0..3, one source, C1 and Cout multiples of 128, >= 256 output tiles.  25 multiplies per 2x2

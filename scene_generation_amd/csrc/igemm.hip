@@ -864,6 +864,29 @@ void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, in
 }
 
 
+// The same batched GEMM on other tiles, for the micro-benchmark behind sg_batched_gemm_nt (tools/bench_wino_gemm.py): the
+// F(4x4,3x3) study of round 5 needed the 36 x [1024 x 1024] x [1024 x 128] shape on 64-row tiles (128x128 tiles give it 288
+// workgroups for 256 CUs).  tile: 0 = 128x128, 1 = 64x128, 2 = 64x64; all 32-deep, software-pipelined, plain epilogue.
+using CfgDI64W = TileCfg<64, 128, 2, 2, 2>;
+using CfgDI64 = TileCfg<64, 64, 2, 2, 2>;
+void wino_bgemm_tile(int tile, const float* A, const float* B, float* Cout, int M, int cols, int K, double flops, hipStream_t s, int NB) {
+  sgk::t_alg_bytes = 4.0 * NB * ((double)M * K + (double)cols * K + (double)M * cols);
+  t_batch = BatchInfo{}; t_batch.cols_per_batch = cols; t_batch.nbatch = NB; t_batch.a_stride = M * K; t_batch.batch_major = 1;
+  {
+    SgProfScope prof(SG_K_OTHER, s, flops, 0);
+    if (tile == 1)
+      launch_cfg<CfgDI64W>(LoadKContig<64, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
+                           EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
+    else if (tile == 2)
+      launch_cfg<CfgDI64>(LoadKContig<64, true, false>{A, K, M}, LoadKContig<64, true, false>{B, K, NB * cols},
+                          EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
+    else
+      launch_cfg<CfgDI128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
+                           EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
+  }
+  t_batch = BatchInfo{};
+}
+
 // T[m][xi*Cc + c] = sum_p Ytp[xi][p][m] * V[xi][p][c]: the Winograd weight gradient straight from the operands the forward (V) and
 // the adjoint data gradient (Ytp) of the same conv already built -- both tile-major, i.e. x-contiguous for a GEMM over p
 // (LoadXContigS): no second input / gradient transform (2 launches and 2 x 41 MB per ResnetBlock conv saved)
@@ -1219,6 +1242,18 @@ bool w24_plan(const sgConvDesc* d, W24Plan* pl) {
   return true;
 }
 }  // namespace
+
+extern "C" int sg_batched_gemm_nt(const float* a, const float* b, float* c, int nbatch, int M, int cols, int K, int tile,
+                                  sgStream stream) {
+  SG_ARG_CHECK(a && b && c && nbatch > 0 && M > 0 && cols > 0 && K > 0 && tile >= 0 && tile <= 2, "sg_batched_gemm_nt: bad arguments");
+  const int bm = tile == 0 ? 128 : 64, bn = tile == 2 ? 64 : 128;
+  SG_ARG_CHECK(M % bm == 0 && cols % bn == 0 && K % 32 == 0, "sg_batched_gemm_nt: M, cols, K must be multiples of the tile (%d, %d, 32)", bm, bn);
+  SG_ARG_CHECK(aligned16(a) && aligned16(b) && aligned16(c), "sg_batched_gemm_nt: operands must be 16-byte aligned");
+  SG_ARG_CHECK((double)nbatch * M * K < SG_MAX_ELEMS && (double)nbatch * cols * K < SG_MAX_ELEMS, "sg_batched_gemm_nt: operand too large");
+  wino_bgemm_tile(tile, a, b, c, M, cols, K, 2.0 * nbatch * (double)M * cols * K, (hipStream_t)stream, nbatch);
+  SG_LAUNCH_CHECK("sg_batched_gemm_nt");
+  return 0;
+}
 
 extern "C" int sg_conv2d_wino_supported(const sgConvDesc* d) { return wino_ok(d) ? 1 : 0; }
 
