@@ -353,6 +353,20 @@ int sg_loss_fwd(int kind, const float* a, const float* b, float target, int64_t 
 /* ga_i = gout[0] * scale * dl/da_i */
 int sg_loss_bwd(int kind, const float* a, const float* b, float target, int64_t n, float scale, const float* gout,
                 float* ga, sgStream stream);
+/* Several scalar losses of ONE kind and their weighted sum, one launch forward and one backward:
+ *   out[0] = sum_t weight[t] * (scale[t] * sum_i l(a_t[i], b_t[i] | target[t])),   t < nterms <= SG_WSUM_MAX
+ * -- the feature-matching L1 terms of calculate_features_loss (trainer.py:331-340), the per-scale terms of GANLoss
+ * (losses.py:166-172), the five VGG terms (losses.py:220-224).  Same arithmetic in the same order as sg_loss_fwd per term
+ * followed by sg_weighted_sum_fwd (bit-identical).  *_host = HOST arrays of nterms entries (a / b / ga: device pointers;
+ * b_host, target_host may be NULL; a NULL ga entry skips that term's gradient); terms_out (optional): the nterms scaled
+ * terms.  _bwd: ga_t[i] = weight[t] * gout[0] * scale[t] * dl/da. */
+size_t sg_multi_loss_ws_bytes(int nterms);
+int sg_multi_loss_fwd(int kind, int nterms, const void* const* a_host, const void* const* b_host, const int64_t* n_host,
+                      const float* scale_host, const float* weight_host, const float* target_host, float* out,
+                      float* terms_out, void* ws, size_t ws_bytes, sgStream stream);
+int sg_multi_loss_bwd(int kind, int nterms, const void* const* a_host, const void* const* b_host, const int64_t* n_host,
+                      const float* scale_host, const float* weight_host, const float* target_host, const float* gout,
+                      void* const* ga_host, sgStream stream);
 /* mean over rows of -log softmax(logits)[target]; per-row loss kept in row_loss[rows] */
 int sg_cross_entropy_fwd(const float* logits, const int64_t* target, int rows, int classes, float* row_loss,
                          float* out, sgStream stream);

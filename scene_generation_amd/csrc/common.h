@@ -61,6 +61,9 @@ enum SgOpt {
   SG_OPT_WINO_FOLD_CELLS, // four-wave cell-gather form of the adjoint Winograd output fold (0: one thread per channel walks the tiles)
   SG_OPT_WINO_PIPE,       // main loop of the dense Winograd GEMMs: 1 = stores at the top of the iteration, 2 = interleaved with phase 0
   SG_OPT_CHECK_INDICES,   // debugging: range-check index operands on the device (one stream synchronisation per check); sg_check_indices
+  SG_OPT_LAST_BLOCK,      // two-stage reductions finished by the last workgroup to arrive (one launch) instead of a second kernel
+  SG_OPT_WINO_GEMM_TILE,  // tile of the K-contiguous batched Winograd GEMMs: 0 = 128x128, 1 = 64x128, 2 = 64x64
+  SG_OPT_WINO43,          // Winograd F(4x4,3x3) for the small-plane reflection-padded ResnetBlock convs (0: F(2x2,3x3))
   SG_OPT_COUNT
 };
 extern std::atomic<int> g_sg_opt[SG_OPT_COUNT];
@@ -149,6 +152,35 @@ __device__ __forceinline__ float sg_sum_strided(const float* __restrict__ p, siz
   }
   return v;
 }
+
+// ---- in-launch finalisation of two-stage reductions ("last block") ----------------------------------------------------------
+// Stage 1 workgroups publish their partials with WRITE-THROUGH (sc1) stores, every wave drains its stores, one lane takes a
+// ticket from an agent-scope counter; the workgroup that draws the last ticket reads all partials with sc1 loads (L1 is never
+// refreshed by other CUs' stores, per-XCD L2s are not coherent: cdna_hip_programming.md 6 G16, form R1 with sc1 loads) and
+// finishes the reduction in the SAME fixed order the separate final kernel used -- results are bit-identical, a ~4-6 us launch
+// and its ~1.7 us boundary are gone.  The counter comes from sg_counter_alloc() (zero-initialised library memory) and is reset
+// by the last arriver, so it is clean for the next launch that is handed it, also under hipGraph replay.
+__device__ __forceinline__ void sg_publish(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float sg_consume(const float* p) {
+  return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Called by ALL threads of the workgroup after its sg_publish() calls.  True (in every thread) in the workgroup that arrived last
+// of ``narrive``.  ``flag``: one int of LDS.
+__device__ __forceinline__ bool sg_arrive_last(int* counter, int narrive, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its sc1 stores
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+    const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == narrive - 1;
+    if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = last;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+// a zeroed 4-byte counter in library-owned device memory for ONE launch on stream ``s`` (runtime.hip); nullptr: none available
+// (the caller then runs its two-kernel form).  ``n`` consecutive counters.
+int* sg_counter_alloc(hipStream_t s, int n = 1);
 
 // block reduction of up to 1024 threads; result valid in every thread. `red` = >=16 floats of LDS.
 __device__ __forceinline__ float sg_block_sum(float v, float* red) {

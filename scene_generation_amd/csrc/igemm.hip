@@ -843,10 +843,38 @@ int wino_tile(const sgConvDesc* d) {
 }
 bool wino_ok(const sgConvDesc* d) { return wino_tile(d) != 0; }
 
+// The batched GEMM of wino_bgemm() below on a choice of tiles: sg_batched_gemm_nt (tools/bench_wino_gemm.py), the F(4x4,3x3)
+// convs (36 x [1024 x 1024] x [1024 x 128] at the trunk: 128x128 tiles would give 288 workgroups for 256 CUs) and the A/B
+// switch wino_gemm_tile.  tile: 0 = 128x128, 1 = 64x128, 2 = 64x64; all 32-deep, software-pipelined, plain epilogue.
+using CfgDI64W = TileCfg<64, 128, 2, 2, 2>;
+using CfgDI64 = TileCfg<64, 64, 2, 2, 2>;
+void wino_bgemm_tile(int tile, const float* A, const float* B, float* Cout, int M, int cols, int K, double flops, hipStream_t s, int NB,
+                     int kind = SG_K_OTHER) {
+  sgk::t_alg_bytes = 4.0 * NB * ((double)M * K + (double)cols * K + (double)M * cols);
+  t_batch = BatchInfo{}; t_batch.cols_per_batch = cols; t_batch.nbatch = NB; t_batch.a_stride = M * K; t_batch.batch_major = 1;
+  {
+    SgProfScope prof(kind, s, flops, 0);
+    if (tile == 1)
+      launch_cfg<CfgDI64W>(LoadKContig<64, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
+                           EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
+    else if (tile == 2)
+      launch_cfg<CfgDI64>(LoadKContig<64, true, false>{A, K, M}, LoadKContig<64, true, false>{B, K, NB * cols},
+                          EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
+    else
+      launch_cfg<CfgDI128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
+                           EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
+  }
+  t_batch = BatchInfo{};
+}
+
 // C[m][b*cols + j] = sum_k A[b][m][k] * B[b*cols + j][k]   (NB batches -- 16 for F(2x2,3x3), 25 (x k-chunks) for F(2x2,4x4) --,
 // everything a multiple of the tile)
 void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, int K, double flops, hipStream_t s, int NB = 16) {
-  EpRowMajor ep{Cout, nullptr, M, NB * cols, NB * cols, SG_ACT_NONE, 0.f, 0};
+  const int tsel = sg_opt(SG_OPT_WINO_GEMM_TILE);
+  if ((tsel == 1 || tsel == 2) && M % 64 == 0 && cols % 128 == 0 && K % 32 == 0) {
+    wino_bgemm_tile(tsel, A, B, Cout, M, cols, K, flops, s, NB, NB == 16 ? SG_K_WINO_GEMM_128 : SG_K_WINO24_GEMM);
+    return;
+  }
   sgk::t_alg_bytes = 4.0 * NB * ((double)M * K + (double)cols * K + (double)M * cols);
   t_batch = BatchInfo{}; t_batch.cols_per_batch = cols; t_batch.nbatch = NB; t_batch.a_stride = M * K; t_batch.batch_major = 1;
   {
@@ -863,29 +891,6 @@ void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, in
   t_batch = BatchInfo{};
 }
 
-
-// The same batched GEMM on other tiles, for the micro-benchmark behind sg_batched_gemm_nt (tools/bench_wino_gemm.py): the
-// F(4x4,3x3) study of round 5 needed the 36 x [1024 x 1024] x [1024 x 128] shape on 64-row tiles (128x128 tiles give it 288
-// workgroups for 256 CUs).  tile: 0 = 128x128, 1 = 64x128, 2 = 64x64; all 32-deep, software-pipelined, plain epilogue.
-using CfgDI64W = TileCfg<64, 128, 2, 2, 2>;
-using CfgDI64 = TileCfg<64, 64, 2, 2, 2>;
-void wino_bgemm_tile(int tile, const float* A, const float* B, float* Cout, int M, int cols, int K, double flops, hipStream_t s, int NB) {
-  sgk::t_alg_bytes = 4.0 * NB * ((double)M * K + (double)cols * K + (double)M * cols);
-  t_batch = BatchInfo{}; t_batch.cols_per_batch = cols; t_batch.nbatch = NB; t_batch.a_stride = M * K; t_batch.batch_major = 1;
-  {
-    SgProfScope prof(SG_K_OTHER, s, flops, 0);
-    if (tile == 1)
-      launch_cfg<CfgDI64W>(LoadKContig<64, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
-                           EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
-    else if (tile == 2)
-      launch_cfg<CfgDI64>(LoadKContig<64, true, false>{A, K, M}, LoadKContig<64, true, false>{B, K, NB * cols},
-                          EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
-    else
-      launch_cfg<CfgDI128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
-                           EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
-  }
-  t_batch = BatchInfo{};
-}
 
 // T[m][xi*Cc + c] = sum_p Ytp[xi][p][m] * V[xi][p][c]: the Winograd weight gradient straight from the operands the forward (V) and
 // the adjoint data gradient (Ytp) of the same conv already built -- both tile-major, i.e. x-contiguous for a GEMM over p

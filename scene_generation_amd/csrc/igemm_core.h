@@ -483,6 +483,7 @@ struct FixedTaps { int lg; unsigned tapcode; };      // lg < 4: tap ids of the c
 template <int BN, int MODE>
 struct LoadFixedKN {
   Gather g; int Npix; int KS; int lg; unsigned tapcode;
+  FastDiv dphw, dpw;                    // n -> (image, pixel row): set by host_prepare() / set_class_b() (no division in init())
   static constexpr int LDS_INTS = 0;
   static constexpr int ROWS = BN * BK / 256;
   struct Stage { float r[ROWS]; };
@@ -497,9 +498,9 @@ struct LoadFixedKN {
     const bool okn = n < Npix;
     const int nn = okn ? n : 0;
     const int phw = g.PH * g.PW;
-    const int img = nn / phw;
+    const int img = (int)dphw.div((unsigned)nn);
     const int pix = nn - img * phw;
-    const int pi = pix / g.PW;
+    const int pi = (int)dpw.div((unsigned)pix);
     const int ph = pi * g.pstep + g.ph0, pw = (pix - pi * g.PW) * g.pstep + g.pw0;
     int ah, aw;
     if (MODE == 0) { ah = ph * g.stride - g.pad; aw = pw * g.stride - g.pad; }
@@ -512,7 +513,8 @@ struct LoadFixedKN {
     for (int i = 0; i < ROWS; ++i) {
       const int ti = (kr_ + i) & (nt - 1);
       const int t = lg == 4 ? ti : (int)((tapcode >> (4 * ti)) & 15u);
-      const int kh = t / KS, kw = t - kh * KS;
+      // t < KS*KS <= 16: the tap row without an integer division (~25 VALU each, ROWS of them per thread)
+      const int kh = KS == 4 ? (t >> 2) : (KS == 3 ? ((t * 11) >> 5) : (KS == 1 ? 0 : t / KS)), kw = t - kh * KS;
       const int v = okn ? tap_offset<MODE>(g, ah, aw, kh, kw) : -1;
       voff_[i] = v < 0 ? 0x80000000u : (img1 + (unsigned)v) * 4u;
     }
@@ -694,7 +696,7 @@ template <int BN, int KS, bool TWO, bool MASK = true, int NS = SG_NSUB>
 struct LoadGatherNK {
   Gather g; int Ncols;
   const int* chan_list; const int* chan_cnt; int L;     // optional per-image active-channel lists
-  int zdiv;                                             // image = blockIdx.z / zdiv (k-chunks per image), 0 == 1
+  int zdiv;                                             // k-chunks per image (informational: the image comes from kbeg)
   static constexpr int KS2 = KS * KS;
   // per k-tile LDS table (separable): rowoff[KS][16] (= ih*SW or -1), coloff[KS][16] (= iw or -1), one all -1 row,
   // img1[16], img2[16]
@@ -711,7 +713,9 @@ struct LoadGatherNK {
   __device__ __forceinline__ void init(int n0, int tid, int* lds, int kbeg, int kend) {
     kl_ = tid & 15; nr_ = tid >> 4; tid_ = tid; lds_ = lds; kbeg_ = kbeg; kend_ = kend;
     const unsigned shw = (unsigned)(g.SH * g.SW);
-    const int zimg = zdiv > 1 ? blockIdx.z / zdiv : blockIdx.z;
+    // the image of a per-image k-chunk launch (BatchInfo::ksplit: chunk (img, q) starts at pixel img * PH*PW + q * kcs); taken
+    // from kbeg, not from blockIdx.z: the XCD pinning of igemm_kernel re-numbers the z slices
+    const int zimg = chan_list ? kbeg / (g.PH * g.PW) : 0;
     const int* list = chan_list ? chan_list + (size_t)zimg * L : nullptr;
     const int ncols = chan_list ? chan_cnt[zimg] * KS2 : Ncols;
     secmask_ = 0;
@@ -910,6 +914,7 @@ struct EpNCHW {     // out[z][img][m][pix], n = img*PHW + pix ; bias per row m (
   float* out; const float* bias; int PHW, Mtot, M, Npix, act; float slope; size_t zstride;
   // optional scatter of a pixel sub-lattice into the full grid (parity-decomposed strided transposed gathers)
   int PWs, step, h0, w0, PWf, PHWf;
+  FastDiv dPHW, dPWs;                   // n -> image, pixel -> row of the sub-lattice: set by host_prepare() / set_class_ep()
   __device__ __forceinline__ void set_limit(int n) { Npix = n; }
   template <int TM, int TN>
   __device__ __forceinline__ void store(f32x16 (&acc)[TM][TN], int mbase, int nbase, int lane, int z) const {
@@ -937,10 +942,10 @@ struct EpNCHW {     // out[z][img][m][pix], n = img*PHW + pix ; bias per row m (
       for (int j = 0; j < TN; ++j) {
         const int n = nbase + j * 32 + (lane & 31);
         if (!FULL && n >= Npix) continue;
-        const int img = n / PHW;
+        const int img = (int)dPHW.div((unsigned)n);
         int pix = n - img * PHW, plane = PHW;
         if (step > 1) {
-          const int i = pix / PWs;
+          const int i = (int)dPWs.div((unsigned)pix);
           pix = (i * step + h0) * PWf + (pix - i * PWs) * step + w0;
           plane = PHWf;
         }
@@ -1045,6 +1050,7 @@ struct ParityClasses {
   int ncls; int tile0[5]; int Npix[4]; int K[4]; int PH[4], PW[4], ph0[4], pw0[4]; unsigned aoff[4];
   const void* ktab[4];
   int lg[4]; unsigned tapcode[4];        // LoadFixedKN: taps per channel (log2) and tap ids of each class
+  unsigned dphw_m[4], dphw_s[4], dpw_m[4], dpw_s[4];      // FastDiv(PH * PW), FastDiv(PW) of each class (launch_cfg fills them)
 };
 struct BatchInfo {
   int cols_per_batch; int nbatch; const int* kcnt; int a_stride; int b_stride;
@@ -1079,9 +1085,24 @@ template <int BN, int MODE>
 __device__ __forceinline__ void set_class_b(LoadFixedKN<BN, MODE>& l, const ParityClasses& p, int c) {
   l.g.PH = p.PH[c]; l.g.PW = p.PW[c]; l.g.ph0 = p.ph0[c]; l.g.pw0 = p.pw0[c]; l.Npix = p.Npix[c];
   l.lg = p.lg[c]; l.tapcode = p.tapcode[c];
+  l.dphw.m = p.dphw_m[c]; l.dphw.s = p.dphw_s[c]; l.dphw.d = (unsigned)(p.PH[c] * p.PW[c]);
+  l.dpw.m = p.dpw_m[c]; l.dpw.s = p.dpw_s[c]; l.dpw.d = (unsigned)p.PW[c];
 }
 __device__ __forceinline__ void set_class_ep(EpNCHW& e, const ParityClasses& p, int c) {
   e.PHW = p.PH[c] * p.PW[c]; e.Npix = p.Npix[c]; e.PWs = p.PW[c]; e.h0 = p.ph0[c]; e.w0 = p.pw0[c];
+  e.dPHW.m = p.dphw_m[c]; e.dPHW.s = p.dphw_s[c]; e.dPHW.d = (unsigned)e.PHW;
+  e.dPWs.m = p.dpw_m[c]; e.dPWs.s = p.dpw_s[c]; e.dPWs.d = (unsigned)e.PWs;
+}
+// host side, just before a launch: operands that carry FastDiv members get them from their own fields
+template <class T> inline void host_prepare(T&) {}
+inline void host_prepare(EpNCHW& e) {
+  e.dPHW = FastDiv((unsigned)(e.PHW > 0 ? e.PHW : 1));
+  e.dPWs = FastDiv((unsigned)(e.PWs > 0 ? e.PWs : 1));
+}
+template <int BN, int MODE> inline void host_prepare(LoadFixedKN<BN, MODE>& l) {
+  const int phw = l.g.PH * l.g.PW;
+  l.dphw = FastDiv((unsigned)(phw > 0 ? phw : 1));
+  l.dpw = FastDiv((unsigned)(l.g.PW > 0 ? l.g.PW : 1));
 }
 template <class CFG, class AL, class BL, class EP>
 __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int kchunk, BatchInfo bi) {
@@ -1134,7 +1155,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   int kbeg = zblk * kchunk;
   int kend = min(K, kbeg + kchunk);
   if (bi.ksplit > 0) {
-    const int img = blockIdx.z / bi.ksplit, q = blockIdx.z - img * bi.ksplit;
+    const int img = zblk / bi.ksplit, q = zblk - img * bi.ksplit;
     kbeg = img * bi.kimg + q * bi.kcs;
     kend = min((img + 1) * bi.kimg, kbeg + bi.kcs);
   }
@@ -1396,9 +1417,18 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
   dim3 grid(tiles, 1, t_grid_z > 0 ? t_grid_z : ((splits > 1 || t_fixed_kchunk > 0) ? sg_cdiv(K, kchunk) : 1));
   if (t_min_z > 0 && (int)grid.z < t_min_z && t_grid_z == 0) grid.z = t_min_z;
   BatchInfo bi = t_batch;
-  bi.xcd_z = (t_xcd_z && t_grid_z == 0 && t_fixed_kchunk == 0 && bi.cols_per_batch == 0 && bi.par.ncls == 0 && bi.ksplit == 0 &&
-              grid.z >= 8 && grid.z % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL((igemm_kernel<CFG, AL, BL, EP>), grid, dim3(256), 0, s, al, bl, ep, M, N, K, kchunk, bi);
+  // k-chunks pinned to XCDs: plain split-K launches, and the per-image k-chunks (ksplit) of the factored stem's weight gradient
+  // (grid.z = images x chunks: its column tiles re-read the same gy chunk from seven L2s -- 6.5x the algorithmic bytes in round 4)
+  const bool plain_z = t_grid_z == 0 && t_fixed_kchunk == 0 && bi.ksplit == 0;
+  const bool image_z = t_grid_z > 0 && bi.ksplit > 0 && t_xcd_z == 2;
+  bi.xcd_z = (t_xcd_z && (plain_z || image_z) && bi.cols_per_batch == 0 && bi.par.ncls == 0 && grid.z >= 8 && grid.z % 8 == 0) ? 1 : 0;
+  AL al2 = al; BL bl2 = bl; EP ep2 = ep;
+  host_prepare(al2); host_prepare(bl2); host_prepare(ep2);
+  for (int c = 0; c < bi.par.ncls && c < 4; ++c) {
+    const FastDiv a((unsigned)(bi.par.PH[c] * bi.par.PW[c] > 0 ? bi.par.PH[c] * bi.par.PW[c] : 1)), b((unsigned)(bi.par.PW[c] > 0 ? bi.par.PW[c] : 1));
+    bi.par.dphw_m[c] = a.m; bi.par.dphw_s[c] = a.s; bi.par.dpw_m[c] = b.m; bi.par.dpw_s[c] = b.s;
+  }
+  hipLaunchKernelGGL((igemm_kernel<CFG, AL, BL, EP>), grid, dim3(256), 0, s, al2, bl2, ep2, M, N, K, kchunk, bi);
   FILE* lf = g_sg_launch_log;
   if (lf) { fprintf(lf, "%u %u %d %d %d %.0f\n", grid.x * 256u, grid.z, M, N, K, sgk::t_alg_bytes); fflush(lf); }
   return 0;

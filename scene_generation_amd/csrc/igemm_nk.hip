@@ -134,6 +134,7 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
     const EpRowMajor ep{dstp, nullptr, M, Ncols, Ncols, SG_ACT_NONE, 0.f, mnc};
     t_batch = BatchInfo{}; t_batch.kimg = PQ; t_batch.ksplit = S; t_batch.kcs = kcs;
     t_grid_z = NB * S;
+    t_xcd_z = sg_opt(SG_OPT_WGRAD_XCD) ? 2 : 0;      // (image, chunk) slices pinned to XCDs when grid.z % 8 == 0 (launch_cfg)
     {
       SgProfScope prof(sg_igemm_kind(2, KS, tile), s, 2.0 * M * (double)Ncols * Kpix, 0);
       switch (KS) {
@@ -145,6 +146,7 @@ int run_nk_ks(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, 
     }
     t_batch = BatchInfo{};
     t_grid_z = 0;
+    t_xcd_z = 0;
     if (S > 1)
       hipLaunchKernelGGL(slab_group_reduce_kernel, dim3(sg_cdiv(mnc * NB, 256)), dim3(256), 0, s, (const float*)ws, sp->gwimg,
                          mnc, S, NB);

@@ -73,6 +73,120 @@ __global__ void __launch_bounds__(256) loss_final_kernel(const float* __restrict
   if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + s * scale;
 }
 
+// The two kernels above as ONE launch: the workgroup that arrives last adds the partials, in the order loss_final_kernel adds
+// them (common.h: sg_arrive_last).
+__global__ void __launch_bounds__(256) loss_fused_kernel(int kind, const float* __restrict__ a, const float* __restrict__ b,
+                                                        float target, size_t n, float* __restrict__ part, int* __restrict__ counter,
+                                                        float scale, float* __restrict__ out, int accumulate) {
+  __shared__ float red[16];
+  __shared__ int last;
+  float s = 0.f;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += 8 * stride) {
+    float av[8], bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const size_t j = i + e * stride;
+      av[e] = j < n ? a[j] : 0.f;
+      bv[e] = (b && j < n) ? b[j] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (i + e * stride < n) s += loss_term(kind, av[e], bv[e], target);
+  }
+  s = sg_block_sum(s, red);
+  if (threadIdx.x == 0) sg_publish(&part[blockIdx.x], s);
+  if (!sg_arrive_last(counter, (int)gridDim.x, &last)) return;
+  float t = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += sg_consume(&part[i]);
+  t = sg_block_sum(t, red);
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + t * scale;
+}
+
+// ---- several scalar losses of one kind and their weighted sum in one launch ------------------------------------------------------
+//   total = sum_t w[t] * (scale[t] * sum_i l(a_t[i], b_t[i] | target[t]))
+// e.g. the 8 + 3 feature-matching L1 terms of trainer.py:331-340, the per-scale terms of GANLoss (losses.py:166-172), the five
+// VGG terms (losses.py:220-224).  Same arithmetic, in the same order, as sg_loss_fwd per term followed by
+// sg_weighted_sum_fwd: term t owns the workgroups [blk0[t], blk0[t+1]) (as many as sg_loss_fwd would launch for it), the last
+// workgroup to arrive reduces every term's partials and adds the terms in index order.
+struct MultiLossArgs {
+  const float* a[SG_WSUM_MAX]; const float* b[SG_WSUM_MAX]; float* ga[SG_WSUM_MAX];
+  unsigned long long n[SG_WSUM_MAX];
+  float scale[SG_WSUM_MAX], w[SG_WSUM_MAX], target[SG_WSUM_MAX];
+  int blk0[SG_WSUM_MAX + 1];
+  int nterms, kind;
+};
+__device__ __forceinline__ int multi_term_of(const MultiLossArgs& A, int blk) {
+  int t = 0;
+  for (int q = 1; q < A.nterms; ++q) t += blk >= A.blk0[q] ? 1 : 0;
+  return t;
+}
+__global__ void __launch_bounds__(256) multi_loss_fwd_kernel(MultiLossArgs A, float* __restrict__ part, int* __restrict__ counter,
+                                                            float* __restrict__ out, float* __restrict__ terms_out) {
+  __shared__ float red[16];
+  __shared__ int last;
+  const int t = multi_term_of(A, blockIdx.x), lb = blockIdx.x - A.blk0[t], nb = A.blk0[t + 1] - A.blk0[t];
+  const float* __restrict__ a = A.a[t];
+  const float* __restrict__ b = A.b[t];
+  const size_t n = (size_t)A.n[t], stride = (size_t)nb * 256;
+  const float target = A.target[t];
+  float s = 0.f;
+  for (size_t i = (size_t)lb * 256 + threadIdx.x; i < n; i += 8 * stride) {
+    float av[8], bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const size_t j = i + e * stride;
+      av[e] = j < n ? a[j] : 0.f;
+      bv[e] = (b && j < n) ? b[j] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (i + e * stride < n) s += loss_term(A.kind, av[e], bv[e], target);
+  }
+  s = sg_block_sum(s, red);
+  if (counter == nullptr) {                      // two-kernel form: multi_loss_final_kernel follows
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+    return;
+  }
+  if (threadIdx.x == 0) sg_publish(&part[blockIdx.x], s);
+  if (!sg_arrive_last(counter, (int)gridDim.x, &last)) return;
+  float total = 0.f;
+  for (int q = 0; q < A.nterms; ++q) {
+    float v = 0.f;
+    for (int i = threadIdx.x; i < A.blk0[q + 1] - A.blk0[q]; i += 256) v += sg_consume(&part[A.blk0[q] + i]);
+    v = sg_block_sum(v, red);
+    const float term = 0.f + v * A.scale[q];
+    if (threadIdx.x == 0 && terms_out) terms_out[q] = term;
+    total += A.w[q] * term;
+  }
+  if (threadIdx.x == 0) out[0] = total;
+}
+__global__ void __launch_bounds__(256) multi_loss_final_kernel(MultiLossArgs A, const float* __restrict__ part,
+                                                              float* __restrict__ out, float* __restrict__ terms_out) {
+  __shared__ float red[16];
+  float total = 0.f;
+  for (int q = 0; q < A.nterms; ++q) {
+    float v = 0.f;
+    for (int i = threadIdx.x; i < A.blk0[q + 1] - A.blk0[q]; i += 256) v += part[A.blk0[q] + i];
+    v = sg_block_sum(v, red);
+    const float term = 0.f + v * A.scale[q];
+    if (threadIdx.x == 0 && terms_out) terms_out[q] = term;
+    total += A.w[q] * term;
+  }
+  if (threadIdx.x == 0) out[0] = total;
+}
+// ga_t[i] = ((w[t] * gout) * scale[t]) * dl/da: sg_weighted_sum_bwd followed by sg_loss_bwd per term, one launch
+__global__ void multi_loss_bwd_kernel(MultiLossArgs A, const float* __restrict__ gout) {
+  const int t = multi_term_of(A, blockIdx.x);
+  float* __restrict__ ga = A.ga[t];
+  if (ga == nullptr) return;
+  const size_t i = (size_t)(blockIdx.x - A.blk0[t]) * 256 + threadIdx.x;
+  if (i >= (size_t)A.n[t]) return;
+  const float g = A.w[t] * gout[0];
+  const float* __restrict__ b = A.b[t];
+  ga[i] = g * A.scale[t] * loss_grad(A.kind, A.a[t][i], b ? b[i] : 0.f, A.target[t]);
+}
+
 __global__ void loss_bwd_kernel(int kind, const float* __restrict__ a, const float* __restrict__ b, float target, size_t n,
                                 float scale, const float* __restrict__ gout, float* __restrict__ ga) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -124,24 +238,15 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   p = p - step_size * (mi / denom);                          // addcdiv_(exp_avg, denom, value=-step_size)
 }
 
-// four parameters per thread through 16-byte loads / stores (n4 = n / 4 float4 groups); the < 4 tail elements go to the
-// last threads of the grid one by one.  Same arithmetic per element as the scalar form.
+// one parameter per thread.  (A float4-per-thread form -- four parameters through 16-byte loads / stores -- was measured SLOWER on
+// MI355X in round 5: 5.5 vs 6.2 TB/s over the generator's 191 M parameters; the 4-byte form keeps four times the waves in flight.)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            size_t n, size_t n4, float gscale, float step_size, float beta1, float beta2, float eps,
-                            float bc2_sqrt) {
+                            size_t n, float gscale, float step_size, float beta1, float beta2, float eps, float bc2_sqrt) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n4) {
-    float4 pi = ((const float4*)p)[i], mi = ((const float4*)m)[i], vi = ((const float4*)v)[i];
-    const float4 gi = ((const float4*)g)[i];
-    adam_one(pi.x, gi.x, mi.x, vi.x, gscale, step_size, beta1, beta2, eps, bc2_sqrt);
-    adam_one(pi.y, gi.y, mi.y, vi.y, gscale, step_size, beta1, beta2, eps, bc2_sqrt);
-    adam_one(pi.z, gi.z, mi.z, vi.z, gscale, step_size, beta1, beta2, eps, bc2_sqrt);
-    adam_one(pi.w, gi.w, mi.w, vi.w, gscale, step_size, beta1, beta2, eps, bc2_sqrt);
-    ((float4*)m)[i] = mi; ((float4*)v)[i] = vi; ((float4*)p)[i] = pi;
-  } else {
-    const size_t j = 4 * n4 + (i - n4);
-    if (j < n) adam_one(p[j], g[j], m[j], v[j], gscale, step_size, beta1, beta2, eps, bc2_sqrt);
-  }
+  if (i >= n) return;
+  float pi = p[i], mi = m[i], vi = v[i];
+  adam_one(pi, g[i], mi, vi, gscale, step_size, beta1, beta2, eps, bc2_sqrt);
+  m[i] = mi; v[i] = vi; p[i] = pi;
 }
 
 __global__ void fill_kernel(float* __restrict__ p, float value, size_t n) {
@@ -208,8 +313,13 @@ extern "C" int sg_loss_fwd(int kind, const float* a, const float* b, float targe
   hipStream_t s = (hipStream_t)stream;
   int nb = sg_cdiv(n, 256 * 8);
   nb = nb < 1 ? 1 : (nb > LOSS_BLOCKS ? LOSS_BLOCKS : nb);
-  hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(256), 0, s, kind, a, b, target, (size_t)n, (float*)ws);
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, nb, scale, out, accumulate);
+  if (int* counter = sg_counter_alloc(s)) {
+    hipLaunchKernelGGL(loss_fused_kernel, dim3(nb), dim3(256), 0, s, kind, a, b, target, (size_t)n, (float*)ws, counter, scale, out,
+                       accumulate);
+  } else {
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(256), 0, s, kind, a, b, target, (size_t)n, (float*)ws);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, (const float*)ws, nb, scale, out, accumulate);
+  }
   SG_LAUNCH_CHECK("sg_loss_fwd");
   return 0;
 }
@@ -220,6 +330,72 @@ extern "C" int sg_loss_bwd(int kind, const float* a, const float* b, float targe
   hipLaunchKernelGGL(loss_bwd_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, kind, a, b, target, (size_t)n,
                      scale, gout, ga);
   SG_LAUNCH_CHECK("sg_loss_bwd");
+  return 0;
+}
+
+namespace {
+inline int loss_blocks(int64_t n) {
+  int nb = sg_cdiv(n, 256 * 8);
+  return nb < 1 ? 1 : (nb > LOSS_BLOCKS ? LOSS_BLOCKS : nb);
+}
+bool multi_args(MultiLossArgs& A, int kind, int nterms, const void* const* a_host, const void* const* b_host, const int64_t* n_host,
+                const float* scale_host, const float* weight_host, const float* target_host, bool bwd) {
+  A.nterms = nterms; A.kind = kind;
+  long blocks = 0;
+  for (int t = 0; t < SG_WSUM_MAX; ++t) {
+    const bool on = t < nterms;
+    A.a[t] = on ? (const float*)a_host[t] : nullptr;
+    A.b[t] = (on && b_host) ? (const float*)b_host[t] : nullptr;
+    A.ga[t] = nullptr;
+    A.n[t] = on ? (unsigned long long)n_host[t] : 0ull;
+    A.scale[t] = on ? scale_host[t] : 0.f;
+    A.w[t] = on ? weight_host[t] : 0.f;
+    A.target[t] = (on && target_host) ? target_host[t] : 0.f;
+    A.blk0[t] = (int)blocks;
+    if (on) {
+      if (!A.a[t] || n_host[t] <= 0) return false;
+      if ((kind == SG_LOSS_MSE || kind == SG_LOSS_L1) && !A.b[t]) return false;
+      blocks += bwd ? sg_cdiv(n_host[t], 256) : loss_blocks(n_host[t]);
+    }
+    if (blocks > 0x3fffffff) return false;
+  }
+  A.blk0[SG_WSUM_MAX] = (int)blocks;
+  for (int t = nterms; t <= SG_WSUM_MAX; ++t) A.blk0[t] = (int)blocks;
+  return true;
+}
+}  // namespace
+
+extern "C" size_t sg_multi_loss_ws_bytes(int nterms) { return (size_t)(nterms > 0 ? nterms : 1) * LOSS_BLOCKS * sizeof(float); }
+
+extern "C" int sg_multi_loss_fwd(int kind, int nterms, const void* const* a_host, const void* const* b_host, const int64_t* n_host,
+                                 const float* scale_host, const float* weight_host, const float* target_host, float* out,
+                                 float* terms_out, void* ws, size_t ws_bytes, sgStream stream) {
+  SG_ARG_CHECK(a_host && n_host && scale_host && weight_host && out && ws && nterms > 0 && nterms <= SG_WSUM_MAX && kind >= 0 &&
+               kind <= SG_LOSS_BCE_PROB_CONST, "sg_multi_loss_fwd: bad arguments (nterms=%d)", nterms);
+  SG_ARG_CHECK(ws_bytes >= sg_multi_loss_ws_bytes(nterms), "sg_multi_loss_fwd: workspace too small");
+  MultiLossArgs A;
+  SG_ARG_CHECK(multi_args(A, kind, nterms, a_host, b_host, n_host, scale_host, weight_host, target_host, false),
+               "sg_multi_loss_fwd: bad term (null operand, n <= 0, or a pair loss without b)");
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = A.blk0[nterms];
+  int* counter = sg_counter_alloc(s);
+  hipLaunchKernelGGL(multi_loss_fwd_kernel, dim3(blocks), dim3(256), 0, s, A, (float*)ws, counter, out, terms_out);
+  if (!counter) hipLaunchKernelGGL(multi_loss_final_kernel, dim3(1), dim3(256), 0, s, A, (const float*)ws, out, terms_out);
+  SG_LAUNCH_CHECK("sg_multi_loss_fwd");
+  return 0;
+}
+
+extern "C" int sg_multi_loss_bwd(int kind, int nterms, const void* const* a_host, const void* const* b_host, const int64_t* n_host,
+                                 const float* scale_host, const float* weight_host, const float* target_host, const float* gout,
+                                 void* const* ga_host, sgStream stream) {
+  SG_ARG_CHECK(a_host && n_host && scale_host && weight_host && gout && ga_host && nterms > 0 && nterms <= SG_WSUM_MAX && kind >= 0 &&
+               kind <= SG_LOSS_BCE_PROB_CONST, "sg_multi_loss_bwd: bad arguments (nterms=%d)", nterms);
+  MultiLossArgs A;
+  SG_ARG_CHECK(multi_args(A, kind, nterms, a_host, b_host, n_host, scale_host, weight_host, target_host, true),
+               "sg_multi_loss_bwd: bad term");
+  for (int t = 0; t < nterms; ++t) A.ga[t] = (float*)ga_host[t];           // nullptr: that term's gradient is not wanted
+  hipLaunchKernelGGL(multi_loss_bwd_kernel, dim3(A.blk0[nterms]), dim3(256), 0, (hipStream_t)stream, A, gout);
+  SG_LAUNCH_CHECK("sg_multi_loss_bwd");
   return 0;
 }
 
@@ -247,11 +423,8 @@ extern "C" int sg_adam_step(float* p, const float* g, float* m, float* v, int64_
   SG_ARG_CHECK(p && g && m && v && n > 0 && bias_corr1 > 0.f && bias_corr2_sqrt > 0.f, "sg_adam_step: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   SgProfScope prof(SG_K_ADAM, s, 0, 28.0 * (double)n);
-  const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
-  const size_t n4 = vec ? (size_t)n / 4 : 0;
-  const size_t threads = n4 + ((size_t)n - 4 * n4);
-  hipLaunchKernelGGL(adam_kernel, dim3(sg_cdiv(threads, 256)), dim3(256), 0, s, p, g, m, v, (size_t)n, n4, grad_scale,
-                     lr / bias_corr1, beta1, beta2, eps, bias_corr2_sqrt);
+  hipLaunchKernelGGL(adam_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, s, p, g, m, v, (size_t)n, grad_scale, lr / bias_corr1, beta1,
+                     beta2, eps, bias_corr2_sqrt);
   SG_LAUNCH_CHECK("sg_adam_step");
   return 0;
 }

@@ -219,9 +219,65 @@ struct BnIter {             // walks i -> (n, p) without a division per element
 // slices of up to BN_REG * 256 elements stay in registers between the mean and the variance pass: x is read ONCE (the two-pass
 // form read every slice twice; slices are ~1-10 K elements: bn_slices)
 constexpr int BN_REG = 40;
+// ``fin.counter`` != nullptr: the slice that arrives last for its channel combines the channel's S partials itself (the arithmetic
+// of bn_final_kernel, same order) -- no second launch (common.h: sg_arrive_last)
+struct BnFinal {
+  int* counter; float* save_mean; float* save_rstd; float* rmean; float* rvar; int64_t* nbt; float eps, momentum;
+};
+__device__ __forceinline__ void bn_combine(const float* __restrict__ part, int c, int S, bool coherent, float& n, float& mean, float& m2) {
+  n = 0.f; mean = 0.f; m2 = 0.f;
+  // (the partials of 8 slices are fetched together: one thread walking S <= 64 dependent round trips took 10 us)
+  for (int z0 = 0; z0 < S; z0 += 8) {
+    float pn[8], pm[8], pq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float* p = part + ((size_t)c * S + min(z0 + e, S - 1)) * 3;
+      if (coherent) { pn[e] = sg_consume(p); pm[e] = sg_consume(p + 1); pq[e] = sg_consume(p + 2); }
+      else { pn[e] = p[0]; pm[e] = p[1]; pq[e] = p[2]; }
+      if (z0 + e >= S) pn[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float nb = pn[e];
+      if (nb <= 0.f) continue;
+      const float d = pm[e] - mean, nt = n + nb;
+      mean += d * (nb / nt);
+      m2 += pq[e] + d * d * (n * nb / nt);
+      n = nt;
+    }
+  }
+}
+__device__ __forceinline__ void bn_write_stats(int c, float n, float mean, float m2, float* save_mean, float* save_rstd, float* rmean,
+                                               float* rvar, int64_t* nbt, float eps, float momentum) {
+  const float var = m2 / n;
+  save_mean[c] = mean;
+  save_rstd[c] = 1.f / sqrtf(var + eps);
+  if (rmean) {
+    const float unb = n > 1.f ? m2 / (n - 1.f) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+  }
+  if (nbt && c == 0) nbt[0] += 1;
+}
+__device__ __forceinline__ void bn_stats_finish(float* __restrict__ part, int c, int z, int S, float m, float mean, float q,
+                                                const BnFinal& fin, int* flag) {
+  float* o = part + ((size_t)c * S + z) * 3;
+  if (fin.counter == nullptr) {
+    if (threadIdx.x == 0) { o[0] = m; o[1] = mean; o[2] = q; }
+    return;
+  }
+  if (threadIdx.x == 0) { sg_publish(o, m); sg_publish(o + 1, mean); sg_publish(o + 2, q); }
+  if (!sg_arrive_last(fin.counter + c, S, flag)) return;
+  if (threadIdx.x == 0) {
+    float n, mu, m2;
+    bn_combine(part, c, S, true, n, mu, m2);
+    bn_write_stats(c, n, mu, m2, fin.save_mean, fin.save_rstd, fin.rmean, fin.rvar, fin.nbt, fin.eps, fin.momentum);
+  }
+}
 __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, int N, int C,
-                                                      int HW, int S) {
+                                                      int HW, int S, BnFinal fin) {
   __shared__ float red[16];
+  __shared__ int lastflag;
   const int c = blockIdx.x, z = blockIdx.y;
   const long cnt = (long)N * HW;
   const long chunk = (cnt + S - 1) / S;
@@ -249,10 +305,7 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__
       q += (beg + threadIdx.x + (long)e * 256 < end) ? d * d : 0.f;
     }
     q = sg_block_sum(q, red);
-    if (threadIdx.x == 0) {
-      float* o = part + ((size_t)c * S + z) * 3;
-      o[0] = m; o[1] = mean; o[2] = q;
-    }
+    bn_stats_finish(part, c, z, S, m, mean, q, fin, &lastflag);
     return;
   }
   float s = 0.f;
@@ -271,10 +324,7 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const float* __restrict__
     }
   }
   q = sg_block_sum(q, red);
-  if (threadIdx.x == 0) {
-    float* o = part + ((size_t)c * S + z) * 3;
-    o[0] = m; o[1] = mean; o[2] = q;
-  }
+  bn_stats_finish(part, c, z, S, m, mean, q, fin, &lastflag);
 }
 
 __global__ void bn_final_kernel(const float* __restrict__ part, float* __restrict__ save_mean, float* __restrict__ save_rstd,
@@ -287,34 +337,9 @@ __global__ void bn_final_kernel(const float* __restrict__ part, float* __restric
     save_rstd[c] = 1.f / sqrtf(rvar[c] + eps);
     return;
   }
-  float n = 0.f, mean = 0.f, m2 = 0.f;
-  // (the partials of 8 slices are fetched together: one thread walking S <= 64 dependent round trips took 10 us)
-  for (int z0 = 0; z0 < S; z0 += 8) {
-    float pn[8], pm[8], pq[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float* p = part + ((size_t)c * S + min(z0 + e, S - 1)) * 3;
-      pn[e] = z0 + e < S ? p[0] : 0.f; pm[e] = p[1]; pq[e] = p[2];
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float nb = pn[e];
-      if (nb <= 0.f) continue;
-      const float d = pm[e] - mean, nt = n + nb;
-      mean += d * (nb / nt);
-      m2 += pq[e] + d * d * (n * nb / nt);
-      n = nt;
-    }
-  }
-  const float var = m2 / n;
-  save_mean[c] = mean;
-  save_rstd[c] = 1.f / sqrtf(var + eps);
-  if (rmean) {
-    const float unb = n > 1.f ? m2 / (n - 1.f) : var;
-    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
-  }
-  if (nbt && c == 0) nbt[0] += 1;
+  float n, mean, m2;
+  bn_combine(part, c, S, false, n, mean, m2);
+  bn_write_stats(c, n, mean, m2, save_mean, save_rstd, rmean, rvar, nbt, eps, momentum);
 }
 
 // y = act((x - mean[c]) * rstd[c] * gamma[c] + beta[c]); one workgroup = 1024 consecutive elements of one plane
@@ -345,8 +370,10 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const float* __restri
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           float* __restrict__ part, int N, int C, int HW, int S, int act,
-                                                          float slope) {
+                                                          float slope, int* __restrict__ counter, float* __restrict__ sums,
+                                                          float* __restrict__ ggamma, float* __restrict__ gbeta) {
   __shared__ float red[16];
+  __shared__ int lastflag;
   const int c = blockIdx.x, z = blockIdx.y;
   const long cnt = (long)N * HW;
   const long chunk = (cnt + S - 1) / S;
@@ -377,7 +404,30 @@ __global__ void __launch_bounds__(256) bn_bwd_stats_kernel(const float* __restri
   }
   s1 = sg_block_sum(s1, red);
   s2 = sg_block_sum(s2, red);
-  if (threadIdx.x == 0) { part[((size_t)c * S + z) * 2] = s1; part[((size_t)c * S + z) * 2 + 1] = s2; }
+  float* o = part + ((size_t)c * S + z) * 2;
+  if (counter == nullptr) {                        // bn_bwd_final_kernel follows
+    if (threadIdx.x == 0) { o[0] = s1; o[1] = s2; }
+    return;
+  }
+  if (threadIdx.x == 0) { sg_publish(o, s1); sg_publish(o + 1, s2); }
+  if (!sg_arrive_last(counter + c, S, &lastflag)) return;
+  if (threadIdx.x == 0) {                          // the channel's last slice: bn_bwd_final_kernel's sums, same order
+    float t1 = 0.f, t2 = 0.f;
+    for (int z0 = 0; z0 < S; z0 += 8) {
+      float a[8], b[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const size_t i = ((size_t)c * S + min(z0 + e, S - 1)) * 2;
+        a[e] = sg_consume(part + i); b[e] = sg_consume(part + i + 1);
+        if (z0 + e >= S) { a[e] = 0.f; b[e] = 0.f; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { t1 += a[e]; t2 += b[e]; }
+    }
+    sums[2 * c] = t1; sums[2 * c + 1] = t2;
+    if (gbeta) gbeta[c] = t1;
+    if (ggamma) ggamma[c] = t2;
+  }
 }
 
 __global__ void bn_bwd_final_kernel(const float* __restrict__ part, float* __restrict__ sums, float* __restrict__ ggamma,
@@ -458,8 +508,10 @@ inline int bn_slices(int N, int C, int HW) {
 // per-channel sum over (N, HW): two deterministic stages -- grid (C, S) partial sums over contiguous chunks of the
 // (n, p) index space, then one block per channel adds the S partials in fixed order.
 __global__ void __launch_bounds__(256) channel_sum_partial_kernel(const float* __restrict__ g, float* __restrict__ part, int N,
-                                                                 int C, int HW, int S) {
+                                                                 int C, int HW, int S, int* __restrict__ counter,
+                                                                 float* __restrict__ out) {
   __shared__ float red[16];
+  __shared__ int lastflag;
   const int c = blockIdx.x, z = blockIdx.y;
   const long cnt = (long)N * HW;
   const long chunk = (cnt + S - 1) / S;
@@ -475,7 +527,24 @@ __global__ void __launch_bounds__(256) channel_sum_partial_kernel(const float* _
     }
   }
   s = sg_block_sum(s, red);
-  if (threadIdx.x == 0) part[(size_t)c * S + z] = s;
+  if (counter == nullptr) {                        // channel_sum_final_kernel follows
+    if (threadIdx.x == 0) part[(size_t)c * S + z] = s;
+    return;
+  }
+  if (threadIdx.x == 0) sg_publish(&part[(size_t)c * S + z], s);
+  if (!sg_arrive_last(counter + c, S, &lastflag)) return;
+  if (threadIdx.x == 0) {                          // the channel's last slice adds the S partials in slice order
+    float t = 0.f;
+    for (int z0 = 0; z0 < S; z0 += 8) {
+      float a[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] = sg_consume(&part[(size_t)c * S + min(z0 + e, S - 1)]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (z0 + e < S) t += a[e];
+    }
+    out[c] = t;
+  }
 }
 
 __global__ void channel_sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int S) {
@@ -841,9 +910,13 @@ extern "C" int sg_batchnorm_fwd(const float* x, const float* gamma, const float*
   SgProfScope prof(SG_K_BATCHNORM, s, 0, (double)N * C * HW * 8.0);       // algorithmic: x in, y out
   const int S = bn_slices(N, C, HW);
   float* part = reinterpret_cast<float*>(ws);
-  if (training) hipLaunchKernelGGL(bn_stats_kernel, dim3(C, S), dim3(256), 0, s, x, part, N, C, HW, S);
-  hipLaunchKernelGGL(bn_final_kernel, dim3(sg_cdiv(C, 64)), dim3(64), 0, s, (const float*)part, save_mean, save_rstd,
-                     running_mean, running_var, num_batches, C, S, eps, momentum, training);
+  int* counter = (training && C <= 4096) ? sg_counter_alloc(s, C) : nullptr;
+  if (training)
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, S), dim3(256), 0, s, x, part, N, C, HW, S,
+                       BnFinal{counter, save_mean, save_rstd, running_mean, running_var, num_batches, eps, momentum});
+  if (!counter)
+    hipLaunchKernelGGL(bn_final_kernel, dim3(sg_cdiv(C, 64)), dim3(64), 0, s, (const float*)part, save_mean, save_rstd,
+                       running_mean, running_var, num_batches, C, S, eps, momentum, training);
   if (HW >= 256)
     hipLaunchKernelGGL(bn_apply_kernel, dim3(sg_cdiv(HW, 1024), N * C), dim3(256), 0, s, x, gamma, beta,
                        (const float*)save_mean, (const float*)save_rstd, y, C, HW, act, slope);
@@ -865,9 +938,11 @@ extern "C" int sg_batchnorm_bwd(const float* x, const float* gy, const float* ga
   const int S = bn_slices(N, C, HW);
   float* part = reinterpret_cast<float*>(ws);
   float* sums = part + (size_t)C * S * 3;
+  int* counter = C <= 4096 ? sg_counter_alloc(s, C) : nullptr;
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(C, S), dim3(256), 0, s, x, gy, gamma, beta, save_mean, save_rstd, part, N, C,
-                     HW, S, act, slope);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(sg_cdiv(C, 64)), dim3(64), 0, s, (const float*)part, sums, ggamma, gbeta, C, S);
+                     HW, S, act, slope, counter, sums, ggamma, gbeta);
+  if (!counter)
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(sg_cdiv(C, 64)), dim3(64), 0, s, (const float*)part, sums, ggamma, gbeta, C, S);
   if (HW >= 256)
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(sg_cdiv(HW, 1024), N * C), dim3(256), 0, s, x, gy, gamma, beta, save_mean,
                        save_rstd, (const float*)sums, gx, C, HW, 1.f / ((float)N * HW), training, act, slope);
@@ -898,8 +973,10 @@ extern "C" int sg_channel_sum(const float* g, float* out, int N, int C, int HW, 
     hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, s, g, out, N, C, HW);
   } else {
     float* part = reinterpret_cast<float*>(ws);
-    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(C, S), dim3(256), 0, s, g, part, N, C, HW, S);
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(sg_cdiv(C, 64)), dim3(64), 0, s, (const float*)part, out, C, S);
+    int* counter = C <= 4096 ? sg_counter_alloc(s, C) : nullptr;
+    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(C, S), dim3(256), 0, s, g, part, N, C, HW, S, counter, out);
+    if (!counter)
+      hipLaunchKernelGGL(channel_sum_final_kernel, dim3(sg_cdiv(C, 64)), dim3(64), 0, s, (const float*)part, out, C, S);
   }
   SG_LAUNCH_CHECK("sg_channel_sum");
   return 0;

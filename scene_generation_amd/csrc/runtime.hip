@@ -31,7 +31,7 @@ const OptDef kOpts[SG_OPT_COUNT] = {
     {"w24_small", 1}, {"w24_s", -1}, {"w24_pmin", 256}, {"wino_adjoint", 1}, {"wino24", 1}, {"linear_nsub", 2},
     {"linear_skinny", 2048}, {"wgrad_rowsum", 1}, {"layout_reg", 1}, {"layout_dsplit", 1}, {"bn_blocks", 4096},
     {"instnorm_reg", 1}, {"wgrad_xcd", 1}, {"wino_reuse", 1}, {"wino_fold_cells", 1}, {"wino_pipe", 2},
-    {"check_indices", 0}};
+    {"check_indices", 0}, {"last_block", 1}, {"wino_gemm_tile", 0}, {"wino43", 1}};
 // runs when the shared library is loaded, before any entry point can be called: the ONLY place the environment is read
 struct OptInit {
   OptInit() {
@@ -69,6 +69,46 @@ extern "C" int sg_set_option(const char* key, int value) {
   if (i < 0) { sg_set_error("sg_set_option: unknown option '%s'", key ? key : "(null)"); return -1; }
   g_sg_opt[i].store(value, std::memory_order_relaxed);
   return 0;
+}
+
+// ---- ticket counters of the in-launch finalisation (common.h: sg_arrive_last) ---------------------------------------------------
+// One zero-initialised pool per device.  Launches outside a stream capture take counters from a RING (a counter is busy only
+// while its launch runs and is left at zero by the last arriver: 65536 slots cannot wrap onto a launch still in flight);
+// launches recorded into a hipGraph keep their counter for the life of the graph, so they come from a second region that is
+// only ever handed out once (exhausted -> nullptr -> the caller's two-kernel form).
+namespace {
+constexpr int CNT_RING = 65536, CNT_CAPTURED = 262144, CNT_DEVICES = 16;
+std::mutex g_cnt_mu;
+int* g_cnt_pool[CNT_DEVICES] = {};
+unsigned g_cnt_ring[CNT_DEVICES] = {};
+int g_cnt_cap[CNT_DEVICES] = {};
+}  // namespace
+
+int* sg_counter_alloc(hipStream_t s, int n) {
+  if (!sg_opt(SG_OPT_LAST_BLOCK) || n < 1 || n > 4096) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CNT_DEVICES) return nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  std::lock_guard<std::mutex> lk(g_cnt_mu);
+  if (!g_cnt_pool[dev]) {
+    if (capturing) return nullptr;                        // (no allocation / memset inside a capture)
+    int* p = nullptr;
+    const size_t bytes = (size_t)(CNT_RING + CNT_CAPTURED) * sizeof(int);
+    if (hipMalloc((void**)&p, bytes) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, bytes) != hipSuccess) { hipFree(p); return nullptr; }      // synchronous: visible to every later launch
+    g_cnt_pool[dev] = p;
+  }
+  if (capturing) {
+    if (g_cnt_cap[dev] + n > CNT_CAPTURED) return nullptr;
+    int* r = g_cnt_pool[dev] + CNT_RING + g_cnt_cap[dev];
+    g_cnt_cap[dev] += n;
+    return r;
+  }
+  unsigned at = g_cnt_ring[dev];
+  if (at + (unsigned)n > (unsigned)CNT_RING) at = 0;
+  g_cnt_ring[dev] = at + (unsigned)n;
+  return g_cnt_pool[dev] + at;
 }
 
 namespace {

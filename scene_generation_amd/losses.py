@@ -18,6 +18,14 @@ def get_gan_losses(gan_type):
     raise ValueError('Unrecognized GAN type "%s"' % gan_type)
 
 
+def _pair(kind, scores_real, scores_fake):
+    """l(real | 1) + l(fake | 0): the two terms and their sum as ONE launch (ops.multi_loss; host tensors: plain terms)"""
+    if scores_real.is_cuda:
+        return ops.multi_loss(kind, [scores_real.reshape(-1), scores_fake.reshape(-1)], None, [1.0, 0.0], [1.0, 1.0])
+    one = {ops.LOSS_BCE_CONST: ops.bce_logits_const, ops.LOSS_MSE_SIGMOID_CONST: ops.mse_sigmoid_const}[kind]
+    return weighted_sum([one(scores_real.reshape(-1), 1.0), one(scores_fake.reshape(-1), 0.0)], [1.0, 1.0])
+
+
 def bce_loss(input, target):
     """Numerically stable BCE-with-logits against a CONSTANT target (losses.py:26-44; every call site uses
     full_like targets, losses.py:47-56)."""
@@ -30,8 +38,7 @@ def gan_g_loss(scores_fake):
 
 def gan_d_loss(scores_real, scores_fake):
     assert scores_real.size() == scores_fake.size()
-    return weighted_sum([ops.bce_logits_const(scores_real.reshape(-1), 1.0),
-                         ops.bce_logits_const(scores_fake.reshape(-1), 0.0)], [1.0, 1.0])
+    return _pair(ops.LOSS_BCE_CONST, scores_real, scores_fake)
 
 
 def wgan_g_loss(scores_fake):
@@ -52,8 +59,7 @@ def lsgan_g_loss(scores_fake):
 def lsgan_d_loss(scores_real, scores_fake):
     """losses.py:122-132"""
     assert scores_real.size() == scores_fake.size()
-    return weighted_sum([ops.mse_sigmoid_const(scores_real.reshape(-1), 1.0),
-                         ops.mse_sigmoid_const(scores_fake.reshape(-1), 0.0)], [1.0, 1.0])
+    return _pair(ops.LOSS_MSE_SIGMOID_CONST, scores_real, scores_fake)
 
 
 class GANLoss(nn.Module):
@@ -72,6 +78,9 @@ class GANLoss(nn.Module):
     def __call__(self, input, target_is_real):
         t = self.real_label if target_is_real else self.fake_label
         if isinstance(input[0], list):
+            if len(input) > 1 and input[0][-1].is_cuda:      # the per-scale terms and their sum as one launch
+                kind = ops.LOSS_MSE_CONST if self.use_lsgan else ops.LOSS_BCE_PROB_CONST
+                return ops.multi_loss(kind, [input_i[-1] for input_i in input], None, [t] * len(input))
             terms = [self._one(input_i[-1], t) for input_i in input]
             return terms[0] if len(terms) == 1 else weighted_sum(terms, [1.0] * len(terms))
         return self._one(input[-1], t)
@@ -175,4 +184,6 @@ class VGGLoss(nn.Module):
         x_vgg = self.vgg(x)
         with torch.no_grad():            # y is the ground-truth image and the network is frozen: nothing to record
             y_vgg = self.vgg(y)
+        if x_vgg[0].is_cuda:
+            return ops.l1_multi(x_vgg, y_vgg, self.weights)         # five terms + their sum: one launch
         return weighted_sum([ops.l1(a, b) for a, b in zip(x_vgg, y_vgg)], self.weights)

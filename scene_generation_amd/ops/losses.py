@@ -105,6 +105,61 @@ def weighted_sum(tensors, weights):
     return WeightedSumFn.apply(tuple(weights), *tensors)
 
 
+class MultiLossFn(Function):
+    """sum_t w_t * (scale_t * sum_i l(a_t[i], b_t[i] | target_t)) over several tensors in ONE launch (and one for the backward):
+    the weighted sum of len(a) ScalarLossFn terms of one kind, same arithmetic in the same order (bit-identical), without the
+    2 + 1 launches per term and the sum's own two (sg_multi_loss_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, kind, targets, scales, weights, nt, *ab):
+        a = [_f32(t, 'loss input') for t in ab[:nt]]
+        b = [None if t is None else _f32(t, 'loss target') for t in ab[nt:]] if len(ab) > nt else [None] * nt
+        dev = a[0].device
+        pa = (ctypes.c_void_p * nt)(*[t.data_ptr() for t in a])
+        pb = (ctypes.c_void_p * nt)(*[None if t is None else t.data_ptr() for t in b])
+        n = (ctypes.c_int64 * nt)(*[t.numel() for t in a])
+        sc, w, tg = (ctypes.c_float * nt)(*scales), (ctypes.c_float * nt)(*weights), (ctypes.c_float * nt)(*targets)
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        wsb = _L().sg_multi_loss_ws_bytes(nt)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        cv = lambda x: ctypes.cast(x, ctypes.c_void_p)
+        _call('sg_multi_loss_fwd', kind, nt, cv(pa), cv(pb), cv(n), cv(sc), cv(w), cv(tg), _p(out), None, _p(ws), wsb, _stream())
+        ctx.cfg = (kind, nt, pa, pb, n, sc, w, tg)
+        ctx.save_for_backward(*(a + [t for t in b if t is not None]))       # (keeps the operands the pointer arrays name alive)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        kind, nt, pa, pb, n, sc, w, tg = ctx.cfg
+        a = ctx.saved_tensors[:nt]
+        gout = _f32(gout.reshape(1))
+        ga = [torch.empty_like(t) if ctx.needs_input_grad[5 + i] else None for i, t in enumerate(a)]
+        pg = (ctypes.c_void_p * nt)(*[None if g is None else g.data_ptr() for g in ga])
+        cv = lambda x: ctypes.cast(x, ctypes.c_void_p)
+        _call('sg_multi_loss_bwd', kind, nt, cv(pa), cv(pb), cv(n), cv(sc), cv(w), cv(tg), _p(gout), cv(pg), _stream())
+        return (None, None, None, None, None) + tuple(ga) + (None,) * (len(ctx.needs_input_grad) - 5 - nt)
+
+
+def multi_loss(kind, a, b=None, targets=None, weights=None, mean=True):
+    """sum_t weights[t] * l_kind(a[t], b[t] | targets[t]) with the mean over each tensor's elements (``mean``), as one launch;
+    chunks of <= 32 terms.  ``b``: per-term second operands (detached) for the pair kinds, else None."""
+    nt = len(a)
+    weights = [1.0] * nt if weights is None else [float(x) for x in weights]
+    targets = [0.0] * nt if targets is None else [float(x) for x in targets]
+    if nt > WSUM_MAX:
+        parts = [multi_loss(kind, a[i:i + WSUM_MAX], None if b is None else b[i:i + WSUM_MAX], targets[i:i + WSUM_MAX],
+                            weights[i:i + WSUM_MAX], mean) for i in range(0, nt, WSUM_MAX)]
+        return weighted_sum(parts, [1.0] * len(parts))
+    scales = [1.0 / t.numel() if mean else 1.0 for t in a]
+    extra = () if b is None else tuple(t.detach() for t in b)
+    return MultiLossFn.apply(kind, tuple(targets), tuple(scales), tuple(weights), nt, *(tuple(a) + extra))
+
+
+def l1_multi(a, b, weights):
+    """sum_t weights[t] * nn.L1Loss()(a[t], b[t].detach())"""
+    return multi_loss(LOSS_L1, a, b, None, weights)
+
+
 class CrossEntropyFn(Function):
     @staticmethod
     def forward(ctx, logits, target):

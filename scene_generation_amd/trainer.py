@@ -423,8 +423,10 @@ class Trainer:
         nums_d = len(pred_fake)
         feat_weights = 4.0 / len(pred_fake[0])
         D_weights = 1.0 / nums_d
-        terms = [ops.l1(pred_fake[i][j], pred_real[i][j].detach())
-                 for i in range(nums_d) for j in range(len(pred_fake[i]) - 1)]
+        pairs = [(pred_fake[i][j], pred_real[i][j].detach()) for i in range(nums_d) for j in range(len(pred_fake[i]) - 1)]
+        if pairs and pairs[0][0].is_cuda:                 # every term and the weighted sum in ONE launch (ops.MultiLossFn)
+            return ops.l1_multi([a for a, _ in pairs], [b for _, b in pairs], [D_weights * feat_weights] * len(pairs))
+        terms = [ops.l1(a, b) for a, b in pairs]
         return weighted_sum(terms, [D_weights * feat_weights] * len(terms))
 
     def draw_use_gt(self, rng=None):
