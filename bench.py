@@ -97,6 +97,8 @@ def cpu_baseline(image_size, n_images, n_steps):
 PMC_KERNELS = {
     # profiler kind -> regex of the kernel symbol (the two dense Winograd instantiations: stores at the top / interleaved)
     'wino_bgemm_t128': r'igemm_kernel.*TileCfg<128, 128, 2, 2, [12]>.*EpRowMajorPlain',
+    # the three 64x64-tile instantiations of the F(4x4,3x3) GEMMs (forward, data gradient, weight gradient)
+    'wino43_bgemm_t64': r'igemm_kernel.*TileCfg<64, 64, 2, 2, 2>.*EpRowMajorPlain',
 }
 
 
@@ -174,6 +176,12 @@ def measure_traffic(kind, timeout_s=150):
 
 # what the profiler kinds are, as template instantiations (include/sg2im_hip.h, csrc/igemm.hip)
 KERNEL_INSTANTIATIONS = {
+    'wino43_bgemm_t64': 'igemm_kernel<TileCfg<64,64,2,2,2>, A, B, EpRowMajorPlain> with (A, B) = (LoadKContig<64>, LoadKContig<64>) forward, '
+                        '(LoadKContig<64>, LoadXContigS<64>) data gradient, (LoadXContigS<64>, LoadXContigS<64>) weight gradient: the 36 '
+                        'batched dense GEMMs of a Winograd F(4x4,3x3) conv (the 1024-channel ResnetBlock convs of the generator '
+                        'trunk), batch-major tile order, 32-deep software-pipelined k-tiles, buffer loads with the k advance in '
+                        'the SGPR offset',
+
     'wino_bgemm_t128': 'igemm_kernel<TileCfg<128,128,2,2,2>, LoadKContig<128,true,false>, LoadKContig<128,true,false>, EpRowMajorPlain>: '
                        'the 16 batched dense GEMMs of a Winograd F(2x2,3x3) conv (ResnetBlock / VGG19 convs), batch-major '
                        'tile order, 32-deep k-tiles, buffer loads with the k advance in the SGPR offset, software-pipelined '
@@ -376,6 +384,9 @@ def main():
             if name == 'wino_bgemm_t128':
                 Cc, P = 64 << 4, B * (S // 32) ** 2
                 alg = 4.0 * 16 * (Cc * Cc + P * Cc + Cc * P)
+            elif name == 'wino43_bgemm_t64':         # 36 batches, P = B (S / 64)^2 tiles of 4x4 outputs (forward / data gradient)
+                Cc, P = 64 << 4, B * (S // 64) ** 2
+                alg = 4.0 * 36 * (Cc * Cc + P * Cc + Cc * P)
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': ach / F32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': tsrc,
                                'traffic_detail': tdetail, 'algorithmic_bytes_per_launch': alg,

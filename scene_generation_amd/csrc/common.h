@@ -86,6 +86,7 @@ enum {
   SG_K_HEAD,          // single-output-channel convolutions on the vector ALUs (smallm.hip), HBM-bound
   SG_K_INSTNORM_BWD,
   SG_K_WINO24_GEMM,   // the 25 (x k-chunks) batched dense GEMMs of a Winograd F(2x2,4x4) conv (same instantiation as SG_K_WINO_GEMM_128)
+  SG_K_WINO43_GEMM,   // the 36 batched dense GEMMs of a Winograd F(4x4,3x3) conv (64x64 tiles)
   SG_K_COUNT
 };
 static inline int sg_igemm_kind(int family, int KS, int tile) {

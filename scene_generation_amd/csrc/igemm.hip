@@ -908,6 +908,418 @@ void wino_bgemm_x(const float* Ytp, const float* V, float* T, int M, int Cc, int
 
 
 // ================================================================================================
+// Winograd F(4x4, 3x3) for the small-plane reflection-padded ResnetBlock convs (generators.py:62-91 through layers.py:234-273: the
+// nine 1024-channel blocks at 8x8 -- 16x16 at 256^2 -- are 54 of the step's GEMM launches): 36 multiplies per 4x4 output tile
+// and channel pair instead of 4 x 16 = 64 with F(2x2,3x3), i.e. 1.78x fewer MACs, 2.25x (not 4x) the activation bytes in the
+// transformed operands.  Interpolation points 0, 1, -1, 1/2, -2, inf -- the set with the smallest fp32 error of the ones
+// tried (tools/winograd_f43.py: 4.1e-6 of max|y| over a 1024-channel reduction against 1.3e-6 for F(2x2,3x3) and 0.8e-6 direct;
+// the classic 0, +-1, +-2 set: 8.1e-6):
+//   A^T = [1 1 1 1 1 0; 0 1 -1 1/2 -2 0; 0 1 1 1/4 4 0; 0 1 -1 1/8 -8 1]
+//   G   = [1 0 0; 1/3 1/3 1/3; -1/3 1/3 -1/3; -16/15 -8/15 -4/15; 1/15 -2/15 4/15; 0 0 1]
+//   B^T = [1 -3/2 -2 3/2 1 0; 0 -1 1/2 5/2 1 0; 0 1 -5/2 1/2 1 0; 0 -2 -1 2 1 0; 0 1/2 -1 -1/2 1 0; 0 1 -3/2 -2 3/2 1]
+//   y = A^T [sum_c (G g G^T) (.) (B^T d B)] A            (forward)
+//   g_d = B [sum_k (G g G^T) (.) (A g_y A^T)] B^T        (data gradient: the adjoint over the OUTPUT tiles, overlap-added)
+//   g_w = G^T [sum_p (A g_y A^T) (.) (B^T d B)] G        (weight gradient)
+// Same structure as the F(2x2,3x3) path above: LDS-staged transforms with the lanes along the channel, 36 batched dense GEMMs
+// on 64x64 tiles (P = N H W / 16 tiles per launch: 128 at the benchmark shape, too few columns for 128-wide tiles), the
+// filter transform U kept from the forward for the data gradient (read x-contiguous there: no transposed twin), V and Ytp
+// kept for the weight gradient.
+// ================================================================================================
+namespace {
+__device__ __forceinline__ constexpr float w43_bt(int i, int j) {
+  constexpr float m[6][6] = {{1.f, -1.5f, -2.f, 1.5f, 1.f, 0.f}, {0.f, -1.f, 0.5f, 2.5f, 1.f, 0.f}, {0.f, 1.f, -2.5f, 0.5f, 1.f, 0.f},
+                             {0.f, -2.f, -1.f, 2.f, 1.f, 0.f},   {0.f, 0.5f, -1.f, -0.5f, 1.f, 0.f}, {0.f, 1.f, -1.5f, -2.f, 1.5f, 1.f}};
+  return m[i][j];
+}
+__device__ __forceinline__ constexpr float w43_g(int i, int j) {
+  constexpr float m[6][3] = {{1.f, 0.f, 0.f}, {1.f / 3.f, 1.f / 3.f, 1.f / 3.f}, {-1.f / 3.f, 1.f / 3.f, -1.f / 3.f},
+                             {-16.f / 15.f, -8.f / 15.f, -4.f / 15.f}, {1.f / 15.f, -2.f / 15.f, 4.f / 15.f}, {0.f, 0.f, 1.f}};
+  return m[i][j];
+}
+__device__ __forceinline__ constexpr float w43_at(int i, int j) {
+  constexpr float m[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 0.5f, -2.f, 0.f}, {0.f, 1.f, 1.f, 0.25f, 4.f, 0.f},
+                             {0.f, 1.f, -1.f, 0.125f, -8.f, 1.f}};
+  return m[i][j];
+}
+// acc += c * x for a compile-time coefficient: nothing for 0, an add / subtract for +-1
+#define W43_ACC(acc, c, x) do { if ((c) == 1.f) (acc) += (x); else if ((c) == -1.f) (acc) -= (x); else if ((c) != 0.f) (acc) += (c) * (x); } while (0)
+
+// v = B^T d B of a 6x6 patch
+__device__ __forceinline__ void w43_input_xform(const float (&d)[6][6], float (&v)[6][6]) {
+  float t[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) W43_ACC(a, w43_bt(i, k), d[k][j]);
+      t[i][j] = a;
+    }
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) W43_ACC(a, w43_bt(j, k), t[i][k]);
+      v[i][j] = a;
+    }
+}
+// u = G g G^T of a 3x3 filter
+__device__ __forceinline__ void w43_weight_xform(const float* __restrict__ g, float (&u)[6][6]) {
+  float t[6][3];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) W43_ACC(a, w43_g(i, k), g[k * 3 + j]);
+      t[i][j] = a;
+    }
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) W43_ACC(a, w43_g(j, k), t[i][k]);
+      u[i][j] = a;
+    }
+}
+// y = A^T q A (4x4 from 6x6)
+__device__ __forceinline__ void w43_output_xform(const float (&q)[6][6], float (&y)[4][4]) {
+  float t[4][6];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) W43_ACC(a, w43_at(i, k), q[k][j]);
+      t[i][j] = a;
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) W43_ACC(a, w43_at(j, k), t[i][k]);
+      y[i][j] = a;
+    }
+}
+// yt = A gy A^T (6x6 from a 4x4 gradient tile), A = (A^T)^T
+__device__ __forceinline__ void w43_gy_xform(const float (&g)[4][4], float (&yt)[6][6]) {
+  float t[6][4];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) W43_ACC(a, w43_at(k, i), g[k][j]);
+      t[i][j] = a;
+    }
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) W43_ACC(a, w43_at(k, j), t[i][k]);
+      yt[i][j] = a;
+    }
+}
+// r = B q B^T (the adjoint of the input transform), B = (B^T)^T
+__device__ __forceinline__ void w43_patch_xform(const float (&q)[6][6], float (&r)[6][6]) {
+  float t[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) W43_ACC(a, w43_bt(k, i), q[k][j]);
+      t[i][j] = a;
+    }
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) W43_ACC(a, w43_bt(k, j), t[i][k]);
+      r[i][j] = a;
+    }
+}
+// gw = G^T q G (3x3 from 6x6)
+__device__ __forceinline__ void w43_wgrad_xform(const float (&q)[6][6], float (&o)[3][3]) {
+  float t[3][6];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) W43_ACC(a, w43_g(k, i), q[k][j]);
+      t[i][j] = a;
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) W43_ACC(a, w43_g(k, j), t[i][k]);
+      o[i][j] = a;
+    }
+}
+
+// stage the H x W planes of 64 consecutive channels of image n (one contiguous block) in LDS, pitch HW + 1
+__device__ __forceinline__ void w43_stage_planes(const float* __restrict__ src, float* __restrict__ pl, int HW, int tid) {
+  const int pitch = HW + 1;
+  for (int i0 = tid * 4; i0 < 64 * HW; i0 += 4096) {          // four float4 loads in flight before the first LDS store
+    float4 v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i0 + e * 1024 < 64 * HW) v[e] = *reinterpret_cast<const float4*>(src + i0 + e * 1024);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = i0 + e * 1024;
+      if (i < 64 * HW) {
+        const int ch = i / HW, px = i - ch * HW;
+        float* d = pl + ch * pitch + px;
+        d[0] = v[e].x; d[1] = v[e].y; d[2] = v[e].z; d[3] = v[e].w;
+      }
+    }
+  }
+}
+
+// V[xi][p][c] = (B^T d B)[xi] of the reflection-padded 6x6 patch of tile p = (n, ti, tj): rows 4ti-1 .. 4ti+4
+__global__ void __launch_bounds__(256) w43_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int C, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float pl[];
+  const int HW = H * W, pitch = HW + 1, TH = H / 4, TW = W / 4;
+  const int n = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
+  w43_stage_planes(x + ((size_t)n * C + c0) * HW, pl, HW, tid);
+  __syncthreads();
+  const int c = tid & 63, g = tid >> 6;
+  const float* pc = pl + c * pitch;
+  const size_t P = (size_t)N * TH * TW;
+  for (int t = g; t < TH * TW; t += 4) {
+    const int ti = t / TW, tj = t - ti * TW;
+    float d[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const int ih = wino_reflect(4 * ti - 1 + a, H);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) d[a][b] = pc[ih * W + wino_reflect(4 * tj - 1 + b, W)];
+    }
+    float v[6][6];
+    w43_input_xform(d, v);
+    const size_t p = (size_t)n * TH * TW + t;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) V[((size_t)(i * 6 + j) * P + p) * C + c0 + c] = v[i][j];
+  }
+}
+
+// U[xi][r][c] = (G g G^T)[xi], g = w[r][c]: a workgroup owns a 32x32 block of (r, c) (wino_weight_lds_kernel's staging)
+__global__ void __launch_bounds__(256) w43_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int R, int Cc) {
+  __shared__ float S[32 * WW_PITCH];
+  const int cb = blockIdx.x % (Cc / 32), rb = blockIdx.x / (Cc / 32);
+  const int r0 = rb * 32, c0 = cb * 32, t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int idx = i * 256 + t, j = idx / 72, o = (idx - j * 72) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(w + ((size_t)(r0 + j) * Cc + c0) * 9 + o);
+    float* d = S + j * WW_PITCH + o;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+  const size_t RC = (size_t)R * Cc;
+  const int cl = t & 31;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rl = (t >> 5) + 8 * q;
+    float u[6][6];
+    w43_weight_xform(S + rl * WW_PITCH + cl * 9, u);
+    const size_t i = (size_t)(r0 + rl) * Cc + c0 + cl;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) U[(size_t)(a * 6 + b) * RC + i] = u[a][b];
+  }
+}
+
+// y[n][m][4ti+a][4tj+b] = act((A^T Mx A)[a][b] + bias[m]),  Mx[m][xi*P + p]
+__global__ void w43_output_kernel(const float* __restrict__ Mx, const float* __restrict__ bias, float* __restrict__ y, int N, int M,
+                                  int H, int W, int act, float slope) {
+  const int TH = H / 4, TW = W / 4;
+  const size_t P = (size_t)N * TH * TW;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= P * M) return;
+  const size_t p = idx % P;
+  const int m = (int)(idx / P);
+  const float* src = Mx + (size_t)m * 36 * P + p;
+  float q[6][6];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) q[i / 6][i % 6] = src[(size_t)i * P];
+  float o[4][4];
+  w43_output_xform(q, o);
+  const float b = bias ? bias[m] : 0.f;
+  const int n = (int)(p / (TH * TW)), r = (int)(p - (size_t)n * TH * TW), ti = r / TW, tj = r - ti * TW;
+  float* dst = y + (((size_t)n * M + m) * H + 4 * ti) * W + 4 * tj;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+    *reinterpret_cast<float4*>(dst + a * W) = make_float4(sg_apply_act(o[a][0] + b, act, slope), sg_apply_act(o[a][1] + b, act, slope),
+                                                          sg_apply_act(o[a][2] + b, act, slope), sg_apply_act(o[a][3] + b, act, slope));
+}
+
+// Ytp[xi][p][m] = (A gy A^T)[xi] of the 4x4 gradient tile p (LDS-staged, lanes along the channel m)
+__global__ void __launch_bounds__(256) w43_gy_kernel(const float* __restrict__ gy, float* __restrict__ Ytp, int N, int M, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float pl[];
+  const int HW = H * W, pitch = HW + 1, TH = H / 4, TW = W / 4;
+  const int n = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x;
+  w43_stage_planes(gy + ((size_t)n * M + c0) * HW, pl, HW, tid);
+  __syncthreads();
+  const int c = tid & 63, g = tid >> 6;
+  const float* pc = pl + c * pitch;
+  const size_t P = (size_t)N * TH * TW;
+  for (int t = g; t < TH * TW; t += 4) {
+    const int ti = t / TW, tj = t - ti * TW;
+    float gt[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) gt[a][b] = pc[(4 * ti + a) * W + 4 * tj + b];
+    float yt[6][6];
+    w43_gy_xform(gt, yt);
+    const size_t p = (size_t)n * TH * TW + t;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) Ytp[((size_t)(i * 6 + j) * P + p) * M + c0 + c] = yt[i][j];
+  }
+}
+
+// gx[n][c][H][W] from G[p][xi*C + c]: the 6x6 patches B G B^T of the tiles are overlap-added into the padded (H+2) x (W+2) plane
+// of their channel and the reflection is folded.  Thread (c, g) transforms the tiles g, g+4, ... of channel c (all loads and
+// the arithmetic of the four groups run side by side); the patches are then added into the channel's LDS plane ROUND by round
+// in tile order -- in round t only the owner of tile t adds -- so every cell receives its contributions in ascending tile
+// order whatever the wave timing: deterministic, no atomics.
+__global__ void __launch_bounds__(256) w43_fold_kernel(const float* __restrict__ G, float* __restrict__ gx, int N, int C, int H, int W) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int HW = H * W, PW = W + 2, PP = (H + 2) * PW, TH = H / 4, TW = W / 4, NT = TH * TW;
+  const int n = blockIdx.y, c0 = blockIdx.x * 64, c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  float* acc = lds + c * (PP + 1);
+  float* stage = lds + 64 * (PP + 1);              // [64][HW + 1]
+  for (int i = g; i < PP; i += 4) acc[i] = 0.f;
+  const size_t ld = (size_t)36 * C;
+  const float* base = G + (size_t)n * NT * ld + c0 + c;
+  __syncthreads();
+  for (int t0 = 0; t0 < NT; t0 += 4) {
+    const int t = t0 + g;                          // this thread's tile of the round (wave-uniform)
+    float r[6][6];
+    if (t < NT) {
+      float q[6][6];
+      const float* src = base + (size_t)t * ld;
+#pragma unroll
+      for (int i = 0; i < 36; ++i) q[i / 6][i % 6] = src[(size_t)i * C];
+      w43_patch_xform(q, r);
+    }
+    for (int k = 0; k < 4; ++k) {                  // tiles t0 .. t0+3 in order
+      if (g == k && t < NT) {
+        const int ti = t / TW, tj = t - ti * TW;
+        float* dst = acc + (4 * ti) * PW + 4 * tj;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = 0; b < 6; ++b) dst[a * PW + b] += r[a][b];
+      }
+      __syncthreads();
+    }
+  }
+  float* so = stage + c * (HW + 1);
+  for (int a = g; a < H; a += 4) {
+    for (int b = 0; b < W; ++b) {
+      float v = acc[(a + 1) * PW + b + 1];
+      const int ra = a == 1 ? 0 : -1, rb = a == H - 2 ? H + 1 : -1;        // padded rows folded onto row a
+      const int ca = b == 1 ? 0 : -1, cb = b == W - 2 ? W + 1 : -1;        // padded columns folded onto column b
+      if (ra >= 0) v += acc[ra * PW + b + 1];
+      if (rb >= 0) v += acc[rb * PW + b + 1];
+      if (ca >= 0) v += acc[(a + 1) * PW + ca];
+      if (cb >= 0) v += acc[(a + 1) * PW + cb];
+      if (ra >= 0 && ca >= 0) v += acc[ra * PW + ca];
+      if (ra >= 0 && cb >= 0) v += acc[ra * PW + cb];
+      if (rb >= 0 && ca >= 0) v += acc[rb * PW + ca];
+      if (rb >= 0 && cb >= 0) v += acc[rb * PW + cb];
+      so[a * W + b] = v;
+    }
+  }
+  __syncthreads();
+  float* dstg = gx + ((size_t)n * C + c0) * HW;
+  for (int i = threadIdx.x * 4; i < 64 * HW; i += 1024) {
+    const int ch = i / HW, px = i - ch * HW;
+    const float* sp = stage + ch * (HW + 1) + px;
+    *reinterpret_cast<float4*>(dstg + i) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+  }
+}
+
+// gw[m][c][3][3] = G^T T G,  T[m][xi*C + c]
+__global__ void w43_wgrad_output_kernel(const float* __restrict__ T, float* __restrict__ gw, int M, int C) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)M * C) return;
+  const int c = (int)(idx % C);
+  const size_t m = idx / C;
+  const float* src = T + m * 36 * C + c;
+  float q[6][6];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) q[i / 6][i % 6] = src[(size_t)i * C];
+  float o[3][3];
+  w43_wgrad_xform(q, o);
+  float* dst = gw + idx * 9;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) dst[a * 3 + b] = o[a][b];
+}
+
+// the three batched GEMMs (36 batches, 64x64 tiles, 32-deep software-pipelined k-tiles)
+//   forward:          Mx[m][xi*P + p]  = sum_c U[xi][m][c] * V[xi][p][c]        (both K-contiguous)
+//   data gradient:    G[p][xi*C + c]   = sum_k Ytp[xi][p][k] * U[xi][k][c]      (A K-contiguous, B x-contiguous)
+//   weight gradient:  T[m][xi*C + c]   = sum_p Ytp[xi][p][m] * V[xi][p][c]      (both x-contiguous, K = P)
+void w43_gemm_fwd(const float* U, const float* V, float* Mx, int M, int P, int C, hipStream_t s) {
+  wino_bgemm_tile(2, U, V, Mx, M, P, C, 2.0 * 36.0 * M * (double)P * C, s, 36, SG_K_WINO43_GEMM);
+}
+void w43_gemm_dgrad(const float* Ytp, const float* U, float* G, int P, int C, int K, hipStream_t s) {
+  sgk::t_alg_bytes = 4.0 * 36 * ((double)P * K + (double)C * K + (double)P * C);
+  t_batch = BatchInfo{}; t_batch.cols_per_batch = C; t_batch.nbatch = 36; t_batch.a_stride = P * K; t_batch.b_stride = K * C;
+  t_batch.batch_major = 1;
+  {
+    SgProfScope prof(SG_K_WINO43_GEMM, s, 2.0 * 36.0 * P * (double)C * K, 0);
+    launch_cfg<CfgDI64>(LoadKContig<64, true, false>{Ytp, K, P}, LoadXContigS<64>{U, C, C}, EpRowMajorPlain{G, 36 * C}, P, 36 * C, K, 1, s);
+  }
+  t_batch = BatchInfo{};
+}
+void w43_gemm_wgrad(const float* Ytp, const float* V, float* T, int M, int C, int P, hipStream_t s) {
+  sgk::t_alg_bytes = 4.0 * 36 * ((double)M * P + (double)C * P + (double)M * C);
+  t_batch = BatchInfo{}; t_batch.cols_per_batch = C; t_batch.nbatch = 36; t_batch.a_stride = P * M; t_batch.b_stride = P * C;
+  t_batch.batch_major = 1;
+  {
+    SgProfScope prof(SG_K_WINO43_GEMM, s, 2.0 * 36.0 * M * (double)C * P, 0);
+    launch_cfg<CfgDI64>(LoadXContigS<64>{Ytp, M, 0}, LoadXContigS<64>{V, C, C}, EpRowMajorPlain{T, 36 * C}, M, 36 * C, P, 1, s);
+  }
+  t_batch = BatchInfo{};
+}
+template <class K> inline void w43_lds_attr(K kernel, size_t lds) {
+  if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+}  // namespace
+
+// ================================================================================================
 // Winograd F(2x2, 4x4) for the stride-1 4x4 convs of the PatchGANs (discriminators.py:221-228: Conv2d(256, 512, 4, 1, 2), the
 // largest single layer of the discriminator steps): 25 multiplies per 2x2 output tile and channel pair instead of 64.
 // Interpolation points 0, 1, -1, -2, inf (the set with the smallest fp32 error of the ones tried: ~3x the direct kernel's):
@@ -1274,7 +1686,12 @@ extern "C" size_t sg_conv2d_wino_ws_bytes(const sgConvDesc* d) {
   const size_t P = (size_t)d->N * (LH / 2) * (LW / 2), M = d->Cout, C = d->C1, Pd = wino_dgrad_tiles(d);
   const size_t a = 16 * (M * C + P * C + M * P);
   const size_t b = 16 * (M * C + Pd * M + C * Pd) + (size_t)d->N * C * (LH + 2) * (LW + 2);
-  return (a > b ? a : b) * sizeof(float) + 1024;
+  // F(4x4,3x3) (wino43_shape; the switch can change between the query and the call: always room for both forms):
+  // U[36][M][C] + max(V + Mx (forward), Ytp + G (data gradient), T + V + Ytp (weight gradient without saved operands))
+  const size_t P4 = (size_t)d->N * (LH / 4) * (LW / 4), mx = M > C ? M : C;
+  const size_t c = 36 * (M * C + 2 * P4 * mx + M * C);
+  const size_t m = a > b ? (a > c ? a : c) : (b > c ? b : c);
+  return m * sizeof(float) + 1024;
 }
 
 // gx [N, C1, H, W].  Reflection padding: Winograd over the (H+2) x (W+2) gradient of the reflect-padded input (correlation of
@@ -1285,9 +1702,17 @@ static bool wino_adjoint_shape(const sgConvDesc* d) {
   return sg_opt(SG_OPT_WINO_ADJOINT) && wino_ok(d) && d->pad_reflect && d->upsample == 1 && d->H * d->W <= 256 && (d->H * d->W) % 4 == 0 &&
          d->C1 % 64 == 0 && d->Cout % 64 == 0;
 }
-// floats of the transposed filter transform sg_conv2d_wino_fwd can hand to sg_conv2d_wino_dgrad (0: that conv's data gradient
-// does not use it)
+// F(4x4,3x3) instead of F(2x2,3x3): the adjoint-form shapes whose planes split into 4x4 output tiles and whose tile count fills
+// whole 64-column GEMM tiles
+static bool wino43_shape(const sgConvDesc* d) {
+  if (!sg_opt(SG_OPT_WINO43) || !wino_adjoint_shape(d) || d->H % 4 != 0 || d->W % 4 != 0) return false;
+  const double P = (double)d->N * (d->H / 4) * (d->W / 4), Cmax = d->C1 > d->Cout ? d->C1 : d->Cout;
+  return (long)P % 64 == 0 && 36.0 * P * Cmax < SG_MAX_ELEMS && 36.0 * d->C1 * d->Cout < SG_MAX_ELEMS;
+}
+// floats of the filter transform sg_conv2d_wino_fwd can hand to sg_conv2d_wino_dgrad (0: that conv's data gradient does not use
+// it): F(2x2,3x3) -- the transposed twin UT[16][C1][Cout]; F(4x4,3x3) -- U[36][Cout][C1] itself (read x-contiguous)
 extern "C" size_t sg_conv2d_wino_ut_floats(const sgConvDesc* d) {
+  if (wino43_shape(d)) return (size_t)36 * d->C1 * d->Cout;
   return (wino_adjoint_shape(d) && d->C1 % 32 == 0 && d->Cout % 32 == 0) ? (size_t)16 * d->C1 * d->Cout : 0;
 }
 
@@ -1295,10 +1720,12 @@ extern "C" size_t sg_conv2d_wino_ut_floats(const sgConvDesc* d) {
 // gradient (0: that conv's weight gradient rebuilds its operands)
 extern "C" size_t sg_conv2d_wino_v_floats(const sgConvDesc* d) {
   if (!sg_opt(SG_OPT_WINO_REUSE) || !wino_adjoint_shape(d)) return 0;
+  if (wino43_shape(d)) return (size_t)36 * d->N * (d->H / 4) * (d->W / 4) * d->C1;
   return (size_t)16 * d->N * (d->H / 2) * (d->W / 2) * d->C1;
 }
 extern "C" size_t sg_conv2d_wino_ytp_floats(const sgConvDesc* d) {
   if (!sg_opt(SG_OPT_WINO_REUSE) || !wino_adjoint_shape(d)) return 0;
+  if (wino43_shape(d)) return (size_t)36 * d->N * (d->H / 4) * (d->W / 4) * d->Cout;
   return (size_t)16 * d->N * (d->H / 2) * (d->W / 2) * d->Cout;
 }
 
@@ -1310,6 +1737,32 @@ extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const 
   const int M = d->C1, K = d->Cout;                 // rows = input channels, reduction over output channels
   const int LH = d->H * d->upsample, LW = d->W * d->upsample;
   const int refl = d->pad_reflect;
+  if (wino43_shape(d) && aligned16(gy) && aligned16(gx) && aligned16(w)) {
+    // F(4x4,3x3), adjoint form: Ytp = A gy A^T, G = Ytp x U (U from the forward, x-contiguous), overlap-add of B G B^T + fold
+    const int HW = d->H * d->W;
+    const size_t P = (size_t)d->N * (d->H / 4) * (d->W / 4);
+    float* Uw = reinterpret_cast<float*>(ws);       // [36][Cout][C1]
+    float* Ytp_ws = Uw + 36 * (size_t)M * K;        // [36][P][Cout]
+    float* G = Ytp_ws + 36 * P * (size_t)(K > M ? K : M);      // [P][36][C1]
+    float* Ytp = ytp_save ? ytp_save : Ytp_ws;
+    const float* U = ut_saved;
+    if (U == nullptr) {
+      SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 45.0 * (double)M * K);
+      hipLaunchKernelGGL(w43_weight_kernel, dim3((K / 32) * (M / 32)), dim3(256), 0, s, w, Uw, K, M);
+      U = Uw;
+    }
+    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * K * HW + 36.0 * (double)P * K));
+      const size_t lds = (size_t)64 * (HW + 1) * sizeof(float);
+      w43_lds_attr(&w43_gy_kernel, lds);
+      hipLaunchKernelGGL(w43_gy_kernel, dim3(K / 64, d->N), dim3(256), lds, s, gy, Ytp, d->N, K, d->H, d->W); }
+    w43_gemm_dgrad(Ytp, U, G, (int)P, M, K, s);
+    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * (36.0 * (double)P * M + (double)d->N * M * HW));
+      const size_t lds = (size_t)64 * ((d->H + 2) * (d->W + 2) + 1 + HW + 1) * sizeof(float);
+      w43_lds_attr(&w43_fold_kernel, lds);
+      hipLaunchKernelGGL(w43_fold_kernel, dim3(M / 64, d->N), dim3(256), lds, s, (const float*)G, gx, d->N, M, d->H, d->W); }
+    SG_LAUNCH_CHECK("sg_conv2d_wino_dgrad");
+    return 0;
+  }
   if (wino_adjoint_shape(d) && aligned16(gy) && aligned16(gx)) {
     // adjoint Winograd over the output tiles (see wino_gy_small_kernel / wino_patch_fold_kernel)
     const int HW = d->H * d->W;
@@ -1370,6 +1823,28 @@ extern "C" int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const flo
   hipStream_t s = (hipStream_t)stream;
   const int M = d->Cout, C = d->C1;
   const int LH = d->H * d->upsample, LW = d->W * d->upsample;
+  if (wino43_shape(d) && aligned16(x) && aligned16(y) && aligned16(w)) {
+    // F(4x4,3x3): U = G g G^T (into ut_save when the data gradient follows), V = B^T d B, 36 GEMMs, y = A^T Mx A + bias
+    const int HW = d->H * d->W;
+    const size_t P = (size_t)d->N * (d->H / 4) * (d->W / 4);
+    float* U_ws = reinterpret_cast<float*>(ws);
+    float* V_ws = U_ws + 36 * (size_t)M * C;
+    float* Mx = V_ws + 36 * P * (size_t)(C > M ? C : M);
+    float* U = ut_save ? ut_save : U_ws;
+    float* V = v_save ? v_save : V_ws;
+    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 45.0 * (double)M * C);
+      hipLaunchKernelGGL(w43_weight_kernel, dim3((M / 32) * (C / 32)), dim3(256), 0, s, w, U, M, C); }
+    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * C * HW + 36.0 * (double)P * C));
+      const size_t lds = (size_t)64 * (HW + 1) * sizeof(float);
+      w43_lds_attr(&w43_input_kernel, lds);
+      hipLaunchKernelGGL(w43_input_kernel, dim3(C / 64, d->N), dim3(256), lds, s, x, V, d->N, C, d->H, d->W); }
+    w43_gemm_fwd(U, V, Mx, M, (int)P, C, s);
+    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * (36.0 * (double)P * M + (double)d->N * M * HW));
+      hipLaunchKernelGGL(w43_output_kernel, dim3(sg_cdiv(P * M, 256)), dim3(256), 0, s, (const float*)Mx, bias, y, d->N, M, d->H, d->W,
+                         act, slope); }
+    SG_LAUNCH_CHECK("sg_conv2d_wino_fwd");
+    return 0;
+  }
   const size_t P = (size_t)d->N * (LH / 2) * (LW / 2);
   float* U = reinterpret_cast<float*>(ws);
   float* V_ws = U + 16 * (size_t)M * C;
@@ -1396,6 +1871,32 @@ extern "C" int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const 
   const int M = d->Cout, C = d->C1;
   const int LH = d->H * d->upsample, LW = d->W * d->upsample;
   const size_t P = (size_t)d->N * (LH / 2) * (LW / 2);
+  if (wino43_shape(d) && aligned16(x) && aligned16(gy)) {
+    // F(4x4,3x3): T = Ytp^T x V over the tiles, gw = G^T T G; the operands come from this conv's forward / data gradient when
+    // the caller kept them, else they are rebuilt here
+    const int HW = d->H * d->W;
+    const size_t P4 = (size_t)d->N * (d->H / 4) * (d->W / 4);
+    float* T4 = reinterpret_cast<float*>(ws);       // [M][36][C]
+    const float* V = v_saved;
+    const float* Ytp = ytp_saved;
+    if (!(V && Ytp)) {
+      float* Vw = T4 + 36 * (size_t)M * C;
+      float* Yw = Vw + 36 * P4 * (size_t)(C > M ? C : M);
+      const size_t lds = (size_t)64 * (HW + 1) * sizeof(float);
+      { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * C * HW + 36.0 * (double)P4 * C));
+        w43_lds_attr(&w43_input_kernel, lds);
+        hipLaunchKernelGGL(w43_input_kernel, dim3(C / 64, d->N), dim3(256), lds, s, x, Vw, d->N, C, d->H, d->W); }
+      { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * M * HW + 36.0 * (double)P4 * M));
+        w43_lds_attr(&w43_gy_kernel, lds);
+        hipLaunchKernelGGL(w43_gy_kernel, dim3(M / 64, d->N), dim3(256), lds, s, gy, Yw, d->N, M, d->H, d->W); }
+      V = Vw; Ytp = Yw;
+    }
+    w43_gemm_wgrad(Ytp, V, T4, M, C, (int)P4, s);
+    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 45.0 * (double)M * C);
+      hipLaunchKernelGGL(w43_wgrad_output_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, (const float*)T4, gw, M, C); }
+    SG_LAUNCH_CHECK("sg_conv2d_wino_wgrad");
+    return 0;
+  }
   float* T = reinterpret_cast<float*>(ws);          // [M][16][C]
   if (v_saved && ytp_saved) {
     // operands already built by the forward (V) and the adjoint data gradient (Ytp) of this conv in this step

@@ -121,7 +121,7 @@ double g_ms[SG_K_COUNT], g_flops[SG_K_COUNT], g_bytes[SG_K_COUNT];
 int64_t g_cnt[SG_K_COUNT];
 const char* kTail[SG_K_COUNT - SG_K_IGEMM_COUNT] = {"linear", "layout_fwd", "layout_bwd", "instnorm", "batchnorm", "adam",
                                                     "segsum", "crop", "other", "wino_bgemm_t128", "wino_bgemm_t64",
-                                                    "wino_transforms", "head_conv", "instnorm_bwd", "wino24_bgemm_t128"};
+                                                    "wino_transforms", "head_conv", "instnorm_bwd", "wino24_bgemm_t128", "wino43_bgemm_t64"};
 char g_names[SG_K_COUNT][32];
 bool g_names_init = false;
 void init_names() {

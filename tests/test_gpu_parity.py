@@ -165,6 +165,9 @@ CONV_CASES = [
     (8, 256, 0, 19, 19, 128, 4, 1, 0, False, 1, 1),    # F(2x2,4x4): valid conv, data gradient with padding 3, k-chunked wgrad
     (6, 3, 0, 64, 64, 64, 4, 2, 1, False, 1, 2),       # crop-D first conv: few-channel wgrad in 48 k-chunks (wide slab reduce)
     (40, 3, 0, 64, 64, 64, 4, 2, 1, False, 1, 2),      # the same at ~200 crops: the 256-chunk cap, XCD-padded chunk count
+    (16, 128, 0, 8, 8, 128, 3, 1, 1, True, 1, 0),      # Winograd F(4x4,3x3): 16 * 2 * 2 = 64 tiles of 4x4 outputs (one 64-column GEMM tile)
+    (8, 256, 0, 16, 16, 128, 3, 1, 1, True, 1, 1),     # F(4x4,3x3) at 16x16 planes (configs[3] trunk), Cin != Cout, fused ReLU
+    (32, 128, 0, 8, 8, 256, 3, 1, 1, True, 1, 2),      # F(4x4,3x3): the benchmark's tile count (128), Cout > Cin, fused LeakyReLU
 ]
 
 
@@ -196,6 +199,38 @@ def test_conv2d(hip, case):
         close(g2.grad, r2.grad, 5e-5, 'gx2')
     close(gw.grad, rw.grad, 5e-5, 'gw')
     close(gb.grad, rb.grad, 5e-5, 'gb')
+
+
+def test_winograd_f43_trunk_shape_vs_f23_and_fp64(hip):
+    """The 1024-channel 8x8 ResnetBlock conv of the generator trunk (generators.py:80-82, layers.py:251-270) at N = 16: Winograd
+    F(4x4,3x3) (the default since round 5) and F(2x2,3x3) (wino43 = 0) against an fp64 reference -- forward, data gradient,
+    weight and bias gradient.  Both must hold the conv tolerances of the suite; the measured errors of the two forms go to
+    gpurun_out/winograd_f43_errors.json (conv-level error of F(4x4,3x3) <= 2x the asserted bounds)."""
+    from scene_generation_amd import _hip
+    N, C, H = 16, 1024, 8
+    x, w, b = det((N, C, H, H), 311), det((C, C, 3, 3), 312, 0.05), det((C,), 313, 0.2)
+    gy = det((N, C, H, H), 314)
+    xr, wr, br = [t.double().requires_grad_() for t in (x, w, b)]
+    yr = F.conv2d(F.pad(xr, (1,) * 4, mode='reflect'), wr, br)
+    yr.backward(gy.double())
+    errs = {}
+    saved = _hip.get_option('wino43')
+    try:
+        for form, flag in (('f43', 1), ('f23', 0)):
+            _hip.set_option('wino43', flag)
+            xg, wg, bg = [t.to(DEV).requires_grad_() for t in (x, w, b)]
+            yg = hip.conv2d(xg, wg, bg, pad=1, reflect=True)
+            yg.backward(gy.to(DEV))
+            for name, got, want, tol in (('y', yg, yr, 3e-5), ('gx', xg.grad, xr.grad, 5e-5), ('gw', wg.grad, wr.grad, 5e-5),
+                                         ('gb', bg.grad, br.grad, 5e-5)):
+                e = float((got.detach().double().cpu() - want.detach()).abs().max() / want.detach().abs().max())
+                errs['%s_%s' % (form, name)] = e
+                close(got, want.detach().float(), tol, '%s %s' % (form, name))
+    finally:
+        _hip.set_option('wino43', saved)
+    _dump('winograd_f43_errors.json', errs)
+    for name in ('y', 'gx', 'gw'):
+        assert errs['f43_' + name] <= 6e-5, errs             # 2x the asserted conv bound, whatever F(2x2,3x3) shows
 
 
 @pytest.mark.parametrize('N,C,dense,H,Cout,KS,stride,pad,reflect,C2', [
