@@ -231,6 +231,14 @@ int sg_check_indices(const int64_t* idx, int64_t n, int64_t lo, int64_t hi, cons
 /* out[t] = [obj[s_t], pred[t], obj[o_t]]  (graph.py:79-84) */
 int sg_gather_concat_fwd(const float* obj, const float* pred, const int64_t* edges, float* out,
                          int T, int Do, int Dp, sgStream stream);
+/* y[t] = act([obj[s_t], pred[t], obj[o_t]] W^T + b): the gather of graph.py:79-84 and the first nn.Linear (+ReLU) of net1
+ * (graph.py:58-60,86) in ONE launch -- the A loader of the register-streaming GEMM reads the node / edge feature rows directly,
+ * the (T, 2 Do + Dp) matrix is never written.  W: [out_f][2 Do + Dp].  Graphs too large for that kernel (the same size rule
+ * as sg_linear_fwd) take gather + GEMM through ws (sg_gconv_gather_linear_ws_bytes: 0 for the fused form). */
+size_t sg_gconv_gather_linear_ws_bytes(int T, int Do, int Dp, int out_f);
+int sg_gconv_gather_linear_fwd(const float* obj, const float* pred, const int64_t* edges, const float* w, const float* b,
+                               float* y, int T, int Do, int Dp, int out_f, int act, float slope, void* ws, size_t ws_bytes,
+                               sgStream stream);
 /* dst[i, :] = (sum over CSR entries e of row i of src[t_e, col_off[pass_e] : +width]) / (avg ? max(deg_i,1) : 1)
  * forward pool: src=new_t, col_off={0, H+Dout}; gather backward: src=g_cur_t, col_off={0, Do+Dp}. Bit-exact
  * w.r.t. sequential CPU scatter_add (deterministic, no atomics). */

@@ -64,6 +64,7 @@ enum SgOpt {
   SG_OPT_LAST_BLOCK,      // two-stage reductions finished by the last workgroup to arrive (one launch) instead of a second kernel
   SG_OPT_WINO_GEMM_TILE,  // tile of the K-contiguous batched Winograd GEMMs: 0 = 128x128, 1 = 64x128, 2 = 64x64
   SG_OPT_WINO43,          // Winograd F(4x4,3x3) for the small-plane reflection-padded ResnetBlock convs (0: F(2x2,3x3))
+  SG_OPT_GCONV_FUSED_GATHER, // GraphTripleConv: the (s, p, o) row gather inside the first MLP layer's A loader (0: materialise cur_t)
   SG_OPT_COUNT
 };
 extern std::atomic<int> g_sg_opt[SG_OPT_COUNT];

@@ -89,23 +89,35 @@ __global__ void __launch_bounds__(256) csr_build_kernel(const int64_t* __restric
     __syncthreads();
   }
   if (tid == 0) off[O] = carry_s;
-  // stable placement
+  // stable placement, 256 entries per round in (pass, t) order.  Rank of an entry among the round's earlier entries with the same
+  // destination: inside its wave from ballots (the wave walks its DISTINCT destinations: one ballot + popcount each, instead of
+  // every thread scanning 255 LDS slots), across the round's four waves by letting them place one after the other, each
+  // advancing the nodes' LDS cursors behind it.
+  const int lane = tid & 63, wv = tid >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
   for (int base = 0; base < 2 * T; base += 256) {
     const int e = base + tid;
     const bool live = e < 2 * T;
     const int pass = live && e >= T, t = live ? e - pass * T : 0;
     const int d = live ? (int)edges[2 * t + pass] : -1;
-    dch[tid] = d;
-    __syncthreads();
-    int before = 0, after = 0;
-    if (live) {
-      for (int j = 0; j < tid; ++j) before += dch[j] == d;
-      for (int j = tid + 1; j < 256; ++j) after += dch[j] == d;
-      ent[cur[d] + before] = t | (pass << PASS_SHIFT);
+    int rank = 0, cnt = 0;
+    unsigned long long todo = __ballot(live);
+    while (todo) {                                           // wave-uniform loop over the distinct destinations of the wave
+      const int src = __ffsll((long long)todo) - 1;
+      const int d0 = __shfl(d, src, 64);
+      const unsigned long long same = __ballot(live && d == d0);
+      if (d == d0) { rank = __popcll(same & below); cnt = __popcll(same); }
+      todo &= ~same;
     }
-    __syncthreads();
-    if (live && after == 0) cur[d] += before + 1;            // the chunk's last entry of this node advances its cursor
-    __syncthreads();
+    for (int w = 0; w < 4; ++w) {
+      if (wv == w && live) {
+        const int at = cur[d] + rank;
+        ent[at] = t | (pass << PASS_SHIFT);
+      }
+      __syncthreads();
+      if (wv == w && live && rank == cnt - 1) cur[d] += cnt;  // the wave's last entry of this node advances its cursor
+      __syncthreads();
+    }
   }
 }
 
@@ -127,9 +139,51 @@ __global__ void gather_concat_kernel(const float* __restrict__ obj, const float*
   }
 }
 
+// One workgroup per node.  The node's entry list (row index | pass bit) is staged in LDS once, 1024 entries at a time, by all threads --
+// the old loop made every column thread walk  ent[e] -> address -> src[...]  as a chain of dependent loads, one round trip per
+// entry and level -- and the source values of eight entries are in flight before the first add.  Same adds, same order.
+constexpr int SEG_CAP = 1024;
 __global__ void segment_sum_kernel(const float* __restrict__ src, int src_ld, int col0, int col1, int width,
                                    const int32_t* __restrict__ off, const int32_t* __restrict__ ent,
                                    float* __restrict__ dst, int avg) {
+  __shared__ unsigned rowoff[SEG_CAP];            // element offset of (row t, column block) of every staged entry
+  const int i = blockIdx.x;
+  const int beg = off[i], end = off[i + 1];
+  const float denom = (float)(end - beg > 1 ? end - beg : 1);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};            // columns threadIdx.x + {0, 1, 2, 3} * blockDim.x (width <= 4 * blockDim.x)
+  const int ncol = (width + (int)blockDim.x - 1) / (int)blockDim.x;
+  for (int e0 = beg; e0 < end; e0 += SEG_CAP) {
+    const int n = end - e0 < SEG_CAP ? end - e0 : SEG_CAP;
+    __syncthreads();
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      const int v = ent[e0 + j];
+      rowoff[j] = (unsigned)(v & ((1 << PASS_SHIFT) - 1)) * (unsigned)src_ld + (unsigned)((v >> PASS_SHIFT) ? col1 : col0);
+    }
+    __syncthreads();
+    for (int q = 0; q < ncol && q < 4; ++q) {
+      const int c = threadIdx.x + q * (int)blockDim.x;
+      if (c >= width) break;
+      float a = acc[q];
+      for (int j0 = 0; j0 < n; j0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = src[(size_t)rowoff[j0 + u < n ? j0 + u : n - 1] + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (j0 + u < n) a += t[u];                // sequential fp32 adds, fixed (pass, t) order
+      }
+      acc[q] = a;
+    }
+  }
+  for (int q = 0; q < ncol && q < 4; ++q) {
+    const int c = threadIdx.x + q * (int)blockDim.x;
+    if (c < width) dst[(size_t)i * width + c] = avg ? acc[q] / denom : acc[q];
+  }
+}
+// (more than 4 column blocks per thread: the plain loop)
+__global__ void segment_sum_wide_kernel(const float* __restrict__ src, int src_ld, int col0, int col1, int width,
+                                        const int32_t* __restrict__ off, const int32_t* __restrict__ ent,
+                                        float* __restrict__ dst, int avg) {
   const int i = blockIdx.x;
   const int beg = off[i], end = off[i + 1];
   const float denom = (float)(end - beg > 1 ? end - beg : 1);
@@ -298,13 +352,48 @@ extern "C" int sg_gather_concat_fwd(const float* obj, const float* pred, const i
   return 0;
 }
 
+namespace sgk {
+int skinny_gemm_gather(const float* obj, const float* pred, const int64_t* edges, int T, int Do, int Dp, const float* w, float* c,
+                       const float* bias, int N, int act, float slope, hipStream_t s);
+}
+static bool gconv_fused_shape(int T, int out_f) {
+  return (long)sg_cdiv(T, 32) * sg_cdiv(out_f, 32) <= (long)sg_opt(SG_OPT_LINEAR_SKINNY) && sg_opt(SG_OPT_GCONV_FUSED_GATHER) != 0;
+}
+extern "C" size_t sg_gconv_gather_linear_ws_bytes(int T, int Do, int Dp, int out_f) {
+  return gconv_fused_shape(T, out_f) ? 0 : (size_t)(T > 0 ? T : 1) * (2 * Do + Dp) * sizeof(float);
+}
+extern "C" int sg_gconv_gather_linear_fwd(const float* obj, const float* pred, const int64_t* edges, const float* w, const float* b,
+                                          float* y, int T, int Do, int Dp, int out_f, int act, float slope, void* ws,
+                                          size_t ws_bytes, sgStream stream) {
+  SG_ARG_CHECK(obj && pred && edges && w && y && T >= 0 && Do > 0 && Dp > 0 && out_f > 0, "sg_gconv_gather_linear_fwd: bad arguments");
+  if (T == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int K = 2 * Do + Dp;
+  if (gconv_fused_shape(T, out_f)) {
+    SgProfScope prof(SG_K_LINEAR, s, 2.0 * T * (double)K * out_f, 0);
+    sgk::skinny_gemm_gather(obj, pred, edges, T, Do, Dp, w, y, b, out_f, act, slope, s);
+    SG_LAUNCH_CHECK("sg_gconv_gather_linear_fwd");
+    return 0;
+  }
+  // large graphs (more 32x32 output tiles than the register-streaming kernel takes): materialise the rows, LDS-tiled GEMM
+  SG_ARG_CHECK(ws && ws_bytes >= (size_t)T * K * sizeof(float), "sg_gconv_gather_linear_fwd: workspace too small");
+  if (const int rc = sg_gather_concat_fwd(obj, pred, edges, (float*)ws, T, Do, Dp, stream)) return rc;
+  return sg_linear_fwd((const float*)ws, w, b, y, T, K, out_f, act, slope, stream);
+}
+
 extern "C" int sg_segment_sum(const float* src, int src_ld, int col_off0, int col_off1, int width, const int32_t* csr_off,
                               const int32_t* csr_ent, float* dst, int O, int avg, sgStream stream) {
   SG_ARG_CHECK(src && csr_off && csr_ent && dst && O > 0 && width > 0, "sg_segment_sum: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   SgProfScope prof(SG_K_SEGSUM, s, 0, 0);
-  hipLaunchKernelGGL(segment_sum_kernel, dim3(O), dim3(row_threads(width)), 0, s, src, src_ld, col_off0, col_off1, width,
-                     csr_off, csr_ent, dst, avg);
+  const int threads = row_threads(width);
+  // (32-bit element offsets in the staged form: the operand limit of the library, 2^29 elements, holds for src)
+  if (width <= 4 * threads)
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(O), dim3(threads), 0, s, src, src_ld, col_off0, col_off1, width, csr_off, csr_ent,
+                       dst, avg);
+  else
+    hipLaunchKernelGGL(segment_sum_wide_kernel, dim3(O), dim3(threads), 0, s, src, src_ld, col_off0, col_off1, width, csr_off,
+                       csr_ent, dst, avg);
   SG_LAUNCH_CHECK("sg_segment_sum");
   return 0;
 }

@@ -64,6 +64,8 @@ int nk_run(int KS, const float* A, int M, int Mtot, const Gather& g, int NB, flo
 // rowsum (optional): [M] row sums of A over k, written by the workgroups of the first column tile
 int skinny_gemm(const float* a, int lda, int a_kcontig, const float* b, int ldb, int b_kcontig, float* c, const float* bias,
                 float* rowsum, int M, int N, int K, int act, float slope, hipStream_t s);
+int skinny_gemm_gather(const float* obj, const float* pred, const int64_t* edges, int T, int Do, int Dp, const float* w, float* c,
+                       const float* bias, int N, int act, float slope, hipStream_t s);
 inline bool skinny_shape(int M, int N) {
   return (long)sg_cdiv(M, 32) * sg_cdiv(N, 32) <= (long)sg_opt(SG_OPT_LINEAR_SKINNY);
 }

@@ -32,6 +32,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sg_rsrc(const float* p) {
 }
 
 struct SkOperand { const float* p; int ld; int X; };
+struct SkGather;
 
 constexpr unsigned SK_INVALID = 0x80000000u;     // byte offset beyond num_records (2^31): the buffer load returns 0
 
@@ -42,7 +43,7 @@ struct SkLoader {
   unsigned base;        // byte offset of (row, k = 8h) [K-contiguous] or of column x [X-contiguous]; SK_INVALID: row outside
   unsigned ldb;         // X-contiguous: row pitch in bytes
   int K, h;
-  __device__ __forceinline__ void init(const SkOperand& o, int x0, int lane, int Ktot) {
+  __device__ __forceinline__ void init(const SkOperand& o, const SkGather&, int x0, int lane, int Ktot) {
     rsrc = sg_rsrc(o.p);
     const int r = lane & 31;
     h = lane >> 5;
@@ -86,11 +87,77 @@ struct SkLoader {
   }
 };
 
+// A operand of the first per-edge MLP layer of GraphTripleConv (graph.py:79-86): row t of the (T, 2 Do + Dp) matrix
+// [obj[s_t] | pred[t] | obj[o_t]] read straight from the node / edge feature rows -- the concatenated matrix is never written.
+// A lane owns one triple: its subject / object node ids are fetched once (init) and become two row offsets into ``obj``; every
+// 8-value run of the k loop then comes from one of the three rows.  obj and pred are different allocations, i.e. two buffer
+// descriptors: each run issues one load against each with the offset of the OTHER segment set outside the descriptor's range
+// (-> 0) and ORs the bit patterns, so there is no divergent control flow and no per-element address select in 64 bits.
+// VEC = 4: Do, Dp multiples of 4 and 16-byte aligned rows (the 128-dim layers: a 4-run never straddles segments); VEC = 1:
+// anything (the first layer's 163-dim object rows).
+struct SkGather { const float* obj; const float* pred; const int64_t* edges; int Do, Dp, T; };
+template <int VEC>
+struct SkLoaderGather {
+  __amdgpu_buffer_rsrc_t robj, rpred;
+  unsigned b0, b1, b2;      // byte offsets of the rows obj[s], pred[t], obj[o]
+  int K, h, Do, Dp;
+  bool ok;
+  __device__ __forceinline__ void init(const SkOperand&, const SkGather& g, int x0, int lane, int Ktot) {
+    robj = sg_rsrc(g.obj);
+    rpred = sg_rsrc(g.pred);
+    h = lane >> 5;
+    K = Ktot; Do = g.Do; Dp = g.Dp;
+    const int x = x0 + (lane & 31);
+    ok = x < g.T;
+    const long long sidx = ok ? g.edges[2 * (size_t)x] : 0, oidx = ok ? g.edges[2 * (size_t)x + 1] : 0;
+    b0 = (unsigned)sidx * (unsigned)Do * 4u;
+    b1 = (unsigned)x * (unsigned)Dp * 4u;
+    b2 = (unsigned)oidx * (unsigned)Do * 4u;
+  }
+  __device__ __forceinline__ void offsets(int k, unsigned& offo, unsigned& offp) const {
+    const bool in = ok && k < K;
+    const bool seg0 = k < Do, seg1 = !seg0 && k < Do + Dp;
+    offo = (in && !seg1) ? (seg0 ? b0 + 4u * (unsigned)k : b2 + 4u * (unsigned)(k - Do - Dp)) : SK_INVALID;
+    offp = (in && seg1) ? b1 + 4u * (unsigned)(k - Do) : SK_INVALID;
+  }
+  __device__ __forceinline__ void load(float (&v)[8], int c) const {
+    const int kb = 16 * c + 8 * h;
+    if (VEC == 4) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        unsigned offo, offp;
+        offsets(kb + 4 * q, offo, offp);
+        const auto a = __builtin_amdgcn_raw_buffer_load_b128(robj, (int)offo, 0, 0);
+        const auto b = __builtin_amdgcn_raw_buffer_load_b128(rpred, (int)offp, 0, 0);
+        unsigned ua[4], ub[4];
+        __builtin_memcpy(ua, &a, 16);
+        __builtin_memcpy(ub, &b, 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = __builtin_bit_cast(float, ua[e] | ub[e]);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        unsigned offo, offp;
+        offsets(kb + q, offo, offp);
+        const unsigned a = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(robj, (int)offo, 0, 0);
+        const unsigned b = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rpred, (int)offp, 0, 0);
+        v[q] = __builtin_bit_cast(float, a | b);
+      }
+    }
+  }
+};
+// AV: 0 / 1 / 2 / 4 = the plain forms above; 5 / 6 = gathered triple rows, 16-byte / 4-byte loads
+template <int AV> struct SkALoader { using type = SkLoader<AV>; };
+template <> struct SkALoader<5> { using type = SkLoaderGather<4>; };
+template <> struct SkALoader<6> { using type = SkLoaderGather<1>; };
+
 constexpr int SK_ROUND = 4;          // chunks per round: 4 x 16 k per wave in flight per operand (64 VGPRs per operand and buffer)
 
 template <int AV, int BV>
 __global__ void __launch_bounds__(256) skinny_gemm_kernel(SkOperand A, SkOperand B, float* __restrict__ C, const float* __restrict__ bias,
-                                                          float* __restrict__ rowsum, int M, int N, int K, int act, float slope) {
+                                                          float* __restrict__ rowsum, int M, int N, int K, int act, float slope,
+                                                          SkGather GA) {
   __shared__ float part[4][16][64];                   // partial accumulators [wave][register][lane]: 16 KB, conflict-free
   __shared__ float rpart[4][32];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -100,10 +167,10 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(SkOperand A, SkOperand
   const int per = chunks >> 2, extra = chunks & 3;
   const int c_beg = w * per + min(w, extra), c_end = c_beg + per + (w < extra ? 1 : 0);
 
-  SkLoader<AV> la;
+  typename SkALoader<AV>::type la;
   SkLoader<BV> lb;
-  la.init(A, m0, lane, K);
-  lb.init(B, n0, lane, K);
+  la.init(A, GA, m0, lane, K);
+  lb.init(B, GA, n0, lane, K);
 
   f32x16 acc;
 #pragma unroll
@@ -170,13 +237,16 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(SkOperand A, SkOperand
 
 template <int AV>
 void launch_b(int bv, const SkOperand& A, const SkOperand& B, float* C, const float* bias, float* rowsum, int M, int N, int K,
-              int act, float slope, hipStream_t s) {
+              int act, float slope, hipStream_t s, const SkGather& G = SkGather{nullptr, nullptr, nullptr, 0, 0, 0}) {
   const dim3 grid(sg_cdiv(N, 32), sg_cdiv(M, 32));
   switch (bv) {
-    case 4: hipLaunchKernelGGL((skinny_gemm_kernel<AV, 4>), grid, dim3(256), 0, s, A, B, C, bias, rowsum, M, N, K, act, slope); break;
-    case 2: hipLaunchKernelGGL((skinny_gemm_kernel<AV, 2>), grid, dim3(256), 0, s, A, B, C, bias, rowsum, M, N, K, act, slope); break;
-    case 1: hipLaunchKernelGGL((skinny_gemm_kernel<AV, 1>), grid, dim3(256), 0, s, A, B, C, bias, rowsum, M, N, K, act, slope); break;
-    default: hipLaunchKernelGGL((skinny_gemm_kernel<AV, 0>), grid, dim3(256), 0, s, A, B, C, bias, rowsum, M, N, K, act, slope); break;
+    case 4: hipLaunchKernelGGL((skinny_gemm_kernel<AV, 4>), grid, dim3(256), 0, s, A, B, C, bias, rowsum, M, N, K, act, slope, G); break;
+    case 2: hipLaunchKernelGGL((skinny_gemm_kernel<AV, 2>), grid, dim3(256), 0, s, A, B, C, bias, rowsum, M, N, K, act, slope, G); break;
+    case 1: hipLaunchKernelGGL((skinny_gemm_kernel<AV, 1>), grid, dim3(256), 0, s, A, B, C, bias, rowsum, M, N, K, act, slope, G); break;
+    default:
+      if constexpr (AV < 5)      // (the gathered forms only pair with K-contiguous weights)
+        hipLaunchKernelGGL((skinny_gemm_kernel<AV, 0>), grid, dim3(256), 0, s, A, B, C, bias, rowsum, M, N, K, act, slope, G);
+      break;
   }
 }
 
@@ -201,6 +271,19 @@ int skinny_gemm(const float* a, int lda, int a_kcontig, const float* b, int ldb,
     case 1: launch_b<1>(bv, A, B, c, bias, rowsum, M, N, K, act, slope, s); break;
     default: launch_b<0>(bv, A, B, c, bias, rowsum, M, N, K, act, slope, s); break;
   }
+  return 0;
+}
+// y[T][N] = act([obj[s_t] | pred[t] | obj[o_t]] W^T + bias): the first per-edge MLP layer of GraphTripleConv with the row
+// gather in the A loader (W: [N][2 Do + Dp], K-contiguous)
+int skinny_gemm_gather(const float* obj, const float* pred, const int64_t* edges, int T, int Do, int Dp, const float* w, float* c,
+                       const float* bias, int N, int act, float slope, hipStream_t s) {
+  const int K = 2 * Do + Dp;
+  const SkOperand A{nullptr, K, T}, B{w, K, N};
+  const SkGather G{obj, pred, edges, Do, Dp, T};
+  const bool v4 = Do % 4 == 0 && Dp % 4 == 0 && (reinterpret_cast<uintptr_t>(obj) % 16 == 0) && (reinterpret_cast<uintptr_t>(pred) % 16 == 0);
+  const int bv = vec_of(w, K, K);
+  if (v4) launch_b<5>(bv, A, B, c, bias, nullptr, T, N, K, act, slope, s, G);
+  else launch_b<6>(bv, A, B, c, bias, nullptr, T, N, K, act, slope, s, G);
   return 0;
 }
 }  // namespace sgk

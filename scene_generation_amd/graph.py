@@ -13,7 +13,7 @@ than the separate launches, 3.0 vs 1.8 ms per step; it was removed in round 4 wh
 import torch.nn as nn
 
 from . import ops
-from .layers import build_mlp, Linear
+from .layers import build_mlp, Linear, _peek_act
 
 
 def _init_weights(module):
@@ -46,8 +46,15 @@ class GraphTripleConv(nn.Module):
         edges = edges if edges.is_contiguous() else edges.contiguous()
         off, ent = csr if csr is not None else ops.build_csr(edges, O)
         pred_vecs = pred_vecs if pred_vecs.is_contiguous() else pred_vecs.contiguous()
-        cur_t = ops.GatherConcatFn.apply(obj_vecs, pred_vecs, edges, off, ent)
-        new_t = self.net1(cur_t)
+        mods = list(self.net1)
+        if isinstance(mods[0], Linear) and (len(mods) < 2 or not isinstance(mods[1], nn.modules.batchnorm._BatchNorm)):
+            # the (s, p, o) row gather runs inside the A loader of net1's first GEMM: [obj[s] | pred | obj[o]] is never written
+            act, slope, used = _peek_act(mods, 1)
+            h = ops.gather_linear(obj_vecs, pred_vecs, edges, off, ent, mods[0].weight, mods[0].bias, act, slope)
+            new_t = self.net1(h, start=1 + used)
+        else:
+            cur_t = ops.GatherConcatFn.apply(obj_vecs, pred_vecs, edges, off, ent)
+            new_t = self.net1(cur_t)
         pooled, new_p = ops.TriplePoolFn.apply(new_t, edges, off, ent, O, H, Dout, self.pooling == 'avg')
         return self.net2(pooled), new_p
 

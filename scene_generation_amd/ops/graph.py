@@ -5,7 +5,7 @@ import torch
 from torch.autograd import Function
 
 from . import _core
-from ._core import (GradOut, _call, _f32, _i64, _p, _stream, _wants_grad)
+from ._core import (ACT_NONE, GradOut, _L, _call, _f32, _i64, _p, _stream, _wants_grad, workspace)
 
 
 # =============================================================================================
@@ -57,6 +57,77 @@ class GatherConcatFn(Function):
             g_pred = torch.empty(T, Dp, dtype=torch.float32, device=g.device)
             _call('sg_copy_cols', _p(g), 2 * Do + Dp, Do, _p(g_pred), Dp, 0, T, Dp, s)
         return g_obj, g_pred, None, None, None
+
+
+class GatherLinearFn(Function):
+    """act([obj[s], pred, obj[o]] W^T + b): the row gather of graph.py:79-84 and the first Linear (+ReLU) of net1 (graph.py:58-60,86)
+    as ONE launch -- the A loader of the register-streaming GEMM reads the node / edge feature rows, the (T, 2 Do + Dp) matrix is
+    never written in the forward (sg_gconv_gather_linear_fwd).  The backward materialises the rows once for the weight gradient
+    (they are the GEMM's second operand there) and scatters the data gradient with the deterministic segmented sums of
+    GatherConcatFn."""
+
+    @staticmethod
+    def forward(ctx, obj, pred, edges, off, ent, weight, bias, act, slope):
+        obj, pred, weight = _f32(obj), _f32(pred), _f32(weight, 'linear weight')
+        T, Do, Dp = edges.size(0), obj.size(1), pred.size(1)
+        out_f = weight.size(0)
+        assert weight.size(1) == 2 * Do + Dp
+        _core.check_indices(edges, 0, obj.size(0), 'edges (subject / object node ids)')      # graph.py:79-80
+        y = torch.empty(T, out_f, dtype=torch.float32, device=obj.device)
+        wsb = _L().sg_gconv_gather_linear_ws_bytes(T, Do, Dp, out_f)
+        ws = workspace(wsb, obj.device) if wsb else None
+        _call('sg_gconv_gather_linear_fwd', _p(obj), _p(pred), _p(edges), _p(weight), _p(bias), _p(y), T, Do, Dp, out_f, act,
+              slope, _p(ws), wsb, _stream())
+        ctx.cfg = (act, slope, bias is not None, obj.size(0), T, Do, Dp, out_f)
+        ctx.bias_ref = bias
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(obj, pred, edges, off, ent, weight, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if gy is None:
+            return (None,) * 9
+        obj, pred, edges, off, ent, weight, y = ctx.saved_tensors
+        act, slope, has_bias, O, T, Do, Dp, out_f = ctx.cfg
+        K = 2 * Do + Dp
+        gy = _f32(gy)
+        s = _stream()
+        dev = gy.device
+        if T == 0:
+            return (torch.zeros_like(obj), torch.zeros_like(pred), None, None, None, torch.zeros_like(weight),
+                    torch.zeros(out_f, device=dev) if has_bias else None, None, None)
+        if act != ACT_NONE:
+            g2 = torch.empty_like(gy)
+            _call('sg_act_bwd', _p(y), _p(gy), _p(g2), gy.numel(), act, slope, s)
+            gy = g2
+        need_w = ctx.needs_input_grad[5] and _wants_grad(weight)
+        need_b = has_bias and ctx.needs_input_grad[6] and _wants_grad(ctx.bias_ref)
+        ow = GradOut(weight) if need_w else None
+        ob = GradOut(ctx.bias_ref) if need_b else None
+        if need_w:
+            cur_t = torch.empty(T, K, dtype=torch.float32, device=dev)
+            _call('sg_gather_concat_fwd', _p(obj), _p(pred), _p(edges), _p(cur_t), T, Do, Dp, s)
+            _call('sg_linear_bwd_weight', _p(gy), _p(cur_t), _p(ow.buf), _p(ob.buf) if need_b else None, T, K, out_f, s)
+        elif need_b:
+            _call('sg_channel_sum', _p(gy), _p(ob.buf), T, out_f, 1, None, 0, s)
+        g_obj = g_pred = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            g = torch.empty(T, K, dtype=torch.float32, device=dev)
+            _call('sg_linear_bwd_data', _p(gy), _p(weight), _p(g), T, K, out_f, s)
+            if ctx.needs_input_grad[0]:
+                g_obj = torch.empty(O, Do, dtype=torch.float32, device=dev)
+                _call('sg_segment_sum', _p(g), K, 0, Do + Dp, Do, _p(off), _p(ent), _p(g_obj), O, 0, s)
+            if ctx.needs_input_grad[1]:
+                g_pred = torch.empty(T, Dp, dtype=torch.float32, device=dev)
+                _call('sg_copy_cols', _p(g), K, Do, _p(g_pred), Dp, 0, T, Dp, s)
+        gw = ow.finish() if need_w else None
+        gb = ob.finish() if need_b else None
+        return g_obj, g_pred, None, None, None, gw, gb, None, None
+
+
+def gather_linear(obj, pred, edges, off, ent, weight, bias, act=ACT_NONE, slope=0.0):
+    return GatherLinearFn.apply(obj, pred, edges, off, ent, weight, bias, act, float(slope))
 
 
 class TriplePoolFn(Function):
