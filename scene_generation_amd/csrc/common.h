@@ -61,10 +61,13 @@ enum SgOpt {
   SG_OPT_WINO_FOLD_CELLS, // four-wave cell-gather form of the adjoint Winograd output fold (0: one thread per channel walks the tiles)
   SG_OPT_WINO_PIPE,       // main loop of the dense Winograd GEMMs: 1 = stores at the top of the iteration, 2 = interleaved with phase 0
   SG_OPT_CHECK_INDICES,   // debugging: range-check index operands on the device (one stream synchronisation per check); sg_check_indices
-  SG_OPT_LAST_BLOCK,      // two-stage reductions finished by the last workgroup to arrive (one launch) instead of a second kernel
+  SG_OPT_LAST_BLOCK,      // two-stage reductions finished by the last workgroup to arrive (one launch) instead of a second kernel;
+                          // OFF by default: measured on MI355X (profiles/r05_ab_sessions.md) the ticket + write-through hand-off in
+                          // thousands of short workgroups costs more than the 4-6 us final kernels it removes (35.04 vs 34.94 ms)
   SG_OPT_WINO_GEMM_TILE,  // tile of the K-contiguous batched Winograd GEMMs: 0 = 128x128, 1 = 64x128, 2 = 64x64
   SG_OPT_WINO43,          // Winograd F(4x4,3x3) for the small-plane reflection-padded ResnetBlock convs (0: F(2x2,3x3))
   SG_OPT_GCONV_FUSED_GATHER, // GraphTripleConv: the (s, p, o) row gather inside the first MLP layer's A loader (0: materialise cur_t)
+  SG_OPT_W24_GEMM_TILE,   // tile of the F(2x2,4x4) GEMMs (K = 256 / 512): 2 = 64x64 (measured 2.03 vs 2.14 ms/step on 128x128), 0, 1
   SG_OPT_COUNT
 };
 extern std::atomic<int> g_sg_opt[SG_OPT_COUNT];

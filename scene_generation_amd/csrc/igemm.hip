@@ -870,7 +870,7 @@ void wino_bgemm_tile(int tile, const float* A, const float* B, float* Cout, int 
 // C[m][b*cols + j] = sum_k A[b][m][k] * B[b*cols + j][k]   (NB batches -- 16 for F(2x2,3x3), 25 (x k-chunks) for F(2x2,4x4) --,
 // everything a multiple of the tile)
 void wino_bgemm(const float* A, const float* B, float* Cout, int M, int cols, int K, double flops, hipStream_t s, int NB = 16) {
-  const int tsel = sg_opt(SG_OPT_WINO_GEMM_TILE);
+  const int tsel = NB == 16 ? sg_opt(SG_OPT_WINO_GEMM_TILE) : sg_opt(SG_OPT_W24_GEMM_TILE);
   if ((tsel == 1 || tsel == 2) && M % 64 == 0 && cols % 128 == 0 && K % 32 == 0) {
     wino_bgemm_tile(tsel, A, B, Cout, M, cols, K, flops, s, NB, NB == 16 ? SG_K_WINO_GEMM_128 : SG_K_WINO24_GEMM);
     return;

@@ -186,13 +186,28 @@ def test_conv2d(hip, case):
         yr = F.conv2d(F.pad(xin, (pad,) * 4, mode='reflect'), rw, rb, stride=stride)
     else:
         yr = F.conv2d(xin, rw, rb, stride=stride, padding=pad)
-    yr = {0: lambda t: t, 1: F.relu, 2: lambda t: F.leaky_relu(t, 0.2), 3: torch.tanh}[act](yr)
+    ypre = yr
+    yr = {0: lambda t: t, 1: F.relu, 2: lambda t: F.leaky_relu(t, 0.2), 3: torch.tanh}[act](ypre)
     gy = det(tuple(yr.shape), 15)
-    yr.backward(gy)
     g1, gw, gb = [t.to(DEV).requires_grad_() for t in (x1, w, b)]
     g2 = x2.to(DEV).requires_grad_() if C2 else None
     yg = hip.conv2d(g1, gw, gb, stride=stride, pad=pad, reflect=reflect, upsample=ups, act=act, slope=0.2, x2=g2)
     yg.backward(gy.to(DEV))
+    if act in (1, 2):
+        # (Leaky)ReLU: a unit whose pre-activation is within rounding error of 0 may sit on the other side of the kink in two
+        # correct fp32 implementations, and ONE such unit moves a gradient entry by |w gy| ~ 0.1 (seen with Winograd F(4x4,3x3),
+        # whose forward error is ~1e-5 of the scale: a few of 262 144 units flip).  The reference backward therefore uses the
+        # derivative mask of the GPU result -- after checking that every unit the two masks disagree on IS within the forward
+        # tolerance of 0.
+        lo = 0.0 if act == 1 else 0.2
+        dg = torch.where(yg.detach().cpu() > 0, torch.tensor(1.0), torch.tensor(lo))
+        dr = torch.where(ypre.detach() > 0, torch.tensor(1.0), torch.tensor(lo))
+        flipped = dg != dr
+        assert float(ypre.detach()[flipped].abs().max() if flipped.any() else 0.0) <= 3e-5 * max(1.0, float(yr.detach().abs().max()))
+        assert int(flipped.sum()) <= 1e-4 * flipped.numel() + 2
+        ypre.backward(gy * dg)
+    else:
+        yr.backward(gy)
     close(yg, yr, 3e-5, 'y')
     close(g1.grad, r1.grad, 5e-5, 'gx1')
     if C2:
