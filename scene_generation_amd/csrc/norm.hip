@@ -176,9 +176,126 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) instnorm_bwd_reg_kernel(con
   }
 }
 
+// ---------------- InstanceNorm, large planes (beyond the register budget of 1024 threads: 256 x 256 at configs[3]) ---------------
+// One workgroup of 1024 threads per plane, float4 streams with four loads in flight per thread; the plane (256 KB at 256^2, plus
+// gy in the backward) stays in the XCD's L2 between the passes, so the extra passes are L2 reads.  The register kernels above
+// would need 64 (forward) / 2 x 64 (backward) values per thread there: their <1024, 64> / <1024, 32> instantiations spilled to
+// scratch (round 4: 156 / 72 / 876 B), and the backward fell to the one-load-at-a-time loop (2 x 288 us per step at configs[3]).
+__global__ void __launch_bounds__(1024) instnorm_fwd_big_kernel(const float* __restrict__ x, const float* __restrict__ skip,
+                                                               float* __restrict__ y, float* __restrict__ mean_o,
+                                                               float* __restrict__ rstd_o, int HW, float eps, int act, float slope) {
+  __shared__ float red[16];
+  const int plane = blockIdx.x, n4 = HW >> 2, tid = threadIdx.x;
+  const float4* xp = reinterpret_cast<const float4*>(x + (size_t)plane * HW);
+  float s = 0.f;
+  for (int i0 = tid; i0 < n4; i0 += 4096) {
+    float4 v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = i0 + e * 1024 < n4 ? xp[i0 + e * 1024] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s += (v[e].x + v[e].y) + (v[e].z + v[e].w);
+  }
+  s = sg_block_sum(s, red);
+  const float mean = s / (float)HW;
+  float q = 0.f;
+  for (int i0 = tid; i0 < n4; i0 += 4096) {
+    float4 v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = i0 + e * 1024 < n4 ? xp[i0 + e * 1024] : make_float4(mean, mean, mean, mean);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = v[e].x - mean, b = v[e].y - mean, c = v[e].z - mean, d = v[e].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  q = sg_block_sum(q, red);
+  const float rstd = 1.f / sqrtf(q / (float)HW + eps);
+  if (tid == 0) { mean_o[plane] = mean; rstd_o[plane] = rstd; }
+  float4* yp = reinterpret_cast<float4*>(y + (size_t)plane * HW);
+  const float4* sp = skip ? reinterpret_cast<const float4*>(skip + (size_t)plane * HW) : nullptr;
+  for (int i0 = tid; i0 < n4; i0 += 4096) {
+    float4 v[4], k[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool ok = i0 + e * 1024 < n4;
+      v[e] = ok ? xp[i0 + e * 1024] : make_float4(0.f, 0.f, 0.f, 0.f);
+      k[e] = (ok && sp) ? sp[i0 + e * 1024] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (i0 + e * 1024 >= n4) continue;
+      float4 o;
+      o.x = sg_apply_act((v[e].x - mean) * rstd, act, slope) + k[e].x;
+      o.y = sg_apply_act((v[e].y - mean) * rstd, act, slope) + k[e].y;
+      o.z = sg_apply_act((v[e].z - mean) * rstd, act, slope) + k[e].z;
+      o.w = sg_apply_act((v[e].w - mean) * rstd, act, slope) + k[e].w;
+      yp[i0 + e * 1024] = o;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(1024) instnorm_bwd_big_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                               const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                               float* __restrict__ gx, int HW, int act, float slope) {
+  __shared__ float red[16];
+  const int plane = blockIdx.x, n4 = HW >> 2, tid = threadIdx.x;
+  const float4* xp = reinterpret_cast<const float4*>(x + (size_t)plane * HW);
+  const float4* gp = reinterpret_cast<const float4*>(gy + (size_t)plane * HW);
+  const float mean = mean_i[plane], rstd = rstd_i[plane];
+  float s1 = 0.f, s2 = 0.f;
+  for (int i0 = tid; i0 < n4; i0 += 2048) {
+    float4 xv[2], gv[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const bool ok = i0 + e * 1024 < n4;
+      xv[e] = ok ? xp[i0 + e * 1024] : make_float4(mean, mean, mean, mean);
+      gv[e] = ok ? gp[i0 + e * 1024] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float zx = (xv[e].x - mean) * rstd, zy = (xv[e].y - mean) * rstd, zz = (xv[e].z - mean) * rstd, zw = (xv[e].w - mean) * rstd;
+      const float a = gv[e].x * act_grad_from_pre(zx, act, slope), b = gv[e].y * act_grad_from_pre(zy, act, slope);
+      const float c = gv[e].z * act_grad_from_pre(zz, act, slope), d = gv[e].w * act_grad_from_pre(zw, act, slope);
+      s1 += (a + b) + (c + d);
+      s2 += (a * zx + b * zy) + (c * zz + d * zw);
+    }
+  }
+  s1 = sg_block_sum(s1, red);
+  s2 = sg_block_sum(s2, red);
+  const float inv = 1.f / (float)HW;
+  const float m1 = s1 * inv, m2 = s2 * inv;
+  float4* op = reinterpret_cast<float4*>(gx + (size_t)plane * HW);
+  for (int i0 = tid; i0 < n4; i0 += 2048) {
+    float4 xv[2], gv[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const bool ok = i0 + e * 1024 < n4;
+      xv[e] = ok ? xp[i0 + e * 1024] : make_float4(mean, mean, mean, mean);
+      gv[e] = ok ? gp[i0 + e * 1024] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (i0 + e * 1024 >= n4) continue;
+      const float zx = (xv[e].x - mean) * rstd, zy = (xv[e].y - mean) * rstd, zz = (xv[e].z - mean) * rstd, zw = (xv[e].w - mean) * rstd;
+      float4 o;
+      o.x = rstd * (gv[e].x * act_grad_from_pre(zx, act, slope) - m1 - zx * m2);
+      o.y = rstd * (gv[e].y * act_grad_from_pre(zy, act, slope) - m1 - zy * m2);
+      o.z = rstd * (gv[e].z * act_grad_from_pre(zz, act, slope) - m1 - zz * m2);
+      o.w = rstd * (gv[e].w * act_grad_from_pre(zw, act, slope) - m1 - zw * m2);
+      op[i0 + e * 1024] = o;
+    }
+  }
+}
+inline bool instnorm_big_ok(int HW, const void* a, const void* b, const void* c, const void* d) {
+  const uintptr_t u = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+                      reinterpret_cast<uintptr_t>(d);
+  return HW % 4 == 0 && HW >= 4096 && (u & 15) == 0;
+}
+
 // (G, E) for a plane of HW elements, or G = 0 when it does not fit 64 registers per thread
 inline void instnorm_shape(int HW, int maxE, int& G, int& E) {
-  G = HW <= 64 ? 16 : (HW <= 1024 ? 64 : (HW <= 256 * maxE ? 256 : (HW <= 1024 * maxE ? 1024 : 0)));
+  // (a workgroup of 1024 threads has 128 registers per thread: half the values per thread of the smaller groups, or it spills)
+  G = HW <= 64 ? 16 : (HW <= 1024 ? 64 : (HW <= 256 * maxE ? 256 : (HW <= 1024 * (maxE / 2) ? 1024 : 0)));
   if (G == 0) { E = 0; return; }
   const int e = (HW + G - 1) / G;
   E = e <= 1 ? 1 : (e <= 2 ? 2 : (e <= 4 ? 4 : (e <= 8 ? 8 : (e <= 16 ? 16 : (e <= 32 ? 32 : 64)))));
@@ -196,12 +313,22 @@ inline void instnorm_shape(int HW, int maxE, int& G, int& E) {
     case 32: SG_IN_CASE(KERNEL, Gv, 32, __VA_ARGS__); break;             \
     default: SG_IN_CASE(KERNEL, Gv, 64, __VA_ARGS__); break;             \
   }
-#define SG_IN_DISPATCH(KERNEL, ...)                                       \
+// (1024-thread groups: only the instantiations that fit 128 registers per thread exist -- TOP = 32 values forward, 16 backward)
+#define SG_IN_DISPATCH_E1024(KERNEL, TOP, ...)                           \
+  switch (E) {                                                           \
+    case 1: SG_IN_CASE(KERNEL, 1024, 1, __VA_ARGS__); break;             \
+    case 2: SG_IN_CASE(KERNEL, 1024, 2, __VA_ARGS__); break;             \
+    case 4: SG_IN_CASE(KERNEL, 1024, 4, __VA_ARGS__); break;             \
+    case 8: SG_IN_CASE(KERNEL, 1024, 8, __VA_ARGS__); break;             \
+    case 16: SG_IN_CASE(KERNEL, 1024, 16, __VA_ARGS__); break;           \
+    default: SG_IN_CASE(KERNEL, 1024, TOP, __VA_ARGS__); break;          \
+  }
+#define SG_IN_DISPATCH(KERNEL, TOP, ...)                                  \
   switch (G) {                                                            \
     case 16: SG_IN_DISPATCH_E(KERNEL, 16, __VA_ARGS__) break;             \
     case 64: SG_IN_DISPATCH_E(KERNEL, 64, __VA_ARGS__) break;             \
     case 256: SG_IN_DISPATCH_E(KERNEL, 256, __VA_ARGS__) break;           \
-    default: SG_IN_DISPATCH_E(KERNEL, 1024, __VA_ARGS__) break;           \
+    default: SG_IN_DISPATCH_E1024(KERNEL, TOP, __VA_ARGS__) break;        \
   }
 
 // ---------------- BatchNorm2d: one block per channel ---------------------------------------------
@@ -872,7 +999,9 @@ extern "C" int sg_instnorm_fwd(const float* x, const float* skip, float* y, floa
   int G = 0, E = 0;
   instnorm_shape(HW, 64, G, E);
   if (reg && G > 0) {
-    SG_IN_DISPATCH(instnorm_fwd_reg_kernel, x, skip, y, mean, rstd, NC, HW, eps, act, slope)
+    SG_IN_DISPATCH(instnorm_fwd_reg_kernel, 32, x, skip, y, mean, rstd, NC, HW, eps, act, slope)
+  } else if (reg && instnorm_big_ok(HW, x, y, skip, nullptr)) {
+    hipLaunchKernelGGL(instnorm_fwd_big_kernel, dim3(NC), dim3(1024), 0, s, x, skip, y, mean, rstd, HW, eps, act, slope);
   } else if (HW <= 1024) hipLaunchKernelGGL(instnorm_fwd_kernel<true>, dim3(sg_cdiv(NC, 4)), dim3(256), 0, s, x, skip, y, mean, rstd, NC, HW, eps, act, slope);
   else hipLaunchKernelGGL(instnorm_fwd_kernel<false>, dim3(NC), dim3(256), 0, s, x, skip, y, mean, rstd, NC, HW, eps, act, slope);
   SG_LAUNCH_CHECK("sg_instnorm_fwd");
@@ -888,7 +1017,9 @@ extern "C" int sg_instnorm_bwd(const float* x, const float* gy, const float* mea
   int G = 0, E = 0;
   instnorm_shape(HW, 32, G, E);                        // (two register arrays: 2 x 32 values per thread at most)
   if (reg && G > 0) {
-    SG_IN_DISPATCH(instnorm_bwd_reg_kernel, x, gy, mean, rstd, gx, NC, HW, act, slope)
+    SG_IN_DISPATCH(instnorm_bwd_reg_kernel, 16, x, gy, mean, rstd, gx, NC, HW, act, slope)
+  } else if (reg && instnorm_big_ok(HW, x, gy, gx, nullptr)) {
+    hipLaunchKernelGGL(instnorm_bwd_big_kernel, dim3(NC), dim3(1024), 0, s, x, gy, mean, rstd, gx, HW, act, slope);
   } else if (HW <= 1024) hipLaunchKernelGGL(instnorm_bwd_kernel<true>, dim3(sg_cdiv(NC, 4)), dim3(256), 0, s, x, gy, mean, rstd, gx, NC, HW, act, slope);
   else hipLaunchKernelGGL(instnorm_bwd_kernel<false>, dim3(NC), dim3(256), 0, s, x, gy, mean, rstd, gx, NC, HW, act, slope);
   SG_LAUNCH_CHECK("sg_instnorm_bwd");
