@@ -941,6 +941,14 @@ __device__ __forceinline__ constexpr float w43_at(int i, int j) {
                              {0.f, 1.f, -1.f, 0.125f, -8.f, 1.f}};
   return m[i][j];
 }
+// d act(z) / dz from the pre-activation z (the InstanceNorm kernels' convention, norm.hip: act_grad_from_pre)
+__device__ __forceinline__ float act_grad_from_pre_w(float z, int act, float slope) {
+  switch (act) {
+    case SG_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+    case SG_ACT_LEAKY: return z > 0.f ? 1.f : slope;
+    default: return 1.f;                 // (only ReLU / LeakyReLU fuse into a normalisation launch: layers._peek_act)
+  }
+}
 // acc += c * x for a compile-time coefficient: nothing for 0, an add / subtract for +-1
 #define W43_ACC(acc, c, x) do { if ((c) == 1.f) (acc) += (x); else if ((c) == -1.f) (acc) -= (x); else if ((c) != 0.f) (acc) += (c) * (x); } while (0)
 
@@ -1265,6 +1273,161 @@ __global__ void __launch_bounds__(256) w43_fold_kernel(const float* __restrict__
     const int ch = i / HW, px = i - ch * HW;
     const float* sp = stage + ch * (HW + 1) + px;
     *reinterpret_cast<float4*>(dstg + i) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+  }
+}
+
+// ---- F(4x4,3x3) conv + InstanceNorm fused at both ends of the GEMMs (ResnetBlock: conv -> InstanceNorm -> ReLU -> conv ->
+// InstanceNorm -> + x, layers.py:251-270) --------------------------------------------------------------------------------------
+// Forward: the output transform of tile-major GEMM results Mx[p][xi*M + m] (lanes along the channel, like the fold kernel), the
+// bias, and the InstanceNorm of the plane the workgroup's threads hold between them: the conv result is written once (the
+// backward needs it) next to the normalised (+ activation)(+ residual) output -- the separate InstanceNorm launch and its read
+// of the conv result are gone.  TPT tiles per thread (1 at 8x8 planes, 4 at 16x16).
+template <int TPT>
+__global__ void __launch_bounds__(256) w43_output_in_kernel(const float* __restrict__ Mx, const float* __restrict__ bias,
+                                                           const float* __restrict__ skip, float* __restrict__ ypre,
+                                                           float* __restrict__ out, float* __restrict__ mean_o,
+                                                           float* __restrict__ rstd_o, int N, int M, int H, int W, float eps, int act,
+                                                           float slope) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int HW = H * W, TH = H / 4, TW = W / 4, NT = TH * TW, pitch = HW + 1;
+  const int n = blockIdx.y, c0 = blockIdx.x * 64, c = threadIdx.x & 63, g = threadIdx.x >> 6, m = c0 + c;
+  float* sa = lds;                                  // [64][HW + 1]: conv result
+  float* sb = lds + 64 * pitch;                     // [64][HW + 1]: normalised result
+  float* red = lds + 128 * pitch;                   // [4][64]
+  const float b = bias ? bias[m] : 0.f;
+  const size_t ld = (size_t)36 * M;
+  float o[TPT][4][4];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < TPT; ++k) {
+    const int t = g + 4 * k;
+    if (t < NT) {
+      const float* src = Mx + ((size_t)n * NT + t) * ld + m;
+      float q[6][6];
+#pragma unroll
+      for (int i = 0; i < 36; ++i) q[i / 6][i % 6] = src[(size_t)i * M];
+      w43_output_xform(q, o[k]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[k][a][e] += b; s += o[k][a][e]; }
+    }
+  }
+  red[g * 64 + c] = s;
+  __syncthreads();
+  const float mean = (((red[c] + red[64 + c]) + red[128 + c]) + red[192 + c]) / (float)HW;
+  __syncthreads();
+  float qv = 0.f;
+#pragma unroll
+  for (int k = 0; k < TPT; ++k)
+    if (g + 4 * k < NT) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float dlt = o[k][a][e] - mean; qv += dlt * dlt; }
+    }
+  red[g * 64 + c] = qv;
+  __syncthreads();
+  const float rstd = 1.f / sqrtf((((red[c] + red[64 + c]) + red[128 + c]) + red[192 + c]) / (float)HW + eps);
+  if (g == 0) { mean_o[(size_t)n * M + m] = mean; rstd_o[(size_t)n * M + m] = rstd; }
+#pragma unroll
+  for (int k = 0; k < TPT; ++k) {
+    const int t = g + 4 * k;
+    if (t < NT) {
+      const int ti = t / TW, tj = t - ti * TW;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int px = (4 * ti + a) * W + 4 * tj + e;
+          sa[c * pitch + px] = o[k][a][e];
+          sb[c * pitch + px] = sg_apply_act((o[k][a][e] - mean) * rstd, act, slope);
+        }
+    }
+  }
+  __syncthreads();
+  // the 64 planes of the workgroup are one contiguous block of each tensor: coalesced float4 rows
+  const size_t base = ((size_t)n * M + c0) * HW;
+  for (int i = threadIdx.x * 4; i < 64 * HW; i += 1024) {
+    const int ch = i / HW, px = i - ch * HW;
+    const float* pa = sa + ch * pitch + px;
+    const float* pb = sb + ch * pitch + px;
+    *reinterpret_cast<float4*>(ypre + base + i) = make_float4(pa[0], pa[1], pa[2], pa[3]);
+    float4 v = make_float4(pb[0], pb[1], pb[2], pb[3]);
+    if (skip) {
+      const float4 k4 = *reinterpret_cast<const float4*>(skip + base + i);
+      v.x += k4.x; v.y += k4.y; v.z += k4.z; v.w += k4.w;
+    }
+    *reinterpret_cast<float4*>(out + base + i) = v;
+  }
+}
+
+// Backward: InstanceNorm's backward (gout -> the conv's gy, layers.py:296 affine=False) and the gradient transform A gy A^T of
+// that conv in one launch: the planes of gout and of the conv result are staged in LDS, thread (c, g) owns the tiles g, g+4, ...
+// of channel c.  gconv is written too (the bias gradient and a weight gradient without saved operands read it).
+__global__ void __launch_bounds__(256) w43_gy_in_kernel(const float* __restrict__ gout, const float* __restrict__ ypre,
+                                                       const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                       float* __restrict__ gconv, float* __restrict__ Ytp, int N, int M, int H, int W,
+                                                       int act, float slope) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int HW = H * W, pitch = HW + 1, TH = H / 4, TW = W / 4, NT = TH * TW;
+  const int n = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x, c = tid & 63, g = tid >> 6;
+  float* pg = lds;                                  // [64][HW + 1]: gout, then the conv's gy
+  float* px = lds + 64 * pitch;                     // [64][HW + 1]: conv result
+  float* red = lds + 128 * pitch;                   // [2][4][64]
+  const size_t base = ((size_t)n * M + c0) * HW;
+  w43_stage_planes(gout + base, pg, HW, tid);
+  w43_stage_planes(ypre + base, px, HW, tid);
+  __syncthreads();
+  const float mean = mean_i[(size_t)n * M + c0 + c], rstd = rstd_i[(size_t)n * M + c0 + c];
+  float* gc = pg + c * pitch;
+  const float* xc = px + c * pitch;
+  float s1 = 0.f, s2 = 0.f;
+  for (int t = g; t < NT; t += 4) {
+    const int ti = t / TW, tj = t - ti * TW;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int p = (4 * ti + a) * W + 4 * tj + e;
+        const float z = (xc[p] - mean) * rstd;
+        const float gp = gc[p] * act_grad_from_pre_w(z, act, slope);
+        s1 += gp; s2 += gp * z;
+      }
+  }
+  red[g * 64 + c] = s1;
+  red[256 + g * 64 + c] = s2;
+  __syncthreads();
+  const float inv = 1.f / (float)HW;
+  const float m1 = (((red[c] + red[64 + c]) + red[128 + c]) + red[192 + c]) * inv;
+  const float m2 = (((red[256 + c] + red[320 + c]) + red[384 + c]) + red[448 + c]) * inv;
+  const size_t P = (size_t)N * NT;
+  for (int t = g; t < NT; t += 4) {
+    const int ti = t / TW, tj = t - ti * TW;
+    float gt[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int p = (4 * ti + a) * W + 4 * tj + e;
+        const float z = (xc[p] - mean) * rstd;
+        const float gp = gc[p] * act_grad_from_pre_w(z, act, slope);
+        gt[a][e] = rstd * (gp - m1 - z * m2);
+        gc[p] = gt[a][e];                           // (this thread's own cells: no other thread reads them before the barrier)
+      }
+    float yt[6][6];
+    w43_gy_xform(gt, yt);
+    const size_t p = (size_t)n * NT + t;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) Ytp[((size_t)(i * 6 + j) * P + p) * M + c0 + c] = yt[i][j];
+  }
+  __syncthreads();
+  for (int i = tid * 4; i < 64 * HW; i += 1024) {
+    const int ch = i / HW, q = i - ch * HW;
+    const float* sp = pg + ch * pitch + q;
+    *reinterpret_cast<float4*>(gconv + base + i) = make_float4(sp[0], sp[1], sp[2], sp[3]);
   }
 }
 
@@ -1914,6 +2077,89 @@ extern "C" int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const 
   wino_bgemm(Yt, Vp, T, M, C, (int)P, 2.0 * M * (double)C * 16.0 * P, s);
   { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 25.0 * (double)M * C); hipLaunchKernelGGL(wino_wgrad_output_kernel, dim3(sg_cdiv((size_t)M * C, 256)), dim3(256), 0, s, (const float*)T, gw, M, C); }
   SG_LAUNCH_CHECK("sg_conv2d_wino_wgrad");
+  return 0;
+}
+
+// ---- F(4x4,3x3) conv + InstanceNorm (see w43_output_in_kernel / w43_gy_in_kernel) ------------------------------------------------
+extern "C" int sg_conv2d_wino_in_supported(const sgConvDesc* d) {
+  if (!sg_opt(SG_OPT_WINO_IN_FUSE) || !wino43_shape(d)) return 0;
+  const int NT = (d->H / 4) * (d->W / 4);
+  return (NT <= 16 && sg_opt(SG_OPT_WINO_REUSE)) ? 1 : 0;      // <= 4 tiles per thread: planes up to 16x16
+}
+
+extern "C" int sg_conv2d_wino_fwd_instnorm(const sgConvDesc* d, const float* x, const float* w, const float* bias, const float* skip,
+                                           float* ypre, float* out, float* mean, float* rstd, float eps, int act, float slope,
+                                           float* ut_save, float* v_save, void* ws, size_t ws_bytes, sgStream stream) {
+  SG_ARG_CHECK(sg_conv2d_wino_in_supported(d), "sg_conv2d_wino_fwd_instnorm: unsupported desc");
+  SG_ARG_CHECK(x && w && ypre && out && mean && rstd && ws && ws_bytes >= sg_conv2d_wino_ws_bytes(d),
+               "sg_conv2d_wino_fwd_instnorm: bad arguments");
+  SG_ARG_CHECK(aligned16(x) && aligned16(w) && aligned16(ypre) && aligned16(out) && (!skip || aligned16(skip)),
+               "sg_conv2d_wino_fwd_instnorm: operands must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int M = d->Cout, C = d->C1, HW = d->H * d->W, NT = (d->H / 4) * (d->W / 4);
+  const size_t P = (size_t)d->N * NT;
+  float* U_ws = reinterpret_cast<float*>(ws);
+  float* V_ws = U_ws + 36 * (size_t)M * C;
+  float* Mx = V_ws + 36 * P * (size_t)(C > M ? C : M);        // [P][36][M]
+  float* U = ut_save ? ut_save : U_ws;
+  float* V = v_save ? v_save : V_ws;
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 45.0 * (double)M * C);
+    hipLaunchKernelGGL(w43_weight_kernel, dim3((M / 32) * (C / 32)), dim3(256), 0, s, w, U, M, C); }
+  { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * ((double)d->N * C * HW + 36.0 * (double)P * C));
+    const size_t lds = (size_t)64 * (HW + 1) * sizeof(float);
+    w43_lds_attr(&w43_input_kernel, lds);
+    hipLaunchKernelGGL(w43_input_kernel, dim3(C / 64, d->N), dim3(256), lds, s, x, V, d->N, C, d->H, d->W); }
+  // tile-major result Mx[p][xi*M + m] = sum_c V[xi][p][c] U[xi][m][c]: the same GEMM with the operand roles swapped
+  wino_bgemm_tile(2, V, U, Mx, (int)P, M, C, 2.0 * 36.0 * M * (double)P * C, s, 36, SG_K_WINO43_GEMM);
+  { SgProfScope xf(SG_K_INSTNORM, s, 0, 4.0 * (36.0 * (double)P * M + (double)d->N * M * HW * (skip ? 3.0 : 2.0)));
+    const size_t lds = (size_t)(128 * (HW + 1) + 256) * sizeof(float);
+    if (NT <= 4) {
+      w43_lds_attr(&w43_output_in_kernel<1>, lds);
+      hipLaunchKernelGGL(w43_output_in_kernel<1>, dim3(M / 64, d->N), dim3(256), lds, s, (const float*)Mx, bias, skip, ypre, out, mean,
+                         rstd, d->N, M, d->H, d->W, eps, act, slope);
+    } else {
+      w43_lds_attr(&w43_output_in_kernel<4>, lds);
+      hipLaunchKernelGGL(w43_output_in_kernel<4>, dim3(M / 64, d->N), dim3(256), lds, s, (const float*)Mx, bias, skip, ypre, out, mean,
+                         rstd, d->N, M, d->H, d->W, eps, act, slope);
+    } }
+  SG_LAUNCH_CHECK("sg_conv2d_wino_fwd_instnorm");
+  return 0;
+}
+
+extern "C" int sg_conv2d_wino_dgrad_instnorm(const sgConvDesc* d, const float* gout, const float* ypre, const float* mean,
+                                             const float* rstd, int act, float slope, const float* w, float* gconv, float* gx,
+                                             const float* ut_saved, float* ytp_save, void* ws, size_t ws_bytes, sgStream stream) {
+  SG_ARG_CHECK(sg_conv2d_wino_in_supported(d), "sg_conv2d_wino_dgrad_instnorm: unsupported desc");
+  SG_ARG_CHECK(gout && ypre && mean && rstd && w && gconv && ws && ws_bytes >= sg_conv2d_wino_ws_bytes(d),
+               "sg_conv2d_wino_dgrad_instnorm: bad arguments");
+  SG_ARG_CHECK(aligned16(gout) && aligned16(ypre) && aligned16(gconv) && aligned16(w) && (!gx || aligned16(gx)),
+               "sg_conv2d_wino_dgrad_instnorm: operands must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int M = d->C1, K = d->Cout, HW = d->H * d->W;
+  const size_t P = (size_t)d->N * (d->H / 4) * (d->W / 4);
+  float* Uw = reinterpret_cast<float*>(ws);
+  float* Ytp_ws = Uw + 36 * (size_t)M * K;
+  float* G = Ytp_ws + 36 * P * (size_t)(K > M ? K : M);
+  float* Ytp = ytp_save ? ytp_save : Ytp_ws;
+  { SgProfScope xf(SG_K_INSTNORM_BWD, s, 0, 4.0 * ((double)d->N * K * HW * 3.0 + 36.0 * (double)P * K));
+    const size_t lds = (size_t)(128 * (HW + 1) + 512) * sizeof(float);
+    w43_lds_attr(&w43_gy_in_kernel, lds);
+    hipLaunchKernelGGL(w43_gy_in_kernel, dim3(K / 64, d->N), dim3(256), lds, s, gout, ypre, mean, rstd, gconv, Ytp, d->N, K, d->H, d->W,
+                       act, slope); }
+  if (gx) {
+    const float* U = ut_saved;
+    if (U == nullptr) {
+      SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * 45.0 * (double)M * K);
+      hipLaunchKernelGGL(w43_weight_kernel, dim3((K / 32) * (M / 32)), dim3(256), 0, s, w, Uw, K, M);
+      U = Uw;
+    }
+    w43_gemm_dgrad(Ytp, U, G, (int)P, M, K, s);
+    { SgProfScope xf(SG_K_WINO_XFORM, s, 0, 4.0 * (36.0 * (double)P * M + (double)d->N * M * HW));
+      const size_t lds = (size_t)64 * ((d->H + 2) * (d->W + 2) + 1 + HW + 1) * sizeof(float);
+      w43_lds_attr(&w43_fold_kernel, lds);
+      hipLaunchKernelGGL(w43_fold_kernel, dim3(M / 64, d->N), dim3(256), lds, s, (const float*)G, gx, d->N, M, d->H, d->W); }
+  }
+  SG_LAUNCH_CHECK("sg_conv2d_wino_dgrad_instnorm");
   return 0;
 }
 

@@ -217,6 +217,18 @@ class FusedSequential(nn.Sequential):
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < n else None
             if isinstance(m, ReflectionPad2d) and isinstance(nxt, Conv2d):
+                nrm = mods[i + 2] if i + 2 < n else None
+                if (isinstance(nrm, InstanceNorm2d) and nxt.groups == 1
+                        and ops.conv_instnorm_fusable(x, nxt.weight, int(m.padding),
+                                                      _pair_to_int(nxt.stride, 'stride'), _pair_to_int(nxt.padding, 'padding'))):
+                    # pad + conv + InstanceNorm (+ act) (+ the block's residual when this is its last norm): one fused operator
+                    act, slope, used = _peek_act(mods, i + 3, norm=True)
+                    sk = None
+                    if i + 3 + used == n and skip is not None:
+                        sk, skip = skip, None
+                    x = ops.conv2d_instnorm(x, nxt.weight, nxt.bias, skip=sk, eps=nrm.eps, act=act, slope=slope)
+                    i += 3 + used
+                    continue
                 act, slope, used = _peek_act(mods, i + 2)
                 x = nxt(x, reflect_pad=m.padding, act=act, slope=slope)
                 i += 2 + used

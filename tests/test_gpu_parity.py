@@ -248,6 +248,62 @@ def test_winograd_f43_trunk_shape_vs_f23_and_fp64(hip):
         assert errs['f43_' + name] <= 6e-5, errs             # 2x the asserted conv bound, whatever F(2x2,3x3) shows
 
 
+@pytest.mark.parametrize('N,C,H,Cout,act,with_skip', [(16, 128, 8, 128, 1, True), (8, 128, 16, 256, 2, False), (32, 256, 8, 128, 0, True)])
+def test_conv_instnorm_fused_vs_fp64_and_unfused(hip, N, C, H, Cout, act, with_skip):
+    """ReflectionPad(1) + Conv3x3 + InstanceNorm (+ ReLU / LeakyReLU) (+ residual) of a ResnetBlock (layers.py:251-270) as the fused
+    Winograd F(4x4,3x3) operator (output transform + norm in one launch, norm backward + gradient transform in one) against an
+    fp64 reference and against the unfused pair of operators: output, input / weight / bias / skip gradients; 8x8 planes (one
+    tile per thread) and 16x16 planes (four)."""
+    from scene_generation_amd import _hip
+    assert hip.conv_instnorm_fusable(torch.empty(N, C, H, H, device=DEV), torch.empty(Cout, C, 3, 3), 1, 1, 0)
+    x, w, b = det((N, C, H, H), 411), det((Cout, C, 3, 3), 412, 0.1), det((Cout,), 413, 0.2)
+    skip = det((N, Cout, H, H), 414) if with_skip else None
+    gy = det((N, Cout, H, H), 415)
+    xr, wr, br = [t.double().requires_grad_() for t in (x, w, b)]
+    sr = skip.double().requires_grad_() if with_skip else None
+    yr = F.instance_norm(F.conv2d(F.pad(xr, (1,) * 4, mode='reflect'), wr, br), eps=1e-5)
+    zr = yr
+    yr = {0: lambda t: t, 1: F.relu, 2: lambda t: F.leaky_relu(t, 0.2)}[act](yr)
+    if with_skip:
+        yr = yr + sr
+    res = {}
+    for fused in (1, 0):
+        _hip.set_option('wino_in_fuse', fused)
+        try:
+            xg, wg, bg = [t.to(DEV).requires_grad_() for t in (x, w, b)]
+            sg = skip.to(DEV).requires_grad_() if with_skip else None
+            if fused:
+                yg = hip.conv2d_instnorm(xg, wg, bg, skip=sg, eps=1e-5, act=act, slope=0.2)
+            else:
+                yg = hip.instance_norm(hip.conv2d(xg, wg, bg, pad=1, reflect=True), skip=sg, eps=1e-5, act=act, slope=0.2)
+            if act and not res:
+                # the reference backward takes the derivative mask of the first GPU result (units within rounding of the kink)
+                lo = 0.0 if act == 1 else 0.2
+                pre = (yg.detach().cpu().double() - (skip.double() if with_skip else 0.0))
+                dg = torch.where(pre > 0, torch.tensor(1.0, dtype=torch.float64), torch.tensor(lo, dtype=torch.float64))
+                flipped = dg != torch.where(zr.detach() > 0, torch.tensor(1.0, dtype=torch.float64), torch.tensor(lo, dtype=torch.float64))
+                assert float(zr.detach()[flipped].abs().max() if flipped.any() else 0.0) <= 1e-4
+                torch.autograd.backward([zr] + ([sr] if with_skip else []), [gy.double() * dg] + ([gy.double()] if with_skip else []))
+            elif not res:
+                yr.backward(gy.double())
+            yg.backward(gy.to(DEV))
+            res[fused] = (yg.detach(), xg.grad, wg.grad, bg.grad, sg.grad if with_skip else None)
+        finally:
+            _hip.set_option('wino_in_fuse', 1)
+    for fused in (1, 0):
+        yg, gx, gw, gb, gs = res[fused]
+        tag = 'fused' if fused else 'unfused'
+        close(yg, yr.detach().float(), 5e-5, tag + ' out')
+        close(gx, xr.grad.float(), 1e-4, tag + ' gx')
+        close(gw, wr.grad.float(), 1e-4, tag + ' gw')
+        if with_skip:
+            close(gs, sr.grad.float(), 1e-6, tag + ' gskip')
+    # the conv bias is followed by a mean subtraction: its gradient is rounding noise around 0 in every implementation
+    assert float(res[1][3].abs().max()) <= 1e-3 * float(gy.abs().sum(dim=(0, 2, 3)).max())
+    close(res[1][0], res[0][0], 2e-5, 'fused vs unfused out')
+    close(res[1][1], res[0][1], 5e-5, 'fused vs unfused gx')
+
+
 @pytest.mark.parametrize('N,C,dense,H,Cout,KS,stride,pad,reflect,C2', [
     (5, 40, 6, 16, 64, 7, 1, 3, True, 0),      # generator stem: mask-free 64x64 tiles
     (3, 30, 4, 11, 24, 3, 1, 1, False, 0),     # ragged everything, zero padding
