@@ -369,7 +369,7 @@ def main():
                     traffic = tdetail['bytes_per_launch']
             if traffic is None:
                 live_note = tsrc
-                for tname in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json'):
+                for tname in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json'):
                     tpath = os.path.join(ROOT, 'profiles', tname)
                     if os.path.isfile(tpath):
                         tab = json.load(open(tpath)).get(name)

@@ -91,7 +91,9 @@ def main():
                 k[0], k[1], a[0], fe / 1e6, wr / 1e6, us, (fe + wr) / us / 1e3, '%.1f' % (ab / 1e6) if ab else '',
                 '%.2f' % ((fe + wr) / ab) if ab else ''))
     if '--json' in sys.argv:
-        names = {'igemm<T128x128, LoadKContig<128, true, false>, LoadKContig<128, true, false>, EpRowMajorPlain>': 'wino_bgemm_t128'}
+        names = {'igemm<T128x128, LoadKContig<128, true, false>, LoadKContig<128, true, false>, EpRowMajorPlain>': 'wino_bgemm_t128',
+                 # F(4x4,3x3): the forward instantiation (the data gradient's -- LoadKContig / LoadXContigS -- has the same grid and bytes)
+                 'igemm<T64x64, LoadKContig<64, true, false>, LoadKContig<64, true, false>, EpRowMajorPlain>': 'wino43_bgemm_t64'}
         for kname, kind in names.items():
             # the instantiation also runs the F(2x2,4x4) GEMMs (other grids): the bench line's kernel is the most frequent grid
             grids = [(a[0], k) for k, a in f.items() if k[0] == kname]
@@ -102,7 +104,7 @@ def main():
                 out[kind] = {'bytes_per_launch': (t[1] + t[2]) / t[0], 'fetch_bytes_per_launch': t[1] / t[0],
                              'write_bytes_per_launch': t[2] / t[0], 'launches_sampled': t[0],
                              'source': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 (gfx950), WRITE '
-                                       'calibrated on adam_kernel: tools/pmc_db_summary.py, profiles/r04_pmc_traffic.md'}
+                                       'calibrated on adam_kernel: tools/pmc_db_summary.py, profiles/r05_pmc_traffic.md'}
         json.dump(out, open(sys.argv[sys.argv.index('--json') + 1], 'w'), indent=1)
 
 
