@@ -161,7 +161,7 @@ int sg_conv2d_wino_dgrad_instnorm(const sgConvDesc* d, const float* gout, const 
                                   float* ytp_save, void* ws, size_t ws_bytes, sgStream stream);
 /* The GEMM stage of the Winograd convs on its own (the transforms of layers.py:251-270's convs aside):
  *   c[m][z*cols + j] = sum_k a[z][m][k] * b[z*cols + j][k],   z < nbatch   (both operands K-contiguous, fp32 MFMA)
- * tile: 0 = 128x128 (the product path), 1 = 64x128, 2 = 64x64; M, cols multiples of the tile, K of 32.  Exposed for
+ * tile: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 64x64 with 16-deep k-tiles; M, cols multiples of the tile, K of 32.  Exposed for
  * micro-benchmarks of candidate Winograd forms (tools/bench_wino_gemm.py: the F(4x4,3x3) study) and for tests. */
 int sg_batched_gemm_nt(const float* a, const float* b, float* c, int nbatch, int M, int cols, int K, int tile,
                        sgStream stream);

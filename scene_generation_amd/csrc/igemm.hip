@@ -848,6 +848,9 @@ bool wino_ok(const sgConvDesc* d) { return wino_tile(d) != 0; }
 // switch wino_gemm_tile.  tile: 0 = 128x128, 1 = 64x128, 2 = 64x64; all 32-deep, software-pipelined, plain epilogue.
 using CfgDI64W = TileCfg<64, 128, 2, 2, 2>;
 using CfgDI64 = TileCfg<64, 64, 2, 2, 2>;
+// 16-deep k-tiles: 20 KB of LDS per workgroup instead of 40 -- the 1152 workgroups of an F(4x4,3x3) GEMM (4.5 per CU) are then
+// all resident at once (32-deep: 4 per CU by LDS = 1024 slots, the other 128 run as a second, nearly empty round)
+using CfgDI64S = TileCfg<64, 64, 2, 1, 2>;
 void wino_bgemm_tile(int tile, const float* A, const float* B, float* Cout, int M, int cols, int K, double flops, hipStream_t s, int NB,
                      int kind = SG_K_OTHER) {
   sgk::t_alg_bytes = 4.0 * NB * ((double)M * K + (double)cols * K + (double)M * cols);
@@ -860,6 +863,9 @@ void wino_bgemm_tile(int tile, const float* A, const float* B, float* Cout, int 
     else if (tile == 2)
       launch_cfg<CfgDI64>(LoadKContig<64, true, false>{A, K, M}, LoadKContig<64, true, false>{B, K, NB * cols},
                           EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
+    else if (tile == 3)
+      launch_cfg<CfgDI64S>(LoadKContig<64, true, false>{A, K, M}, LoadKContig<64, true, false>{B, K, NB * cols},
+                           EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
     else
       launch_cfg<CfgDI128>(LoadKContig<128, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
                            EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
@@ -1454,8 +1460,9 @@ __global__ void w43_wgrad_output_kernel(const float* __restrict__ T, float* __re
 //   forward:          Mx[m][xi*P + p]  = sum_c U[xi][m][c] * V[xi][p][c]        (both K-contiguous)
 //   data gradient:    G[p][xi*C + c]   = sum_k Ytp[xi][p][k] * U[xi][k][c]      (A K-contiguous, B x-contiguous)
 //   weight gradient:  T[m][xi*C + c]   = sum_p Ytp[xi][p][m] * V[xi][p][c]      (both x-contiguous, K = P)
+inline int w43_tile() { return sg_opt(SG_OPT_W43_NSUB) == 1 ? 3 : 2; }
 void w43_gemm_fwd(const float* U, const float* V, float* Mx, int M, int P, int C, hipStream_t s) {
-  wino_bgemm_tile(2, U, V, Mx, M, P, C, 2.0 * 36.0 * M * (double)P * C, s, 36, SG_K_WINO43_GEMM);
+  wino_bgemm_tile(w43_tile(), U, V, Mx, M, P, C, 2.0 * 36.0 * M * (double)P * C, s, 36, SG_K_WINO43_GEMM);
 }
 void w43_gemm_dgrad(const float* Ytp, const float* U, float* G, int P, int C, int K, hipStream_t s) {
   sgk::t_alg_bytes = 4.0 * 36 * ((double)P * K + (double)C * K + (double)P * C);
@@ -1463,7 +1470,10 @@ void w43_gemm_dgrad(const float* Ytp, const float* U, float* G, int P, int C, in
   t_batch.batch_major = 1;
   {
     SgProfScope prof(SG_K_WINO43_GEMM, s, 2.0 * 36.0 * P * (double)C * K, 0);
-    launch_cfg<CfgDI64>(LoadKContig<64, true, false>{Ytp, K, P}, LoadXContigS<64>{U, C, C}, EpRowMajorPlain{G, 36 * C}, P, 36 * C, K, 1, s);
+    if (sg_opt(SG_OPT_W43_NSUB) == 1)
+      launch_cfg<CfgDI64S>(LoadKContig<64, true, false>{Ytp, K, P}, LoadXContigS<64>{U, C, C}, EpRowMajorPlain{G, 36 * C}, P, 36 * C, K, 1, s);
+    else
+      launch_cfg<CfgDI64>(LoadKContig<64, true, false>{Ytp, K, P}, LoadXContigS<64>{U, C, C}, EpRowMajorPlain{G, 36 * C}, P, 36 * C, K, 1, s);
   }
   t_batch = BatchInfo{};
 }
@@ -1473,7 +1483,10 @@ void w43_gemm_wgrad(const float* Ytp, const float* V, float* T, int M, int C, in
   t_batch.batch_major = 1;
   {
     SgProfScope prof(SG_K_WINO43_GEMM, s, 2.0 * 36.0 * M * (double)C * P, 0);
-    launch_cfg<CfgDI64>(LoadXContigS<64>{Ytp, M, 0}, LoadXContigS<64>{V, C, C}, EpRowMajorPlain{T, 36 * C}, M, 36 * C, P, 1, s);
+    if (sg_opt(SG_OPT_W43_NSUB) == 1)
+      launch_cfg<CfgDI64S>(LoadXContigS<64>{Ytp, M, 0}, LoadXContigS<64>{V, C, C}, EpRowMajorPlain{T, 36 * C}, M, 36 * C, P, 1, s);
+    else
+      launch_cfg<CfgDI64>(LoadXContigS<64>{Ytp, M, 0}, LoadXContigS<64>{V, C, C}, EpRowMajorPlain{T, 36 * C}, M, 36 * C, P, 1, s);
   }
   t_batch = BatchInfo{};
 }
@@ -1825,8 +1838,8 @@ bool w24_plan(const sgConvDesc* d, W24Plan* pl) {
 
 extern "C" int sg_batched_gemm_nt(const float* a, const float* b, float* c, int nbatch, int M, int cols, int K, int tile,
                                   sgStream stream) {
-  SG_ARG_CHECK(a && b && c && nbatch > 0 && M > 0 && cols > 0 && K > 0 && tile >= 0 && tile <= 2, "sg_batched_gemm_nt: bad arguments");
-  const int bm = tile == 0 ? 128 : 64, bn = tile == 2 ? 64 : 128;
+  SG_ARG_CHECK(a && b && c && nbatch > 0 && M > 0 && cols > 0 && K > 0 && tile >= 0 && tile <= 3, "sg_batched_gemm_nt: bad arguments");
+  const int bm = tile == 0 ? 128 : 64, bn = tile >= 2 ? 64 : 128;
   SG_ARG_CHECK(M % bm == 0 && cols % bn == 0 && K % 32 == 0, "sg_batched_gemm_nt: M, cols, K must be multiples of the tile (%d, %d, 32)", bm, bn);
   SG_ARG_CHECK(aligned16(a) && aligned16(b) && aligned16(c), "sg_batched_gemm_nt: operands must be 16-byte aligned");
   SG_ARG_CHECK((double)nbatch * M * K < SG_MAX_ELEMS && (double)nbatch * cols * K < SG_MAX_ELEMS, "sg_batched_gemm_nt: operand too large");
@@ -2110,7 +2123,7 @@ extern "C" int sg_conv2d_wino_fwd_instnorm(const sgConvDesc* d, const float* x, 
     w43_lds_attr(&w43_input_kernel, lds);
     hipLaunchKernelGGL(w43_input_kernel, dim3(C / 64, d->N), dim3(256), lds, s, x, V, d->N, C, d->H, d->W); }
   // tile-major result Mx[p][xi*M + m] = sum_c V[xi][p][c] U[xi][m][c]: the same GEMM with the operand roles swapped
-  wino_bgemm_tile(2, V, U, Mx, (int)P, M, C, 2.0 * 36.0 * M * (double)P * C, s, 36, SG_K_WINO43_GEMM);
+  wino_bgemm_tile(w43_tile(), V, U, Mx, (int)P, M, C, 2.0 * 36.0 * M * (double)P * C, s, 36, SG_K_WINO43_GEMM);
   { SgProfScope xf(SG_K_INSTNORM, s, 0, 4.0 * (36.0 * (double)P * M + (double)d->N * M * HW * (skip ? 3.0 : 2.0)));
     const size_t lds = (size_t)(128 * (HW + 1) + 256) * sizeof(float);
     if (NT <= 4) {

@@ -30,7 +30,7 @@ def timeit(fn, n=20, reps=3):
     return best
 
 
-def run(name, nb, M, cols, K, tiles=(0, 1, 2)):
+def run(name, nb, M, cols, K, tiles=(0, 1, 2, 3)):
     L = _hip.lib()
     g = torch.Generator(device='cpu').manual_seed(nb * 7 + cols)
     a = (torch.randn(nb, M, K, generator=g) * 0.05).to(DEV)
@@ -41,6 +41,7 @@ def run(name, nb, M, cols, K, tiles=(0, 1, 2)):
     flops = 2.0 * nb * M * cols * K
     for tile in tiles:
         bm, bn = (128, 128) if tile == 0 else ((64, 128) if tile == 1 else (64, 64))
+        tag = ' k16' if tile == 3 else ''
         if M % bm or cols % bn:
             continue
         fn = lambda: _hip.check(L.sg_batched_gemm_nt(a.data_ptr(), b.data_ptr(), c.data_ptr(), nb, M, cols, K, tile, st), 'bgemm')
@@ -49,8 +50,8 @@ def run(name, nb, M, cols, K, tiles=(0, 1, 2)):
         got = c.view(M, nb, cols).permute(1, 0, 2).double()
         err = float((got - want).abs().max() / want.abs().max())
         ms = timeit(fn)
-        print('%-34s tile %dx%-3d  %4d workgroups  %7.1f us  %6.1f TFLOP/s (%.2f of peak)  rel.err %.1e' % (
-            name, bm, bn, (M // bm) * (cols // bn) * nb, 1e3 * ms, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12 / PEAK, err))
+        print('%-34s tile %dx%-3d%s  %4d workgroups  %7.1f us  %6.1f TFLOP/s (%.2f of peak)  rel.err %.1e' % (
+            name, bm, bn, tag, (M // bm) * (cols // bn) * nb, 1e3 * ms, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12 / PEAK, err))
 
 
 if __name__ == '__main__':
