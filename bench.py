@@ -387,7 +387,19 @@ def main():
             elif name == 'wino43_bgemm_t64':         # 36 batches, P = B (S / 64)^2 tiles of 4x4 outputs (forward / data gradient)
                 Cc, P = 64 << 4, B * (S // 64) ** 2
                 alg = 4.0 * 36 * (Cc * Cc + P * Cc + Cc * P)
+            # what the launches of this kernel would cost in the DIRECT form of the convs they serve (SURVEY 8d counts the step in
+            # direct-form MACs): a ResnetBlock conv pass is 2 * 9 * C^2 * H W * N flops whichever Winograd form runs it
+            direct = None
+            if name in ('wino_bgemm_t128', 'wino43_bgemm_t64'):
+                Cc = 64 << 4
+                direct = 2.0 * 9 * Cc * Cc * (S // 16) ** 2 * B
             out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'direct_form_flops_per_launch': direct,
+                               'direct_form_equivalent_tflops': (direct * v['launches'] / (v['ms'] * 1e-3) / 1e12) if direct else None,
+                               'flops_note': '``achieved`` / ``frac`` count the multiplies the matrix pipe really issues (F(4x4,3x3): 36 per '
+                                             '16 outputs and channel pair, 1.78x fewer than F(2x2,3x3), 4x fewer than the direct 3x3 form); '
+                                             '``direct_form_equivalent_tflops`` prices the same launches at the direct-form flops of the '
+                                             'convs they compute (the unit of SURVEY 8d) -- it exceeds the peak by the MACs Winograd removes',
                                'frac': ach / F32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': tsrc,
                                'traffic_detail': tdetail, 'algorithmic_bytes_per_launch': alg,
                                'traffic_over_algorithmic': (traffic / alg) if (traffic and alg) else None,
@@ -409,6 +421,9 @@ def main():
                 'all_mfma_gemms': {'ms_per_step': igms / a.steps, 'tflops': igfl / (igms * 1e-3) / 1e12 if igms else 0.0,
                                    'frac': igfl / (igms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS if igms else 0.0},
                 'step_mfma_frac': step_flops / (dt / a.steps) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                # 237 GFLOP per image in the direct form of every conv / GEMM of the step at 128x128 -- the step runs above
+                # the fp32 MFMA peak on that scale because the Winograd / sub-pixel / factored forms remove MACs
+                'step_direct_form_tflops': (237e9 * B / (dt / a.steps) / 1e12) if S == 128 else None,
                 'step_mfma_tflop': step_flops / 1e12,
                 'timed_kernels_ms_per_step': all_ms / a.steps,
                 'top': {k: {'ms_per_step': round(x['ms'] / a.steps, 3), 'launches_per_step': x['launches'] / a.steps,
