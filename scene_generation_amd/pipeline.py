@@ -60,6 +60,11 @@ class DeviceBatchPrefetcher(object):
         self.stream = torch.cuda.Stream(self.device) if self.cuda else None
         self.depth = max(1, int(depth))
         self._queue = []
+        # pinned staging buffers, re-used: ``t.pin_memory()`` page-locks a fresh allocation per tensor and batch (milliseconds of
+        # host time each -- measured in bench.py's host_buffers leg: the step went host-bound on a slow box); a slot holds one
+        # buffer per tensor of the 8-tuple and the event behind its last H2D copies, depth + 1 slots rotate
+        self._slots = [dict() for _ in range(self.depth + 1)]
+        self._staged = 0
 
     def _stage(self):
         try:
@@ -72,10 +77,24 @@ class DeviceBatchPrefetcher(object):
         objs_host = hb.objs.tolist()
         seg = segment_offsets(o2i, N)
         if self.cuda:
+            slot = self._slots[self._staged % len(self._slots)]
+            self._staged += 1
+            if slot.get('ev') is not None:
+                slot['ev'].synchronize()           # the copies that last read this slot's buffers (depth + 1 batches ago)
+            moved = []
             with torch.cuda.stream(self.stream):
-                dev = Batch(*[t.pin_memory().to(self.device, non_blocking=True) for t in hb])
+                for i, t in enumerate(hb):
+                    t = t.contiguous()
+                    buf = slot.get(i)
+                    if buf is None or buf.dtype != t.dtype or buf.numel() < t.numel():
+                        buf = slot[i] = torch.empty(t.numel() * 5 // 4 + 16, dtype=t.dtype, pin_memory=True)
+                    view = buf[:t.numel()].view(t.shape)
+                    view.copy_(t)                  # host memcpy into page-locked memory
+                    moved.append(view.to(self.device, non_blocking=True))
+            dev = Batch(*moved)
             ev = torch.cuda.Event()
             ev.record(self.stream)
+            slot['ev'] = ev
         else:
             dev, ev = hb, None
         self._queue.append((DeviceBatch(dev, objs_host, o2i, seg, N), ev))
