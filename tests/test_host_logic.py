@@ -487,3 +487,24 @@ def test_library_kernels_fit_their_register_budget():
     assert sum(1 for k in t64 if k['waves_per_simd'] >= 5) >= 0.8 * len(t64)       # the fixed-tap / K-contiguous forms: 6
     head = [k for k in ks if k['name'].startswith('smallm_fwd_kernel<7, 3>')]
     assert head and head[0]['vgpr'] <= 128                                          # 512 threads: two workgroups per CU
+
+
+def test_threaded_prefetcher_order_and_error_propagation():
+    """the background staging thread of DeviceBatchPrefetcher (the default on a GPU; forced here on CPU tensors): batches come out
+    in source order with their host summaries, the iterator ends cleanly, and a batch that violates the collate contract raises
+    in the CONSUMER, at its position in the stream."""
+    from scene_generation_amd.pipeline import DeviceBatchPrefetcher
+    from scene_generation_amd.synthetic import make_batch, Batch
+    hbs = [make_batch(N=3, min_objs=2, max_objs=4, size=16, mask_size=8, num_objs=12, num_preds=4, seed=s) for s in range(5)]
+    out = list(DeviceBatchPrefetcher(hbs, 'cpu', threaded=True, depth=2))
+    assert len(out) == 5
+    for db, hb in zip(out, hbs):
+        assert torch.equal(db.batch.imgs, hb.imgs) and db.objs_host == hb.objs.tolist() and db.num_images == 3
+        assert db.seg_offsets_host[-1] == hb.objs.numel()
+    bad = Batch(*hbs[1])._replace(obj_to_img=hbs[1].obj_to_img.flip(0))
+    it = DeviceBatchPrefetcher([hbs[0], bad, hbs[2]], 'cpu', threaded=True)
+    assert torch.equal(next(it).batch.objs, hbs[0].objs)
+    with pytest.raises(ValueError):
+        next(it)
+    with pytest.raises(StopIteration):
+        next(it)
