@@ -352,6 +352,13 @@ int sg_crop_bbox_fwd(const float* feats, const float* boxes, const int64_t* box_
  * footprint covers each image pixel, summed in (box, crop row, crop column) order => bit-reproducible */
 int sg_crop_bbox_bwd(const float* gout, const float* boxes, const int64_t* box_to_feat, float* g_feats, int N, int C,
                      int H, int W, int B, int HH, int WW, sgStream stream);
+/* crop_bbox(feats, bbox, HH, WW, backend='jj') (bilinear.py:101-130 with bilinear_sample, bilinear.py:188-243): one box per
+ * image, pixel coordinate X * W without the half-pixel shift, floor / floor + 1 taps clamped to the plane.  No caller of the
+ * reference reaches this sampler (crop_bbox_batch never forwards its backend); _bwd = the gradient w.r.t. feats, deterministic. */
+int sg_crop_bbox_jj_fwd(const float* feats, const float* boxes, float* out, int N, int C, int H, int W, int HH, int WW,
+                        sgStream stream);
+int sg_crop_bbox_jj_bwd(const float* gout, const float* boxes, float* g_feats, int N, int C, int H, int W, int HH, int WW,
+                        sgStream stream);
 /* Per-image filters of the factored layout convs: layout = sum_o [one_hot(class_o) | repr_o] (x) S_o (model.py:165-168,
  * layout.py:85-86) => conv(layout | x2, w)[n] = sum_j wimg[n][:, j] (*) plane_j with
  *   wimg[n][m][j][t] = w[m][class_o][t] + sum_d repr[o][d] w[m][C + d][t]   for the j-th object o of image n (j < cnt_n)

@@ -163,6 +163,29 @@ def crop_bbox_batch(feats, bbox, bbox_to_feats, HH, WW=None, backend='cudnn'):
     return bilinear_sample(feats[bbox_to_feats], gx, gy)
 
 
+def crop_bbox_jj(feats, bbox, HH, WW=None):
+    """crop_bbox(feats, bbox, HH, WW, backend='jj') = bilinear_sample on the box grid (bilinear.py:101-130,188-243): one box per
+    image, grid x[j] = start_w[j] * x0 + end_w[j] * x1 in [0, 1] (tensor_linspace, bilinear.py:246-275), pixel coordinate
+    X = x * W (no half-pixel shift), taps floor(X) and floor(X) + 1 clamped to [0, W - 1], weights (x1 - X)(y1 - Y) etc. taken
+    from the CLAMPED tap positions."""
+    WW = HH if WW is None else WW
+    N, C, H, W = feats.shape
+    X = (torch.linspace(1, 0, steps=WW).to(feats)[None] * bbox[:, 0:1] + torch.linspace(0, 1, steps=WW).to(feats)[None] * bbox[:, 2:3]) * W
+    Y = (torch.linspace(1, 0, steps=HH).to(feats)[None] * bbox[:, 1:2] + torch.linspace(0, 1, steps=HH).to(feats)[None] * bbox[:, 3:4]) * H
+    x0 = X.floor().clamp(min=0, max=W - 1)
+    x1 = (x0 + 1).clamp(min=0, max=W - 1)
+    y0 = Y.floor().clamp(min=0, max=H - 1)
+    y1 = (y0 + 1).clamp(min=0, max=H - 1)
+    n = torch.arange(N)[:, None, None]
+
+    def tap(yi, xi):                                   # (N, C, HH, WW)
+        return feats[n, :, yi.long()[:, :, None], xi.long()[:, None, :]].permute(0, 3, 1, 2)
+
+    wx0, wx1 = (x1 - X)[:, None, None, :], (X - x0)[:, None, None, :]
+    wy0, wy1 = (y1 - Y)[:, None, :, None], (Y - y0)[:, None, :, None]
+    return (wx0 * wy0) * tap(y0, x0) + (wx0 * wy1) * tap(y1, x0) + (wx1 * wy0) * tap(y0, x1) + (wx1 * wy1) * tap(y1, x1)
+
+
 # ------------------------------------------------------------------------------------------
 # layers.py
 # ------------------------------------------------------------------------------------------

@@ -21,11 +21,16 @@ def crop_bbox_batch(feats, bbox, bbox_to_feats, HH, WW=None, backend='cudnn'):
 def crop_bbox(feats, bbox, HH, WW=None, backend='cudnn'):
     """feats[i] cropped by bbox[i] (bilinear.py:101-130)."""
     import torch
+    N = feats.size(0)
+    assert bbox.size(0) == N and bbox.size(1) == 4
+    if WW is None:
+        WW = HH
+    if backend == 'jj':
+        # bilinear.py:127-128 (``bilinear_sample``: pixel coordinates X * W without the half-pixel shift, clamped taps); called by
+        # nothing in the reference (crop_bbox_batch never forwards its backend, see above), built for the surface's completeness
+        return ops.CropBBoxJJFn.apply(feats, bbox, int(HH), int(WW))
     if backend != 'cudnn':
-        # bilinear.py:127-128 (``bilinear_sample``: pixel coordinates X*W without the half-pixel shift, clamped taps): called by
-        # nothing in the reference (crop_bbox_batch never forwards its backend, see above)
-        raise NotImplementedError("crop_bbox(backend=%r): only the grid_sample geometry has a HIP kernel; no caller in the "
-                                  "reference reaches the 'jj' sampler" % (backend,))
+        return None                         # bilinear.py:125-130 falls off the end for any other value
     N = feats.size(0)
     assert bbox.size(0) == N and bbox.size(1) == 4
     idx = torch.arange(N, dtype=torch.int64, device=feats.device)

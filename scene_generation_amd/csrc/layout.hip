@@ -640,6 +640,75 @@ extern "C" int sg_crop_bbox_bwd(const float* gout, const float* boxes, const int
   return 0;
 }
 
+// ---- crop_bbox(backend='jj'): the bilinear_sample geometry (bilinear.py:127-128,188-243) ----------------------------------------
+// One box per image; grid x[j] = lin10(j) x0 + lin01(j) x1 in [0, 1] (tensor_linspace), pixel coordinate X = x * W (no half-pixel
+// shift), taps floor(X) and floor(X) + 1 clamped to [0, W - 1], weights (x1 - X) and (X - x0) from the CLAMPED tap positions (at
+// X >= W - 1 both taps are W - 1 and the weights cancel: the reference's own edge behaviour).  No caller of the reference reaches
+// this sampler (crop_bbox_batch never forwards its backend); built for completeness of the bilinear.py surface, not for speed.
+struct JJTap { int i0, i1; float w0, w1; };
+__device__ __forceinline__ JJTap jj_tap(float c0, float c1, int j, int n, int size) {
+  const float X = (lin10(j, n) * c0 + lin01(j, n) * c1) * (float)size;
+  const float hi = (float)(size - 1);
+  const float f0 = fminf(fmaxf(floorf(X), 0.f), hi), f1 = fminf(fmaxf(f0 + 1.f, 0.f), hi);
+  JJTap t;
+  t.i0 = (int)f0; t.i1 = (int)f1; t.w0 = f1 - X; t.w1 = X - f0;
+  return t;
+}
+__global__ void crop_jj_fwd_kernel(const float* __restrict__ feats, const float* __restrict__ boxes, float* __restrict__ out, int N,
+                                   int C, int H, int W, int HH, int WW) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * C * HH * WW) return;
+  const int x = i % WW, y = (i / WW) % HH, c = (i / ((size_t)WW * HH)) % C, n = i / ((size_t)WW * HH * C);
+  const JJTap tx = jj_tap(boxes[n * 4 + 0], boxes[n * 4 + 2], x, WW, W), ty = jj_tap(boxes[n * 4 + 1], boxes[n * 4 + 3], y, HH, H);
+  const float* f = feats + ((size_t)n * C + c) * H * W;
+  // w1 v(y0,x0) + w2 v(y1,x0) + w3 v(y0,x1) + w4 v(y1,x1), in the reference's order of additions (bilinear.py:242)
+  float v = (tx.w0 * ty.w0) * f[ty.i0 * W + tx.i0];
+  v += (tx.w0 * ty.w1) * f[ty.i1 * W + tx.i0];
+  v += (tx.w1 * ty.w0) * f[ty.i0 * W + tx.i1];
+  v += (tx.w1 * ty.w1) * f[ty.i1 * W + tx.i1];
+  out[i] = v;
+}
+// gradient w.r.t. feats as a gather: one thread per input pixel walks the crop rows / columns whose taps name it, in (row, column)
+// order -- deterministic, no atomics; O(HH WW) per pixel, which is fine for a path nobody trains through
+__global__ void crop_jj_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ boxes, float* __restrict__ gf, int N,
+                                   int C, int H, int W, int HH, int WW) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * C * H * W) return;
+  const int u = i % W, r = (i / W) % H, c = (i / ((size_t)W * H)) % C, n = i / ((size_t)W * H * C);
+  const float bx0 = boxes[n * 4 + 0], by0 = boxes[n * 4 + 1], bx1 = boxes[n * 4 + 2], by1 = boxes[n * 4 + 3];
+  const float* g = gout + ((size_t)n * C + c) * HH * WW;
+  float acc = 0.f;
+  for (int y = 0; y < HH; ++y) {
+    const JJTap ty = jj_tap(by0, by1, y, HH, H);
+    const float wy = (ty.i0 == r ? ty.w0 : 0.f) + (ty.i1 == r ? ty.w1 : 0.f);
+    if (ty.i0 != r && ty.i1 != r) continue;
+    for (int x = 0; x < WW; ++x) {
+      const JJTap tx = jj_tap(bx0, bx1, x, WW, W);
+      if (tx.i0 != u && tx.i1 != u) continue;
+      const float wx = (tx.i0 == u ? tx.w0 : 0.f) + (tx.i1 == u ? tx.w1 : 0.f);
+      acc += (wx * wy) * g[y * WW + x];
+    }
+  }
+  gf[i] = acc;
+}
+
+extern "C" int sg_crop_bbox_jj_fwd(const float* feats, const float* boxes, float* out, int N, int C, int H, int W, int HH, int WW,
+                                   sgStream stream) {
+  SG_ARG_CHECK(feats && boxes && out && N > 0 && C > 0 && H > 0 && W > 0 && HH > 0 && WW > 0, "sg_crop_bbox_jj_fwd: bad arguments");
+  hipLaunchKernelGGL(crop_jj_fwd_kernel, dim3(sg_cdiv((size_t)N * C * HH * WW, 256)), dim3(256), 0, (hipStream_t)stream, feats, boxes,
+                     out, N, C, H, W, HH, WW);
+  SG_LAUNCH_CHECK("sg_crop_bbox_jj_fwd");
+  return 0;
+}
+extern "C" int sg_crop_bbox_jj_bwd(const float* gout, const float* boxes, float* g_feats, int N, int C, int H, int W, int HH, int WW,
+                                   sgStream stream) {
+  SG_ARG_CHECK(gout && boxes && g_feats && N > 0 && C > 0 && H > 0 && W > 0 && HH > 0 && WW > 0, "sg_crop_bbox_jj_bwd: bad arguments");
+  hipLaunchKernelGGL(crop_jj_bwd_kernel, dim3(sg_cdiv((size_t)N * C * H * W, 256)), dim3(256), 0, (hipStream_t)stream, gout, boxes,
+                     g_feats, N, C, H, W, HH, WW);
+  SG_LAUNCH_CHECK("sg_crop_bbox_jj_bwd");
+  return 0;
+}
+
 extern "C" int sg_vector_pool_exchange(float* pool, const float* vectors, const int32_t* plan, float* out, int O, int R,
                                        int pool_size, sgStream stream) {
   SG_ARG_CHECK(pool && vectors && plan && out && O >= 0 && R > 0 && pool_size > 0, "sg_vector_pool_exchange: bad arguments");

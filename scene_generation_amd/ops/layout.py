@@ -314,6 +314,32 @@ def factored_layout_conv(f, weight, bias, stride, pad, reflect, act, slope, x2):
                                 float(slope))
 
 
+class CropBBoxJJFn(Function):
+    """crop_bbox(feats, bbox, HH, WW, backend='jj'): the ``bilinear_sample`` geometry (bilinear.py:127-128,188-243), one box per image;
+    gradient w.r.t. feats."""
+
+    @staticmethod
+    def forward(ctx, feats, boxes, HH, WW):
+        feats, boxes = _f32(feats, 'feats'), _f32(boxes, 'bbox')
+        N, C, H, W = feats.shape
+        out = torch.empty(N, C, HH, WW, dtype=torch.float32, device=feats.device)
+        _call('sg_crop_bbox_jj_fwd', _p(feats), _p(boxes), _p(out), N, C, H, W, HH, WW, _stream())
+        ctx.dims = (N, C, H, W, HH, WW)
+        ctx.save_for_backward(boxes)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        boxes, = ctx.saved_tensors
+        N, C, H, W, HH, WW = ctx.dims
+        gf = None
+        if ctx.needs_input_grad[0]:
+            g = _f32(g)
+            gf = torch.empty(N, C, H, W, dtype=torch.float32, device=g.device)
+            _call('sg_crop_bbox_jj_bwd', _p(g), _p(boxes), _p(gf), N, C, H, W, HH, WW, _stream())
+        return gf, None, None, None
+
+
 class CropBBoxFn(Function):
     """crop_bbox_batch (bilinear.py:26-41,67-130): gather forward, scatter-add backward w.r.t. feats."""
 

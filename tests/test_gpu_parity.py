@@ -757,6 +757,19 @@ def test_crop_golden(hip, golden, case):
     close(feats.grad, g['g_feats'], 1e-4, 'g_feats')
 
 
+@pytest.mark.parametrize('case', ['sq', 'rect'])
+def test_crop_bbox_jj_direct_golden(hip, golden, case):
+    """crop_bbox(feats, bbox, HH, WW, backend='jj') against the reference's own output (bilinear.py:101-130,188-243: pixel coordinate
+    X * W, clamped floor / floor + 1 taps, the cancelling weights at the far edge) and its gradient w.r.t. feats"""
+    from scene_generation_amd.bilinear import crop_bbox
+    g = golden('crop_jj_direct_' + case)
+    feats = torch.from_numpy(g['feats']).to(DEV).requires_grad_()
+    out = crop_bbox(feats, torch.from_numpy(g['boxes']).to(DEV), int(g['HH']), int(g['WW']), backend='jj')
+    close(out, g['out'], 1e-6, 'crop jj')
+    (out * torch.from_numpy(g['w']).to(DEV)).sum().backward()
+    close(feats.grad, g['g_feats'], 1e-5, 'g_feats')
+
+
 def test_vector_pool_matches_reference_semantics(hip):
     from scene_generation_amd.utils import VectorPool
     random.seed(7)

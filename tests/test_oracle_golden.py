@@ -345,6 +345,18 @@ def test_c_oracle_layout(golden, case):
     close(out, g['out'], 1e-5, 'layout (C)')
 
 
+
+@pytest.mark.parametrize('case', ['sq', 'rect'])
+def test_crop_bbox_jj_vs_reference(golden, case):
+    """crop_bbox(backend='jj') called directly -- the ``bilinear_sample`` geometry of bilinear.py:188-243, which no caller of the
+    reference reaches -- restated in the oracle: forward bit-exact, gradient w.r.t. feats to rounding"""
+    g = golden('crop_jj_direct_' + case)
+    feats = T(g['feats']).requires_grad_()
+    out = O.crop_bbox_jj(feats, T(g['boxes']), int(g['HH']), int(g['WW']))
+    assert torch.equal(out, T(g['out']))
+    (out * T(g['w'])).sum().backward()
+    close(feats.grad, g['g_feats'], 1e-6, 'g_feats')
+
 @pytest.mark.parametrize('case', ['sorted_8', 'perm_8', 'perm_32'])
 def test_c_oracle_crop(golden, case):
     g = golden('crop_' + case)

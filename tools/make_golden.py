@@ -208,6 +208,16 @@ def golden_crop():
     w = probe_weight(out.shape, 33)
     gf, = grads_of((out * w).sum(), [feats])
     npz('crop_jj_batch', feats=feats, boxes=boxes, idx=idx_t, out=out, w=w, g_feats=gf, HH=8, WW=12)
+    # crop_bbox(backend='jj') called directly: the bilinear_sample geometry (bilinear.py:127-128,188-243: pixel coordinate X * W
+    # without the half-pixel shift, floor / floor + 1 taps clamped to the plane -- at X * W >= W - 1 both taps coincide and their
+    # weights cancel).  One box per image, incl. the full box (whose last row / column hits that edge case)
+    from scene_generation.bilinear import crop_bbox
+    bj = torch.stack([torch.tensor([0., 0., 1., 1.]), torch.tensor([0.25, 0.25, 0.75, 0.75]), torch.tensor([0.1, 0.3, 0.62, 0.97])], 0)
+    for name, HH, WW in (('sq', 8, 8), ('rect', 6, 11)):
+        out = crop_bbox(feats, bj, HH, WW, backend='jj')
+        w = probe_weight(out.shape, 34)
+        gf, = grads_of((out * w).sum(), [feats])
+        npz('crop_jj_direct_' + name, feats=feats, boxes=bj, out=out, w=w, g_feats=gf, HH=HH, WW=WW)
 
 
 def run_module(name, mod, inputs, extra=None, train=True):
