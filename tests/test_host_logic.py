@@ -508,3 +508,37 @@ def test_threaded_prefetcher_order_and_error_propagation():
         next(it)
     with pytest.raises(StopIteration):
         next(it)
+
+
+def test_winograd_f43_matrices_in_the_kernel_source_satisfy_the_identities():
+    """The F(4x4,3x3) transform matrices as WRITTEN in csrc/igemm.hip (w43_bt / w43_g / w43_at), parsed from the source: forward
+    y = A^T [(G g G^T) (.) (B^T d B)] A equals the 3x3 correlation of a 6x6 patch, and the data / weight gradient forms the kernels
+    use -- B [U (.) (A gy A^T)] B^T and G^T [(A gy A^T) (.) (B^T d B)] G -- are its exact adjoints (float64).  Guards the constants
+    against an edit that the GPU tolerances might absorb."""
+    import re
+    import numpy as np
+    src = open(os.path.join(ROOT, 'scene_generation_amd', 'csrc', 'igemm.hip')).read()
+
+    def matrix(fn, rows, cols):
+        body = re.search(r'%s\(int i, int j\) \{\s*constexpr float m\[%d\]\[%d\] = (\{.*?\});' % (fn, rows, cols), src, re.S).group(1)
+        vals = [eval(v.replace('f', ''), {'__builtins__': {}}) for v in re.findall(r'-?\d+\.?\d*f(?:\s*/\s*\d+\.?\d*f)?', body)]
+        assert len(vals) == rows * cols, (fn, len(vals))
+        return np.array(vals, dtype=np.float64).reshape(rows, cols)
+
+    BT, G, AT = matrix('w43_bt', 6, 6), matrix('w43_g', 6, 3), matrix('w43_at', 4, 6)
+    rng = np.random.RandomState(0)
+    d, g, gy = rng.randn(6, 6), rng.randn(3, 3), rng.randn(4, 4)
+    U, V = G @ g @ G.T, BT @ d @ BT.T
+    y = AT @ (U * V) @ AT.T
+    ref = np.array([[(g * d[i:i + 3, j:j + 3]).sum() for j in range(4)] for i in range(4)])
+    assert np.abs(y - ref).max() < 1e-12
+    Yt = AT.T @ gy @ AT
+    gd = BT.T @ (U * Yt) @ BT                       # d/dd of sum(y * gy)
+    gd_ref = np.zeros((6, 6))
+    for i in range(4):
+        for j in range(4):
+            gd_ref[i:i + 3, j:j + 3] += gy[i, j] * g
+    assert np.abs(gd - gd_ref).max() < 1e-12
+    gw = G.T @ (Yt * V) @ G                         # d/dg of sum(y * gy)
+    gw_ref = np.array([[(gy * d[a:a + 4, b:b + 4]).sum() for b in range(3)] for a in range(3)])
+    assert np.abs(gw - gw_ref).max() < 1e-12
