@@ -69,6 +69,136 @@ def physical_cores():
         return os.cpu_count()
 
 
+class ClockSampler(object):
+    """sclk / mclk / socket power of one GPU sampled on a background thread while the timed region runs (two
+    boxes of the pool differ by ~5 % in kernel time at equal host speed; the line now says at what clocks and power it was
+    measured).  Source: the amdgpu hwmon files of the device (freq1_input = sclk, freq2_input = mclk, power1_average / power1_input
+    in microwatts) -- plain file reads, ~20 us each, nothing is launched on the GPU; ``rocm-smi --json`` as a (slow, ~100 ms per
+    sample) fallback when sysfs is not readable.  Reported clocks are the SMU's view, not an in-kernel cycle count."""
+
+    def __init__(self, index=0, period_s=0.02):
+        import glob
+        import threading
+        self.period, self.samples, self._stop, self._th = period_s, [], threading.Event(), None
+        self.src, self._files = None, {}
+        cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/hwmon/hwmon*'))
+        cards = [c for c in cards if os.path.isfile(os.path.join(c, 'freq1_input'))]
+        if cards:
+            h = cards[min(index, len(cards) - 1)]
+            # the HIP device index is not the DRM card index when the box exposes more cards than the process may use: match the
+            # PCI address (domain:bus:device) of the HIP device against the card's sysfs path
+            try:
+                pr = torch.cuda.get_device_properties(index)
+                addr = '%04x:%02x:%02x.' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+                hit = [c for c in cards if addr in os.path.realpath(c)]
+                if hit:
+                    h = hit[0]
+            except Exception:
+                pass
+            for key, names in (('sclk_mhz', ('freq1_input',)), ('mclk_mhz', ('freq2_input',)),
+                               ('power_w', ('power1_average', 'power1_input'))):
+                for n in names:
+                    if os.path.isfile(os.path.join(h, n)):
+                        self._files[key] = os.path.join(h, n)
+                        break
+            self.src = 'sysfs:' + h
+        elif os.path.exists('/opt/rocm/bin/rocm-smi'):
+            self.src, self.period = 'rocm-smi', 0.1
+        self._index = index
+
+    def _read(self):
+        t = time.perf_counter()
+        if self._files:
+            row = {'t': t}
+            for key, path in self._files.items():
+                try:
+                    v = float(open(path).read().strip())
+                    row[key] = v / 1e6                       # Hz -> MHz, microwatt -> W
+                except (OSError, ValueError):
+                    pass
+            return row
+        import re as _re
+        import subprocess
+        try:
+            txt = subprocess.run(['/opt/rocm/bin/rocm-smi', '-d', str(self._index), '--showclocks', '--showpower', '--json'],
+                                 capture_output=True, text=True, timeout=10).stdout
+        except Exception:
+            return {'t': t}
+        row = {'t': t}
+        for key, rx in (('sclk_mhz', r'"sclk clock speed:?": "\((\d+)Mhz\)"'), ('mclk_mhz', r'"mclk clock speed:?": "\((\d+)Mhz\)"'),
+                        ('power_w', r'Power \(W\)": "([0-9.]+)"')):
+            m = _re.search(rx, txt)
+            if m:
+                row[key] = float(m.group(1))
+        return row
+
+    def _loop(self):
+        while not self._stop.is_set():
+            self.samples.append(self._read())
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self.src is None:
+            return self
+        import threading
+        self.samples, self._stop = [], threading.Event()
+        self._th = threading.Thread(target=self._loop, daemon=True)
+        self._th.start()
+        return self
+
+    def stop(self, t0=None, t1=None):
+        """-> summary of the samples taken inside [t0, t1] (perf_counter times; default: all of them)"""
+        if self._th is not None:
+            self._stop.set()
+            self._th.join(timeout=5)
+            self._th = None
+        rows = [r for r in self.samples if (t0 is None or r['t'] >= t0) and (t1 is None or r['t'] <= t1)]
+        out = {'source': self.src, 'samples': len(rows), 'period_ms': 1e3 * self.period}
+        for key in ('sclk_mhz', 'mclk_mhz', 'power_w'):
+            v = sorted(r[key] for r in rows if key in r)
+            if v:
+                out[key] = {'min': round(v[0], 1), 'median': round(v[len(v) // 2], 1), 'max': round(v[-1], 1)}
+        return out
+
+
+def rccl_info(backend):
+    """what transport the multi-GPU line was measured on: torch's view of the RCCL version, the version line RCCL itself
+    printed under NCCL_DEBUG=VERSION (NCCL_DEBUG_FILE of this process), and the environment that selects the transport"""
+    import glob
+    import socket
+    info = {'backend': backend, 'hip': getattr(torch.version, 'hip', None), 'torch': torch.__version__}
+    try:
+        info['torch_cuda_nccl_version'] = list(torch.cuda.nccl.version())
+    except Exception as e:
+        info['torch_cuda_nccl_version'] = 'unavailable: %r' % (e,)
+    pat = os.environ.get('NCCL_DEBUG_FILE', '')
+    line = None
+    if pat:
+        path = pat.replace('%h', socket.gethostname()).replace('%p', str(os.getpid()))
+        for f in [path] + sorted(glob.glob(pat.replace('%h', '*').replace('%p', '*'))):
+            try:
+                for ln in open(f, errors='replace'):
+                    if 'version' in ln.lower() and ('nccl' in ln.lower() or 'rccl' in ln.lower()):
+                        line = ln.strip()
+                        break
+            except OSError:
+                continue
+            if line:
+                break
+    info['version_line'] = line
+    info['env'] = {k: os.environ.get(k) for k in ('NCCL_DEBUG', 'HSA_ENABLE_IPC_MODE_LEGACY', 'NCCL_P2P_DISABLE', 'NCCL_SOCKET_IFNAME',
+                                                  'RCCL_MSCCL_ENABLE', 'HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES')
+                   if os.environ.get(k) is not None}
+    return info
+
+
+def split_blocks(n_steps, want=5):
+    """step counts of the back-to-back timing blocks the K timed steps are cut into (>= 5 blocks when K allows)"""
+    nb = max(1, min(want, n_steps))
+    base, extra = divmod(n_steps, nb)
+    return [base + (1 if i < extra else 0) for i in range(nb)]
+
+
 def cpu_baseline(image_size, n_images, n_steps):
     """The oracle (oracle/sg_oracle.py, kind "port") timed on the host cores on a bounded sample of the same workload
     (SURVEY 8d): the full G+D step at the same widths and flags as the headline pass on ``n_images`` images, 1 warm-up +
@@ -213,6 +343,12 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = os.environ.get('SG_DIST_BACKEND', 'nccl')
+        # the first real multi-GPU run describes itself: RCCL prints its version line at communicator
+        # creation when NCCL_DEBUG >= VERSION; it goes to a per-process file (never into the one-JSON-line stdout) and is read back
+        # into ``rccl`` below
+        if backend == 'nccl' and 'NCCL_DEBUG' not in os.environ:
+            os.environ['NCCL_DEBUG'] = 'VERSION'
+            os.environ.setdefault('NCCL_DEBUG_FILE', '/tmp/sg_rccl_debug.%h.%p.log')
         import datetime
         # a rank that never arrives must fail the run, not hang it: 10 minutes covers the slowest first import on a fresh box
         dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
@@ -254,20 +390,45 @@ def main():
 
     issue = [0.0]
 
-    def timed(trainer, n_steps, first, batches=None):
+    blocks_ms = [None]
+
+    def timed(trainer, n_steps, first, batches=None, blocks=None):
+        """K steps between barrier + synchronize on both sides (the contract); ``blocks``: step counts of back-to-back blocks whose
+        boundaries are HIP events recorded on the launch stream (no host synchronisation inside the region) -> blocks_ms[0]"""
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        evs = []
+        if blocks:
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(blocks) + 1)]
+            bounds, acc = set(), 0
+            for nb in blocks:
+                acc += nb
+                bounds.add(acc)
         t0 = time.perf_counter()
+        if evs:
+            evs[0].record()
+        ie = 1
         for i in range(n_steps):
             one_step(trainer, first + i, batches)
+            if evs and (i + 1) in bounds:
+                evs[ie].record()
+                ie += 1
         issue[0] = time.perf_counter() - t0          # host done issuing; the GPU may still be working
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         d = time.perf_counter() - t0
+        timed.t0, timed.t1 = t0, t0 + d
+        if evs:
+            bm = [evs[j].elapsed_time(evs[j + 1]) for j in range(len(blocks))]
+            if world > 1:
+                tb = torch.tensor(bm, device=dev, dtype=torch.float64)
+                dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+                bm = [float(x) for x in tb.tolist()]
+            blocks_ms[0] = bm
         if world > 1:
             t = torch.tensor([d], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -280,8 +441,20 @@ def main():
         one_step(tr, i)
     # headline pass: exactly K steps, no per-launch instrumentation
     calls0, replays0 = ops.CALLS[0], graphs.REPLAYS[0]
-    dt = timed(tr, a.steps, a.warmup)
+    blocks = split_blocks(a.steps)
+    sampler = ClockSampler(local).start()
+    dt = timed(tr, a.steps, a.warmup, blocks=blocks)
+    clocks = sampler.stop(timed.t0, timed.t1)
     host_issue = issue[0]
+    # value = the MEDIAN block: the K steps run back to back exactly as the contract says, cut into >= 5
+    # blocks by HIP events on the launch stream; the whole-region figure (host clock around barrier + synchronize) stays in
+    # ``whole_region``.  Block rates are per-step rates, so blocks of unequal length compare directly.
+    per_step = sorted(ms / nb for ms, nb in zip(blocks_ms[0], blocks))
+    med_ms = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
+    repeat = {'blocks': len(blocks), 'steps_per_block': blocks,
+              'ms_per_step_blocks': [round(ms / nb, 4) for ms, nb in zip(blocks_ms[0], blocks)],
+              'ms_per_step_median': med_ms, 'ms_per_step_min': per_step[0], 'ms_per_step_max': per_step[-1],
+              'spread': (per_step[-1] - per_step[0]) / med_ms}
     calls, replays = (ops.CALLS[0] - calls0) / a.steps, (graphs.REPLAYS[0] - replays0) / a.steps
     # host cost of ISSUING one step, measured with an idle GPU in front of it: once the step is GPU-bound the number above
     # mostly measures back-pressure of the full launch queue, not host work
@@ -332,8 +505,8 @@ def main():
         comm['ms_per_step_observed'] = 1e3 * d_obs / 3
 
     out = {
-        'metric': 'images/sec G+D step, 128x128 <=8-obj scene graphs', 'value': B * world * a.steps / dt,
-        'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * dt / a.steps,
+        'metric': 'images/sec G+D step, 128x128 <=8-obj scene graphs', 'value': B * world / (med_ms * 1e-3),
+        'unit': 'images/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': med_ms,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]: COCO-Stuff-shaped %dx%d, <=8 objects/img (+__image__), batch %d '
                                'per GPU, full G+D train step (G fwd/bwd + 3 D steps + 4 Adam%s), reference default '
@@ -349,11 +522,17 @@ def main():
         # C-ABI calls (each launches 1..4 kernels) and hipGraph launches the host issues per step; the kernels inside a
         # replayed graph are dispatched by the GPU front-end without host involvement
         'host_calls_per_step': calls, 'graph_replays_per_step': replays,
+        # ``value`` / ``ms_per_step`` are the median of these back-to-back blocks of the K timed steps; ``whole_region`` is the
+        # host clock around barrier + synchronize on both sides of the same K steps (what rounds 1-5 reported as ``value``)
+        'repeat_spread': repeat['spread'], 'repeat': repeat,
+        'whole_region': {'value': B * world * a.steps / dt, 'ms_per_step': 1e3 * dt / a.steps, 'seconds': dt},
+        'clocks': clocks,
     }
     if world > 1:
         out['rccl_ranks'] = dist.get_world_size()
         out['dist_backend'] = backend
         out['allreduce'] = comm
+        out['rccl'] = rccl_info(backend)
     if rank == 0 and not a.no_prof:
         prof = ops.prof_read()
         mm = {k: v for k, v in prof.items() if v['launches'] > 0 and v['flops'] > 0 and k not in ('linear', 'head_conv')}

@@ -1913,7 +1913,11 @@ extern "C" int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const 
   const int M = d->C1, K = d->Cout;                 // rows = input channels, reduction over output channels
   const int LH = d->H * d->upsample, LW = d->W * d->upsample;
   const int refl = d->pad_reflect;
-  if (wino43_shape(d) && aligned16(gy) && aligned16(gx) && aligned16(w)) {
+  // the form is a function of the desc ALONE (the saved-operand sizes sg_conv2d_wino_{ut,v,ytp}_floats are): an unaligned operand
+  // on an F(4x4,3x3) shape is an argument error, not a silent switch to the F(2x2,3x3) layouts
+  SG_ARG_CHECK(!wino43_shape(d) || (aligned16(gy) && aligned16(gx) && aligned16(w)),
+               "sg_conv2d_wino_dgrad: F(4x4,3x3) shapes need 16-byte aligned gy / gx / w");
+  if (wino43_shape(d)) {
     // F(4x4,3x3), adjoint form: Ytp = A gy A^T, G = Ytp x U (U from the forward, x-contiguous), overlap-add of B G B^T + fold
     const int HW = d->H * d->W;
     const size_t P = (size_t)d->N * (d->H / 4) * (d->W / 4);
@@ -1999,7 +2003,9 @@ extern "C" int sg_conv2d_wino_fwd(const sgConvDesc* d, const float* x, const flo
   hipStream_t s = (hipStream_t)stream;
   const int M = d->Cout, C = d->C1;
   const int LH = d->H * d->upsample, LW = d->W * d->upsample;
-  if (wino43_shape(d) && aligned16(x) && aligned16(y) && aligned16(w)) {
+  SG_ARG_CHECK(!wino43_shape(d) || (aligned16(x) && aligned16(y) && aligned16(w)),
+               "sg_conv2d_wino_fwd: F(4x4,3x3) shapes need 16-byte aligned x / y / w");
+  if (wino43_shape(d)) {
     // F(4x4,3x3): U = G g G^T (into ut_save when the data gradient follows), V = B^T d B, 36 GEMMs, y = A^T Mx A + bias
     const int HW = d->H * d->W;
     const size_t P = (size_t)d->N * (d->H / 4) * (d->W / 4);
@@ -2047,7 +2053,9 @@ extern "C" int sg_conv2d_wino_wgrad(const sgConvDesc* d, const float* gy, const 
   const int M = d->Cout, C = d->C1;
   const int LH = d->H * d->upsample, LW = d->W * d->upsample;
   const size_t P = (size_t)d->N * (LH / 2) * (LW / 2);
-  if (wino43_shape(d) && aligned16(x) && aligned16(gy)) {
+  SG_ARG_CHECK(!wino43_shape(d) || (aligned16(x) && aligned16(gy)),
+               "sg_conv2d_wino_wgrad: F(4x4,3x3) shapes need 16-byte aligned x / gy");
+  if (wino43_shape(d)) {
     // F(4x4,3x3): T = Ytp^T x V over the tiles, gw = G^T T G; the operands come from this conv's forward / data gradient when
     // the caller kept them, else they are rebuilt here
     const int HW = d->H * d->W;

@@ -218,7 +218,11 @@ class FusedSequential(nn.Sequential):
             nxt = mods[i + 1] if i + 1 < n else None
             if isinstance(m, ReflectionPad2d) and isinstance(nxt, Conv2d):
                 nrm = mods[i + 2] if i + 2 < n else None
+                # (the fused operator IS plain InstanceNorm: an affine / running-statistics norm or a dilated conv -- both
+                #  rejected by the unfused modules' own forwards -- must reach those checks, not be computed as something else)
                 if (isinstance(nrm, InstanceNorm2d) and nxt.groups == 1
+                        and not getattr(nrm, 'affine', False) and not getattr(nrm, 'track_running_stats', False)
+                        and _pair_to_int(getattr(nxt, 'dilation', 1), 'dilation') == 1
                         and ops.conv_instnorm_fusable(x, nxt.weight, int(m.padding),
                                                       _pair_to_int(nxt.stride, 'stride'), _pair_to_int(nxt.padding, 'padding'))):
                     # pad + conv + InstanceNorm (+ act) (+ the block's residual when this is its last norm): one fused operator

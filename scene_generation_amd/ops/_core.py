@@ -63,6 +63,14 @@ def _f32(t, name='tensor'):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _al16(t):
+    """``t`` (contiguous) at a 16-byte aligned address: itself, or a copy when a view starts mid-vector.  The F(4x4,3x3) Winograd
+    entry points take float4 loads of their operands and reject unaligned pointers (the form is a function of the conv desc alone:
+    the saved-operand buffers are sized from it); torch allocations and FlatParams slices are 256-byte aligned, so the copy is for
+    odd views only."""
+    return t if t is None or (t.data_ptr() & 15) == 0 else t.clone()
+
+
 def _i64(t, name='index'):
     _dev(t, name)
     if t.dtype != torch.int64:

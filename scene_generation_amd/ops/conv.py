@@ -6,7 +6,7 @@ import torch
 from torch.autograd import Function
 
 from . import _core
-from ._core import (ACT_NONE, GradOut, _L, _call, _conv_desc, _f32, _p, _q, _stream, _wants_grad, conv_out_size,
+from ._core import (ACT_NONE, GradOut, _L, _al16, _call, _conv_desc, _f32, _p, _q, _stream, _wants_grad, conv_out_size,
     ensure_dense, hints_of, scale_, workspace)
 from .layout import (factored_layout_conv)
 
@@ -31,6 +31,8 @@ class Conv2dFn(Function):
         y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=x1.device)
         ctx.smallm = x2 is None and sparse is None and bool(_q(d, 'sg_conv2d_smallm_supported'))
         ctx.wino = (x2 is None and sparse is None and _core.WINOGRAD and bool(_q(d, 'sg_conv2d_wino_supported')))
+        if ctx.wino:                  # (float4 operand loads: a view that starts mid-vector is copied, see _al16)
+            x1, weight = _al16(x1), _al16(weight)
         ctx.head = (x2 is None and sparse is None and _core.HEADCONV and not ctx.wino and not ctx.smallm
                     and bool(_q(d, 'sg_conv2d_head_supported')))
         ctx.wino24 = (x2 is None and sparse is None and _core.WINOGRAD24 and not ctx.head and not ctx.smallm
@@ -86,6 +88,8 @@ class Conv2dFn(Function):
         d = ctx.desc
         act, slope, has_bias, grad_from = ctx.cfg
         gy = _f32(gy)
+        if ctx.wino:
+            gy = _al16(gy)
         s = _stream()
         if act != ACT_NONE:
             g2 = torch.empty_like(gy)
@@ -212,9 +216,9 @@ class ConvInstNormFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, skip, eps, act, slope):
-        x = _f32(x, 'conv input')
-        weight = _f32(weight, 'conv weight')
-        skip = None if skip is None else _f32(skip)
+        x = _al16(_f32(x, 'conv input'))               # (the fused entry points reject operands that start mid-vector: ADVICE r5)
+        weight = _al16(_f32(weight, 'conv weight'))
+        skip = None if skip is None else _al16(_f32(skip))
         N, C, H, W = x.shape
         Cout = weight.size(0)
         d = _conv_desc(N, C, 0, H, W, Cout, 3, 1, 1, True, 1, H, W, 0, 0)
@@ -246,7 +250,7 @@ class ConvInstNormFn(Function):
         x, weight, ypre, mean, rstd = ctx.saved_tensors
         d = ctx.desc
         act, slope, has_bias, has_skip = ctx.cfg
-        gout = _f32(gout)
+        gout = _al16(_f32(gout))
         s = _stream()
         dev = gout.device
         need_x = ctx.needs_input_grad[0]

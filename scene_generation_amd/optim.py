@@ -168,6 +168,9 @@ class FusedAdam:
         self._touched = [False] * len(self.fp.params)
         self._contrib = [0] * len(self.fp.params)
         self._spill_k, self._spill_dirty = [0] * len(self.fp.params), False
+        # a deferred 1 / world belongs to the gradients just cleared (a wait(defer_scale=True) whose step() never came, or a
+        # step() that raised): it must not leak into the next step, which may run without a reduce
+        self.grad_scale = 1.0
         for h in self.zero_grad_hooks:
             h()
 
@@ -175,28 +178,38 @@ class FusedAdam:
         """for callers that write gradients directly into the flat buffer (tests, custom reducers)"""
         self._touched = [True] * len(self.fp.params)
 
+    def scaled_grad(self, i=None):
+        """The gradient the coming step() will apply -- ``grad * grad_scale`` -- of parameter ``i`` (None: the whole flat buffer),
+        as a new tensor.  After a data-parallel reduce with a deferred scale (GradReducer.wait(defer_scale=True)) ``p.grad`` holds
+        the SUM over ranks and ``grad_scale`` the 1 / world; a pre_step hook registered after the reducer's (gradient clipping,
+        norm logging) reads the mean through this helper instead of the raw buffer."""
+        g = self.fp.grad if i is None else self.fp.grad_view(i)
+        return g * self.grad_scale if self.grad_scale != 1.0 else g.clone()
+
     def step(self):
-        streams.join_all(self.fp.grad.device)      # (see zero_grad)
-        self._fold_spill()
-        for h in self.pre_step_hooks:
-            h()
-        self.fp.attach_grads()
-        fp = self.fp
-        i, n = 0, len(fp.params)
-        while i < n:
-            if not self._touched[i]:
-                i += 1
-                continue
-            j, st = i, self.steps[i]
-            while j + 1 < n and self._touched[j + 1] and self.steps[j + 1] == st:
-                j += 1
-            lo, hi = fp.offsets[i], fp.offsets[j] + fp.params[j].numel()
-            ops.adam_step(fp.flat[lo:hi], fp.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
-                          self.betas[0], self.betas[1], self.eps, st + 1, self.grad_scale)
-            for q in range(i, j + 1):
-                self.steps[q] = st + 1
-            i = j + 1
-        self.grad_scale = 1.0
+        try:
+            streams.join_all(self.fp.grad.device)      # (see zero_grad)
+            self._fold_spill()
+            for h in self.pre_step_hooks:
+                h()
+            self.fp.attach_grads()
+            fp = self.fp
+            i, n = 0, len(fp.params)
+            while i < n:
+                if not self._touched[i]:
+                    i += 1
+                    continue
+                j, st = i, self.steps[i]
+                while j + 1 < n and self._touched[j + 1] and self.steps[j + 1] == st:
+                    j += 1
+                lo, hi = fp.offsets[i], fp.offsets[j] + fp.params[j].numel()
+                ops.adam_step(fp.flat[lo:hi], fp.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.lr,
+                              self.betas[0], self.betas[1], self.eps, st + 1, self.grad_scale)
+                for q in range(i, j + 1):
+                    self.steps[q] = st + 1
+                i = j + 1
+        finally:
+            self.grad_scale = 1.0          # also when a hook or a launch raised: the scale never outlives its step
 
     # ---- torch.optim.Adam-compatible (de)serialisation ----
     def state_dict(self):

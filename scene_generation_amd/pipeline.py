@@ -48,6 +48,11 @@ def segment_offsets(o2i, N):
     return off
 
 
+def threading_current():
+    import threading
+    return threading.current_thread()
+
+
 class DeviceBatchPrefetcher(object):
     """Iterates DeviceBatch objects; the H2D copies of batch k+1 are in flight (pinned memory, side stream) while the
     caller trains on batch k.
@@ -76,7 +81,9 @@ class DeviceBatchPrefetcher(object):
             import threading
             self._q = queue.Queue(maxsize=self.depth)
             self._stop = threading.Event()
-            self._thread = threading.Thread(target=self._worker, name='sg-prefetch', daemon=True)
+            import weakref
+            self._thread = threading.Thread(target=DeviceBatchPrefetcher._worker_main, name='sg-prefetch', daemon=True,
+                                            args=(weakref.ref(self), self._q, self._stop))
             self._thread.start()
 
     def _stage_one(self):
@@ -113,17 +120,38 @@ class DeviceBatchPrefetcher(object):
             dev, ev = hb, None
         return DeviceBatch(dev, objs_host, o2i, seg, N), ev
 
-    def _worker(self):
-        try:
-            if self.cuda and self.device.index is not None:
-                torch.cuda.set_device(self.device)
-            while not self._stop.is_set():
-                item = self._stage_one()
-                self._q.put(item)
-                if item is None:
+    @staticmethod
+    def _worker_main(wref, q, stop):
+        """Staging thread.  It holds the prefetcher only through a weak reference and only while it stages a batch: a consumer that
+        drops the iterator without close() lets it be collected (``__del__`` -> close()), and the worker -- which would otherwise
+        sit in a blocking put on a full queue forever, keeping the pinned slots and the source iterator alive -- sees the stop
+        flag or the dead reference within 0.1 s.  Exceptions travel to the consumer through the same bounded put."""
+        import queue
+        me = wref()
+        if me is None:
+            return
+        if me.cuda and me.device.index is not None:
+            torch.cuda.set_device(me.device)
+        del me
+        while not stop.is_set():
+            me = wref()
+            if me is None:
+                return
+            try:
+                item = me._stage_one()
+            except BaseException as e:            # re-raised in the consumer (validation errors must not vanish in a thread)
+                item = e
+            del me
+            while True:
+                if stop.is_set() or wref() is None:
                     return
-        except BaseException as e:                # re-raised in the consumer (validation errors must not vanish in a thread)
-            self._q.put(e)
+                try:
+                    q.put(item, timeout=0.1)
+                    break
+                except queue.Full:
+                    continue
+            if item is None or isinstance(item, BaseException):
+                return
 
     def _stage(self):
         item = self._stage_one()
@@ -159,8 +187,11 @@ class DeviceBatchPrefetcher(object):
         return db
 
     def close(self):
-        """stop the staging thread (it is a daemon: an abandoned iterator does not keep the process alive)"""
-        if self.threaded and self._thread is not None:
+        """stop the staging thread and release what it holds (pinned slots, the source iterator).  Call it -- or use the
+        prefetcher as a context manager -- when a loop leaves early (``break`` at max iterations): the worker reads up to
+        depth + 1 batches ahead of the consumer, and those batches are consumed from the source."""
+        th = self._thread
+        if self.threaded and th is not None:
             self._stop.set()
             try:
                 while True:
@@ -168,3 +199,18 @@ class DeviceBatchPrefetcher(object):
             except Exception:
                 pass
             self._thread = None
+            if th is not threading_current():
+                th.join(timeout=2.0)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

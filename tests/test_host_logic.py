@@ -510,6 +510,103 @@ def test_threaded_prefetcher_order_and_error_propagation():
         next(it)
 
 
+def test_abandoned_prefetcher_releases_its_worker_and_source():
+    """the staging thread reads depth + 1 batches ahead; a consumer that stops early must not leave it parked in a
+    blocking put forever.  Dropping the iterator (or leaving its ``with`` block, or close()) ends the thread within a fraction of
+    a second; an exception raised by the source while the queue is FULL still reaches the consumer."""
+    import gc
+    import threading
+    import time
+    from scene_generation_amd.pipeline import DeviceBatchPrefetcher
+    from scene_generation_amd.synthetic import make_batch
+    hbs = [make_batch(N=2, min_objs=2, max_objs=3, size=16, mask_size=4, seed=s) for s in range(8)]
+
+    def workers():
+        return [t for t in threading.enumerate() if t.name == 'sg-prefetch' and t.is_alive()]
+
+    def wait_gone():
+        for _ in range(40):
+            if not workers():
+                return True
+            time.sleep(0.05)
+        return False
+
+    assert wait_gone()
+    p = DeviceBatchPrefetcher(hbs, 'cpu', threaded=True, depth=1)
+    next(p)
+    time.sleep(0.2)                       # the worker is now blocked on the full queue, two batches ahead
+    assert workers()
+    del p
+    gc.collect()
+    assert wait_gone(), 'an abandoned prefetcher kept its staging thread'
+    with DeviceBatchPrefetcher(hbs, 'cpu', threaded=True, depth=1) as q:
+        next(q)
+        assert workers()
+    assert wait_gone()
+
+    def bad_source():
+        yield hbs[0]
+        yield hbs[1]
+        raise RuntimeError('loader died')
+    it = DeviceBatchPrefetcher(bad_source(), 'cpu', threaded=True, depth=1)
+    time.sleep(0.3)                       # queue full (batch 0), the worker holds batch 1 and then hits the exception
+    next(it)
+    next(it)
+    with pytest.raises(RuntimeError, match='loader died'):
+        next(it)
+    assert wait_gone()
+
+
+def test_deferred_grad_scale_never_outlives_its_step():
+    """FusedAdam.grad_scale (the 1 / world a data-parallel reduce hands over instead of scaling 765 MB) is reset by
+    zero_grad() and by a step() that raises -- a later step without a reduce must see 1.0 -- and ``scaled_grad`` shows a hook the
+    gradient the step will apply."""
+    from scene_generation_amd import ops
+    from scene_generation_amd.optim import FusedAdam
+    m = fill_deterministic(torch.nn.Linear(4, 3))
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    m(torch.ones(2, 4)).sum().backward()
+    opt.grad_scale = 0.125
+    g = opt.fp.grad.clone()
+    assert torch.allclose(opt.scaled_grad(), g * 0.125) and torch.allclose(opt.scaled_grad(0), opt.fp.grad_view(0) * 0.125)
+    fill = ops.fill_
+    ops.fill_ = lambda t, v: t.fill_(v)              # (the device fill of zero_grad(): host bookkeeping is what is tested here)
+    try:
+        opt.zero_grad()
+    finally:
+        ops.fill_ = fill
+    assert opt.grad_scale == 1.0
+    m(torch.ones(2, 4)).sum().backward()
+    opt.grad_scale = 0.5
+
+    def boom():
+        raise RuntimeError('hook failed')
+    opt.pre_step_hooks.append(boom)
+    with pytest.raises(RuntimeError, match='hook failed'):
+        opt.step()
+    assert opt.grad_scale == 1.0
+
+
+def test_fused_conv_instnorm_is_not_taken_for_affine_or_tracking_norms():
+    """FusedSequential fuses ReflectionPad2d + Conv2d + InstanceNorm2d only for the plain (affine=False, no running
+    statistics) norm; any other InstanceNorm2d must reach the module's own forward (which rejects it) instead of being
+    computed as plain InstanceNorm.  Checked on the fusion predicate's host side: with an affine norm the fusable query is
+    never consulted."""
+    from scene_generation_amd import layers, ops
+    calls = []
+    orig = ops.conv_instnorm_fusable
+    ops.conv_instnorm_fusable = lambda *a, **k: calls.append(1) or False
+    try:
+        for kw, consulted in ((dict(), True), (dict(affine=True), False), (dict(track_running_stats=True), False)):
+            del calls[:]
+            seq = layers.FusedSequential(layers.ReflectionPad2d(1), layers.Conv2d(4, 4, 3), layers.InstanceNorm2d(4, **kw))
+            with pytest.raises(Exception):          # CPU tensors: whatever runs next fails loudly (no CPU compute path)
+                seq(torch.zeros(1, 4, 8, 8))
+            assert bool(calls) == consulted, kw
+    finally:
+        ops.conv_instnorm_fusable = orig
+
+
 def test_winograd_f43_matrices_in_the_kernel_source_satisfy_the_identities():
     """The F(4x4,3x3) transform matrices as WRITTEN in csrc/igemm.hip (w43_bt / w43_g / w43_at), parsed from the source: forward
     y = A^T [(G g G^T) (.) (B^T d B)] A equals the 3x3 correlation of a 6x6 patch, and the data / weight gradient forms the kernels
