@@ -136,8 +136,22 @@ def batch_to(batch, device):
 # shipping weights.
 # ----------------------------------------------------------------------------------------------
 
+# optional memo {(numel, salt): pattern} of the large fill patterns: a test session that fills many full-width models sets this
+# to a dict (tests/conftest.py) and pays the int64 hash of a 183 M-parameter generator once instead of once per Trainer
+HASH_CACHE = None
+
+
 def _hash_uniform(numel, salt):
     """u in [-0.5, 0.5): 32-bit multiplicative hash of the element index, int64-exact."""
+    if HASH_CACHE is not None and numel >= 65536:
+        hit = HASH_CACHE.get((numel, salt))
+        if hit is None:
+            hit = HASH_CACHE[(numel, salt)] = _hash_uniform_compute(numel, salt)
+        return hit
+    return _hash_uniform_compute(numel, salt)
+
+
+def _hash_uniform_compute(numel, salt):
     idx = torch.arange(numel, dtype=torch.int64)
     x = (idx * 2654435761 + (salt + 1) * 40503 * 65537) & 0xFFFFFFFF
     x = (x ^ (x >> 15)) * 2246822519 & 0xFFFFFFFF

@@ -33,3 +33,36 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
     return load
+
+
+def pytest_sessionstart(session):
+    # fill_deterministic's closed-form patterns are functions of (numel, name hash): computed once per session
+    from scene_generation_amd import synthetic
+    if synthetic.HASH_CACHE is None:
+        synthetic.HASH_CACHE = {}
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def skip_random_init():
+    """Construct modules WITHOUT their random initialisation (for objects whose every parameter is overwritten right after
+    construction by fill_deterministic / load_state_dict): the normal / uniform draws of a 183 M-parameter generator cost ~8 s
+    per Trainer on the host and the full-size step tests build a dozen of them."""
+    import torch
+    import torch.nn.init as I
+    names = ['kaiming_normal_', 'kaiming_uniform_', 'normal_', 'uniform_', 'xavier_uniform_', 'xavier_normal_', 'trunc_normal_',
+             'orthogonal_']
+    saved = {n: getattr(I, n) for n in names if hasattr(I, n)}
+    tn, tu = torch.Tensor.normal_, torch.Tensor.uniform_
+    for n in saved:
+        setattr(I, n, lambda t, *a, **k: t)
+    torch.Tensor.normal_ = lambda self, *a, **k: self
+    torch.Tensor.uniform_ = lambda self, *a, **k: self
+    try:
+        yield
+    finally:
+        for n, f in saved.items():
+            setattr(I, n, f)
+        torch.Tensor.normal_, torch.Tensor.uniform_ = tn, tu

@@ -119,7 +119,10 @@ def test_two_rank_hip_trainer_matches_sequential_shards(backend):
         assert np.array_equal(res[0][2][n], res[1][2][n]), '%s: ranks diverged after two steps' % n
 
 
-@pytest.mark.parametrize('world,per_gpu,steps', [(2, 8, 2), (8, 2, 1)])
+# (round 6: the two-rank case ran batch 8 per rank for 2 timed steps and took 444 s of an 1100 s suite on one box of the pool --
+#  two full-width processes time-slicing one GPU spend ~35 s per step; it now runs the same 13-step protocol at batch 2 like the
+#  eight-rank case, still with the per-launch profiler pass that only it covers)
+@pytest.mark.parametrize('world,per_gpu,steps', [(2, 2, 1), (8, 2, 1)])
 def test_bench_dp_leg_executes_two_ranks_on_one_gpu(world, per_gpu, steps):
     """bench.py's multi-GPU leg exactly as the driver launches it (``python -m torch.distributed.run --nproc-per-node N bench.py
     --gpus N``), with N = 2 and N = 8 ranks sharing this box's one GPU over gloo (SG_DIST_BACKEND=gloo SG_SHARE_GPU=1):
@@ -135,7 +138,7 @@ def test_bench_dp_leg_executes_two_ranks_on_one_gpu(world, per_gpu, steps):
            str(steps), '--warmup', '3', '--batch_per_gpu', str(per_gpu), '--no_secondary', '--no_legs', '--cpu_baseline', 'off']
     if world > 2:
         cmd.append('--no_prof')            # (eight ranks time-slice one GPU: the per-launch event pass adds nothing here)
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, 'bench.py --gpus %d failed:\n%s\n%s' % (world, r.stdout[-3000:], r.stderr[-6000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
     assert len(lines) == 1, 'exactly ONE JSON line from rank 0, got %d:\n%s' % (len(lines), r.stdout[-3000:])
@@ -148,9 +151,15 @@ def test_bench_dp_leg_executes_two_ranks_on_one_gpu(world, per_gpu, steps):
     except OSError:
         pass
     assert out['n_gpus'] == world and out['rccl_ranks'] == world and out['dist_backend'] == 'gloo'
-    assert out['scaling'] == 'weak' and out['config']['global_batch'] == 16 and out['config']['parallelism'] == 'dp%d' % world
+    assert out['scaling'] == 'weak' and out['config']['global_batch'] == per_gpu * world and out['config']['parallelism'] == 'dp%d' % world
     assert out['steps'] == steps and out['warmup'] == 3 and out['value'] > 0 and out['ms_per_step'] > 0
-    assert abs(out['value'] - 16 * steps / (out['ms_per_step'] * steps * 1e-3)) < 1e-6 * out['value']   # whole-job images / max-rank time
+    # ``value`` = whole-job images per second of the median timing block (max over ranks per block); the whole-region figure
+    # (barrier + synchronize on both sides, max over ranks) rides along
+    assert abs(out['value'] - per_gpu * world / (out['ms_per_step'] * 1e-3)) < 1e-6 * out['value']
+    assert out['repeat']['blocks'] == min(5, steps) and sum(out['repeat']['steps_per_block']) == steps
+    wr = out['whole_region']
+    assert abs(wr['value'] - per_gpu * world * steps / wr['seconds']) < 1e-6 * wr['value'] and wr['ms_per_step'] > 0
+    assert out['rccl']['backend'] == 'gloo' and 'torch_cuda_nccl_version' in out['rccl']
     ar = out['allreduce']
     assert ar['world'] == world
     # 764.7 MB of generator gradient in 64 MB buckets that close at parameter boundaries: 10 of them
