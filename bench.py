@@ -226,9 +226,10 @@ def cpu_baseline(image_size, n_images, n_steps):
 
 PMC_KERNELS = {
     # profiler kind -> regex of the kernel symbol (the two dense Winograd instantiations: stores at the top / interleaved)
-    'wino_bgemm_t128': r'igemm_kernel.*TileCfg<128, 128, 2, 2, [12]>.*EpRowMajorPlain',
+    'wino_bgemm_t128': r'igemm_kernel.*TileCfg<128, 128, 2, 2, [12](?:, \d+)?>.*EpRowMajorPlain',
     # the three 64x64-tile instantiations of the F(4x4,3x3) GEMMs (forward, data gradient, weight gradient)
-    'wino43_bgemm_t64': r'igemm_kernel.*TileCfg<64, 64, 2, 2, 2>.*EpRowMajorPlain',
+    # (16- or 32-deep k-tiles, with or without the chunked channel sum: TileCfg<64, 64, 2, NSUB, 2, KFOLD>)
+    'wino43_bgemm_t64': r'igemm_kernel.*TileCfg<64, 64, 2, [12], 2(?:, \d+)?>.*EpRowMajorPlain',
 }
 
 
@@ -325,6 +326,9 @@ KERNEL_INSTANTIATIONS = {
 
 def main():
     a = parse()
+    if os.environ.get('SG_BENCH_STACKS'):          # debugging aid: dump every thread's stack to stderr every N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ['SG_BENCH_STACKS']), repeat=True)
     # the host driver only supports dmabuf IPC: RCCL / cross-process tensor sharing fails without it (set before HIP starts)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -459,7 +463,8 @@ def main():
     # host cost of ISSUING one step, measured with an idle GPU in front of it: once the step is GPU-bound the number above
     # mostly measures back-pressure of the full launch queue, not host work
     iso = []
-    for i in range(3):
+    quick = os.environ.get('SG_BENCH_QUICK') == '1'      # test harnesses: one isolated / one observed step instead of three
+    for i in range(1 if quick else 3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         one_step(tr, a.warmup + a.steps + i)
@@ -482,7 +487,8 @@ def main():
         comm = {'world': world}
         for r in tr.reducers:
             r.profile = True
-        d_obs = timed(tr, 3, a.warmup + 2 * a.steps + 3)
+        n_obs = 1 if quick else 3
+        d_obs = timed(tr, n_obs, a.warmup + 2 * a.steps + 3)
         names = {id(tr.optimizer): 'G', id(tr.optimizer_d_img): 'D_img', id(tr.optimizer_d_obj): 'D_obj',
                  id(tr.optimizer_d_mask): 'D_mask'}
         iso_total, exposed_total = 0.0, 0.0
@@ -492,17 +498,17 @@ def main():
             buckets = r.time_buckets()
             iso_ms = sum(ms for _, ms in buckets)
             iso_total += iso_ms
-            exposed_total += exp_ms / 3
+            exposed_total += exp_ms / n_obs
             comm[names.get(id(r.optimizer), '?')] = {
                 'buckets': len(buckets), 'bytes': sum(b for b, _ in buckets), 'overlap_mode': bool(r.overlap),
                 'isolated_allreduce_ms': round(iso_ms, 3),
                 'per_bucket_ms': [round(ms, 3) for _, ms in buckets],
                 'algbw_GBps': round(sum(b for b, _ in buckets) / (iso_ms * 1e-3) / 1e9, 1) if iso_ms > 0 else None,
-                'exposed_ms_per_step': round(exp_ms / 3, 3)}
+                'exposed_ms_per_step': round(exp_ms / n_obs, 3)}
         comm['exposed_ms_per_step'] = round(exposed_total, 3)
         comm['isolated_ms_per_step'] = round(iso_total, 3)
         comm['overlap_fraction'] = round(1.0 - exposed_total / iso_total, 3) if iso_total > 0 else None
-        comm['ms_per_step_observed'] = 1e3 * d_obs / 3
+        comm['ms_per_step_observed'] = 1e3 * d_obs / n_obs
 
     out = {
         'metric': 'images/sec G+D step, 128x128 <=8-obj scene graphs', 'value': B * world / (med_ms * 1e-3),

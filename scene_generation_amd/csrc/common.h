@@ -70,6 +70,7 @@ enum SgOpt {
   SG_OPT_W24_GEMM_TILE,   // tile of the F(2x2,4x4) GEMMs (K = 256 / 512): 2 = 64x64 (measured 2.03 vs 2.14 ms/step on 128x128), 0, 1
   SG_OPT_WINO_IN_FUSE,    // F(4x4,3x3) conv + InstanceNorm: output transform + norm in one launch, norm backward + gradient transform in one
   SG_OPT_W43_NSUB,        // k-tile depth (x16) of the F(4x4,3x3) GEMMs: 1 = 16-deep (default: 20 KB of LDS, 7 workgroups per CU; measured +0.5 % on the step), 2 = 32-deep
+  SG_OPT_W43_KFOLD,       // F(4x4,3x3) forward / data-gradient GEMMs: accumulate the channel sum in chunks of this many k (256 / 128; 0 = one fma chain): see TileCfg::KFOLD
   SG_OPT_COUNT
 };
 extern std::atomic<int> g_sg_opt[SG_OPT_COUNT];

@@ -851,6 +851,20 @@ using CfgDI64 = TileCfg<64, 64, 2, 2, 2>;
 // 16-deep k-tiles: 20 KB of LDS per workgroup instead of 40 -- the 1152 workgroups of an F(4x4,3x3) GEMM (4.5 per CU) are then
 // all resident at once (32-deep: 4 per CU by LDS = 1024 slots, the other 128 run as a second, nearly empty round)
 using CfgDI64S = TileCfg<64, 64, 2, 1, 2>;
+// ... with the channel sum accumulated in chunks (TileCfg::KFOLD): the F(4x4,3x3) forward / data-gradient GEMMs (w43_kfold)
+using CfgDI64F256 = TileCfg<64, 64, 2, 2, 2, 256>;
+using CfgDI64SF256 = TileCfg<64, 64, 2, 1, 2, 256>;
+using CfgDI64F128 = TileCfg<64, 64, 2, 2, 2, 128>;
+using CfgDI64SF128 = TileCfg<64, 64, 2, 1, 2, 128>;
+// kfold (0 / 128 / 256) x k-tile depth -> one of the six 64x64 instantiations
+template <class AL, class BL>
+int launch_w43(const AL& al, const BL& bl, const EpRowMajorPlain& ep, int M, int N, int K, hipStream_t s) {
+  const int kf = (K > 256 || (K > 128 && sg_opt(SG_OPT_W43_KFOLD) == 128)) ? sg_opt(SG_OPT_W43_KFOLD) : 0;
+  const bool deep = sg_opt(SG_OPT_W43_NSUB) != 1;
+  if (kf == 256) return deep ? launch_cfg<CfgDI64F256>(al, bl, ep, M, N, K, 1, s) : launch_cfg<CfgDI64SF256>(al, bl, ep, M, N, K, 1, s);
+  if (kf == 128) return deep ? launch_cfg<CfgDI64F128>(al, bl, ep, M, N, K, 1, s) : launch_cfg<CfgDI64SF128>(al, bl, ep, M, N, K, 1, s);
+  return deep ? launch_cfg<CfgDI64>(al, bl, ep, M, N, K, 1, s) : launch_cfg<CfgDI64S>(al, bl, ep, M, N, K, 1, s);
+}
 void wino_bgemm_tile(int tile, const float* A, const float* B, float* Cout, int M, int cols, int K, double flops, hipStream_t s, int NB,
                      int kind = SG_K_OTHER) {
   sgk::t_alg_bytes = 4.0 * NB * ((double)M * K + (double)cols * K + (double)M * cols);
@@ -860,6 +874,9 @@ void wino_bgemm_tile(int tile, const float* A, const float* B, float* Cout, int 
     if (tile == 1)
       launch_cfg<CfgDI64W>(LoadKContig<64, true, false>{A, K, M}, LoadKContig<128, true, false>{B, K, NB * cols},
                            EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
+    else if ((tile == 2 || tile == 3) && kind == SG_K_WINO43_GEMM)        // F(4x4,3x3) forward: chunked channel sum (w43_kfold)
+      launch_w43(LoadKContig<64, true, false>{A, K, M}, LoadKContig<64, true, false>{B, K, NB * cols},
+                 EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, s);
     else if (tile == 2)
       launch_cfg<CfgDI64>(LoadKContig<64, true, false>{A, K, M}, LoadKContig<64, true, false>{B, K, NB * cols},
                           EpRowMajorPlain{Cout, NB * cols}, M, NB * cols, K, 1, s);
@@ -1470,10 +1487,7 @@ void w43_gemm_dgrad(const float* Ytp, const float* U, float* G, int P, int C, in
   t_batch.batch_major = 1;
   {
     SgProfScope prof(SG_K_WINO43_GEMM, s, 2.0 * 36.0 * P * (double)C * K, 0);
-    if (sg_opt(SG_OPT_W43_NSUB) == 1)
-      launch_cfg<CfgDI64S>(LoadKContig<64, true, false>{Ytp, K, P}, LoadXContigS<64>{U, C, C}, EpRowMajorPlain{G, 36 * C}, P, 36 * C, K, 1, s);
-    else
-      launch_cfg<CfgDI64>(LoadKContig<64, true, false>{Ytp, K, P}, LoadXContigS<64>{U, C, C}, EpRowMajorPlain{G, 36 * C}, P, 36 * C, K, 1, s);
+    launch_w43(LoadKContig<64, true, false>{Ytp, K, P}, LoadXContigS<64>{U, C, C}, EpRowMajorPlain{G, 36 * C}, P, 36 * C, K, s);
   }
   t_batch = BatchInfo{};
 }
@@ -1843,7 +1857,9 @@ extern "C" int sg_batched_gemm_nt(const float* a, const float* b, float* c, int 
   SG_ARG_CHECK(M % bm == 0 && cols % bn == 0 && K % 32 == 0, "sg_batched_gemm_nt: M, cols, K must be multiples of the tile (%d, %d, 32)", bm, bn);
   SG_ARG_CHECK(aligned16(a) && aligned16(b) && aligned16(c), "sg_batched_gemm_nt: operands must be 16-byte aligned");
   SG_ARG_CHECK((double)nbatch * M * K < SG_MAX_ELEMS && (double)nbatch * cols * K < SG_MAX_ELEMS, "sg_batched_gemm_nt: operand too large");
-  wino_bgemm_tile(tile, a, b, c, M, cols, K, 2.0 * nbatch * (double)M * cols * K, (hipStream_t)stream, nbatch);
+  // (the 64x64 tiles are the F(4x4,3x3) GEMMs: same launch path, incl. the chunked channel sum selected by w43_kfold)
+  wino_bgemm_tile(tile, a, b, c, M, cols, K, 2.0 * nbatch * (double)M * cols * K, (hipStream_t)stream, nbatch,
+                  tile >= 2 ? SG_K_WINO43_GEMM : SG_K_OTHER);
   SG_LAUNCH_CHECK("sg_batched_gemm_nt");
   return 0;
 }

@@ -87,9 +87,18 @@ constexpr int BK = 16;     // sub-tile depth: the unit one loader call stages (1
 #define SG_PIPE_DEFAULT 2      // main loop of every instantiation: 0 = plain; 1 = software-pipelined fragment reads (measured on
 #endif                         // MI355X: 648 -> 660 images/s, every family +1..6 %); 2 = 1 + the LDS stores of the next tile
                                // interleaved with the MFMAs of phase 0 (855 -> 859 images/s, profiles/r04_ab_sessions.md)
-template <int BM_, int BN_, int WGM_, int NSUB_, int PIPE_ = SG_PIPE_DEFAULT>
+// KFOLD > 0 (pipelined loop only): the k-sum is accumulated in CHUNKS of KFOLD elements -- every KFOLD k the MFMA accumulator is
+// added into a second register set and cleared, the chunks meet in ascending order.  The fp32 rounding error of a length-K fma
+// chain grows like K; in the transformed domain of Winograd F(4x4,3x3) the running sums are large against the output the
+// inverse transform extracts from them, and that accumulation error is what dominated the form's conv-level error (round 6
+// study with tools/winograd_f43.py: all-fp32 3.9e-6 of max|y| at K = 1024, 2.5e-6 with 256-chunks, 1.4e-6 with 128-chunks,
+// 0.6e-6 with an fp64 accumulator; transforms in fp64 instead: no change).  Cost: 2 x 16 vector-ALU instructions per wave and
+// chunk boundary and 16 more registers per 32x32 accumulator.  Deterministic; the order is a function of K alone.
+template <int BM_, int BN_, int WGM_, int NSUB_, int PIPE_ = SG_PIPE_DEFAULT, int KFOLD_ = 0>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = 4 / WGM_, NSUB = NSUB_, BKT = BK * NSUB_, PIPE = PIPE_;
+  static constexpr int KFOLD = KFOLD_;
+  static_assert(KFOLD_ == 0 || (PIPE_ != 0 && KFOLD_ % (BK * NSUB_) == 0), "KFOLD: whole k-tiles of the pipelined loop");
   static constexpr int WM = BM / WGM, WN = BN / WGN;
   static constexpr int TM = WM / 32, TN = WN / 32;
   static constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -1245,8 +1254,29 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     // loaders that keep per-tile tap tables in LDS: the entries prefetch() just wrote are read by load() at the top of the
     // first iteration (later iterations have the mid-iteration barrier in between)
     if (AL::LDS_INTS > 0 || BL::LDS_INTS > 0) __syncthreads();
+    constexpr bool FOLD = CFG::KFOLD > 0;
+    f32x16 acc2[FOLD ? TM : 1][FOLD ? TN : 1];
+    if constexpr (FOLD) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+    }
     for (int k0 = kbeg; k0 < kend; k0 += BKT) {
       const bool more1 = k0 + BKT < kend, more2 = k0 + 2 * BKT < kend;
+      if constexpr (FOLD) {
+        // chunk boundary (wave-uniform): at the top of an iteration ``acc`` holds exactly the products of [chunk start, k0)
+        if (k0 > kbeg && ((k0 - kbeg) % CFG::KFOLD) == 0) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) { acc2[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+        }
+      }
       // PIPE == 2 (dense Winograd GEMMs): the LDS stores of the next tile do not sit in front of the iteration's first MFMA
       // (8 ds_write_b128 = ~100 cycles during which this wave feeds nothing to the matrix pipe) but BETWEEN the MFMAs of phase 0,
       // one store call after each group of four: a 64-cycle MFMA covers the 13 cycles a store takes to issue.  The global loads
@@ -1301,6 +1331,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
       __builtin_amdgcn_sched_barrier(0);
       mma(fa[(P - 1) & 1], fb[(P - 1) & 1]);
       buf ^= 1;
+    }
+    if constexpr (FOLD) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = acc2[i][j][r] + acc[i][j][r];
     }
     rowsum_finish(al, zblk);
     ep.store(acc, m0 + wm0, n0 + wn0, lane, zblk);

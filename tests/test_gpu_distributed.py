@@ -119,9 +119,11 @@ def test_two_rank_hip_trainer_matches_sequential_shards(backend):
         assert np.array_equal(res[0][2][n], res[1][2][n]), '%s: ranks diverged after two steps' % n
 
 
-# (round 6: the two-rank case ran batch 8 per rank for 2 timed steps and took 444 s of an 1100 s suite on one box of the pool --
-#  two full-width processes time-slicing one GPU spend ~35 s per step; it now runs the same 13-step protocol at batch 2 like the
-#  eight-rank case, still with the per-launch profiler pass that only it covers)
+# (round 6: the two-rank case ran batch 8 per rank for 2 timed steps and took 444 s of an 1100 s suite on one box of the pool: with
+#  two ranks on one GPU every step sits ~20 s in gloo's waits for the 765 MB of gradient buckets (stack dumps, SG_BENCH_STACKS;
+#  the isolated all-reduces take 0.23 s, eight ranks 1.3 s per step) -- an artefact of gloo on a shared device, nothing RCCL
+#  shares.  The eight-rank case now carries the per-launch profiler pass; the two-rank case runs the protocol at its minimum:
+#  batch 2, one timed / isolated / observed step, no profiler pass)
 @pytest.mark.parametrize('world,per_gpu,steps', [(2, 2, 1), (8, 2, 1)])
 def test_bench_dp_leg_executes_two_ranks_on_one_gpu(world, per_gpu, steps):
     """bench.py's multi-GPU leg exactly as the driver launches it (``python -m torch.distributed.run --nproc-per-node N bench.py
@@ -136,8 +138,9 @@ def test_bench_dp_leg_executes_two_ranks_on_one_gpu(world, per_gpu, steps):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr',
            '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps',
            str(steps), '--warmup', '3', '--batch_per_gpu', str(per_gpu), '--no_secondary', '--no_legs', '--cpu_baseline', 'off']
-    if world > 2:
-        cmd.append('--no_prof')            # (eight ranks time-slice one GPU: the per-launch event pass adds nothing here)
+    if world == 2:
+        cmd.append('--no_prof')
+        env['SG_BENCH_QUICK'] = '1'
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, 'bench.py --gpus %d failed:\n%s\n%s' % (world, r.stdout[-3000:], r.stderr[-6000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
@@ -168,5 +171,5 @@ def test_bench_dp_leg_executes_two_ranks_on_one_gpu(world, per_gpu, steps):
         assert ar[name]['buckets'] >= 1 and ar[name]['isolated_allreduce_ms'] > 0
     assert ar['overlap_fraction'] is not None and ar['overlap_fraction'] == ar['overlap_fraction']      # finite, not NaN
     assert ar['isolated_ms_per_step'] > 0 and ar['exposed_ms_per_step'] >= 0
-    if world == 2:
+    if world == 8:
         assert 'roofline' in out and out['roofline']['frac'] > 0

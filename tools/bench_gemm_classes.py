@@ -159,9 +159,11 @@ def main():
         base = [sys.executable, here, '--iters', '2', '--pass', a.passes] + (['--only', a.only] if a.only else [])
         for o in a.opt:
             base += ['--opt', o]
-        groups = ['SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES',
-                  'SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT '
-                  'SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM']
+        # pass 0: instruction mix (tools/pmc_raw_summary.py); pass 1: where the wave cycles go + MFMA pipe busy
+        # (tools/pmc_sq_db_summary.py expects exactly this set)
+        groups = ['SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT',
+                  'SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES '
+                  'SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU']
         for i, gsel in enumerate(groups):
             d = os.path.join(os.path.abspath(a.pmc), 'pass%d' % i)
             cmd = ['rocprofv3', '--pmc'] + gsel.split() + ['--kernel-trace', '-d', d, '-o', 'pmc', '--'] + base

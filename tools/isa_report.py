@@ -54,7 +54,7 @@ def demangle(names):
 
 def _short(n):
     n = re.sub(r'\((?:[^()]|\([^()]*\))*\)$', '', n)          # drop the argument list
-    return re.sub(r'TileCfg<(\d+), (\d+), \d+, \d+(?:, \d+)?>', r'T\1x\2', n)
+    return re.sub(r'TileCfg<(\d+), (\d+), \d+, \d+(?:, \d+)*>', r'T\1x\2', n)
 
 
 def kernels_of(elf):

@@ -13,7 +13,7 @@ def short(n):
     n = n.replace('(anonymous namespace)::', '')
     m = re.match(r'void igemm_kernel<(.*)>\(', n)
     if m:
-        return 'igemm<' + re.sub(r'TileCfg<(\d+), (\d+), \d+, \d+(?:, \d+)?>', r'T\1x\2', m.group(1))[:104] + '>'
+        return 'igemm<' + re.sub(r'TileCfg<(\d+), (\d+), \d+, \d+(?:, \d+)*>', r'T\1x\2', m.group(1))[:104] + '>'
     return re.sub(r'\(.*', '', n).replace('void ', '')[:80]
 
 
