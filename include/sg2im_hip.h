@@ -147,9 +147,11 @@ int sg_conv2d_wino_dgrad(const sgConvDesc* d, const float* gy, const float* w, f
  * channels multiples of 128, tile count a multiple of 64):
  *   forward : output transform + bias + InstanceNorm + activation + skip in one launch; ypre = the conv result (kept for the
  *             backward), out = act((ypre - mean) * rstd) + skip, mean / rstd [N * Cout]
- *   backward: InstanceNorm's backward and the gradient transform in one launch (gconv = the conv's gy: its bias gradient is
- *             sg_channel_sum(gconv), its weight gradient sg_conv2d_wino_wgrad(d, gconv, x, gw, v_saved, ytp_saved)); gx is
- *             computed when non-NULL.  ut_save / v_save / ytp_save as in sg_conv2d_wino_fwd / _dgrad.
+ *   backward: InstanceNorm's backward and the gradient transform in one launch (gconv = the conv's gy: its weight gradient
+ *             is sg_conv2d_wino_wgrad(d, gconv, x, gw, v_saved, ytp_saved)); gx is computed when non-NULL; gb [Cout], when
+ *             non-NULL, receives the conv's bias gradient = sum of gconv over images and pixels (per-image plane sums from the
+ *             same launch, added over the images in ascending order by one small launch; NULL: the caller runs
+ *             sg_channel_sum(gconv)).  ut_save / v_save / ytp_save as in sg_conv2d_wino_fwd / _dgrad.
  * Same arithmetic as sg_conv2d_wino_fwd + sg_instnorm_fwd / sg_instnorm_bwd + sg_conv2d_wino_dgrad up to the order of the
  * per-plane sums. */
 int sg_conv2d_wino_in_supported(const sgConvDesc* d);
@@ -157,8 +159,8 @@ int sg_conv2d_wino_fwd_instnorm(const sgConvDesc* d, const float* x, const float
                                 float* ypre, float* out, float* mean, float* rstd, float eps, int act, float slope,
                                 float* ut_save, float* v_save, void* ws, size_t ws_bytes, sgStream stream);
 int sg_conv2d_wino_dgrad_instnorm(const sgConvDesc* d, const float* gout, const float* ypre, const float* mean, const float* rstd,
-                                  int act, float slope, const float* w, float* gconv, float* gx, const float* ut_saved,
-                                  float* ytp_save, void* ws, size_t ws_bytes, sgStream stream);
+                                  int act, float slope, const float* w, float* gconv, float* gx, float* gb,
+                                  const float* ut_saved, float* ytp_save, void* ws, size_t ws_bytes, sgStream stream);
 /* The GEMM stage of the Winograd convs on its own (the transforms of layers.py:251-270's convs aside):
  *   c[m][z*cols + j] = sum_k a[z][m][k] * b[z*cols + j][k],   z < nbatch   (both operands K-contiguous, fp32 MFMA)
  * tile: 0 = 128x128, 1 = 64x128, 2 = 64x64, 3 = 64x64 with 16-deep k-tiles; M, cols multiples of the tile, K of 32.  Exposed for

@@ -71,6 +71,9 @@ enum SgOpt {
   SG_OPT_WINO_IN_FUSE,    // F(4x4,3x3) conv + InstanceNorm: output transform + norm in one launch, norm backward + gradient transform in one
   SG_OPT_W43_NSUB,        // k-tile depth (x16) of the F(4x4,3x3) GEMMs: 1 = 16-deep (default: 20 KB of LDS, 7 workgroups per CU; measured +0.5 % on the step), 2 = 32-deep
   SG_OPT_W43_KFOLD,       // F(4x4,3x3) forward / data-gradient GEMMs: accumulate the channel sum in chunks of this many k (256 / 128; 0 = one fma chain): see TileCfg::KFOLD
+  SG_OPT_WAVE_PRIO,       // GEMM kernels: s_setprio 3 outside the main loop (prologue / epilogue VALU work does not queue behind other waves' MFMAs).
+                          // OFF: measured on MI355X, profiles/r06_gemm_prio.md -- most classes +-1 %, Gup4 fwd +11 %, F(4x4,3x3) dgrad / wgrad +7 %, step -0.3 %
+  SG_OPT_PAR_XCD_CHUNK,   // parity-class launches: tiles dealt to the XCDs in chunks of this many (power of two; 0 = one contiguous eighth per XCD)
   SG_OPT_COUNT
 };
 extern std::atomic<int> g_sg_opt[SG_OPT_COUNT];

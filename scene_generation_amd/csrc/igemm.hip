@@ -1390,8 +1390,8 @@ __global__ void __launch_bounds__(256) w43_output_in_kernel(const float* __restr
 // of channel c.  gconv is written too (the bias gradient and a weight gradient without saved operands read it).
 __global__ void __launch_bounds__(256) w43_gy_in_kernel(const float* __restrict__ gout, const float* __restrict__ ypre,
                                                        const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
-                                                       float* __restrict__ gconv, float* __restrict__ Ytp, int N, int M, int H, int W,
-                                                       int act, float slope) {
+                                                       float* __restrict__ gconv, float* __restrict__ Ytp, float* __restrict__ gb_part,
+                                                       int N, int M, int H, int W, int act, float slope) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int HW = H * W, pitch = HW + 1, TH = H / 4, TW = W / 4, NT = TH * TW;
   const int n = blockIdx.y, c0 = blockIdx.x * 64, tid = threadIdx.x, c = tid & 63, g = tid >> 6;
@@ -1425,6 +1425,7 @@ __global__ void __launch_bounds__(256) w43_gy_in_kernel(const float* __restrict_
   const float m1 = (((red[c] + red[64 + c]) + red[128 + c]) + red[192 + c]) * inv;
   const float m2 = (((red[256 + c] + red[320 + c]) + red[384 + c]) + red[448 + c]) * inv;
   const size_t P = (size_t)N * NT;
+  float sb = 0.f;                                   // this thread's share of the plane sum of the conv's gy (= bias gradient)
   for (int t = g; t < NT; t += 4) {
     const int ti = t / TW, tj = t - ti * TW;
     float gt[4][4];
@@ -1437,6 +1438,7 @@ __global__ void __launch_bounds__(256) w43_gy_in_kernel(const float* __restrict_
         const float gp = gc[p] * act_grad_from_pre_w(z, act, slope);
         gt[a][e] = rstd * (gp - m1 - z * m2);
         gc[p] = gt[a][e];                           // (this thread's own cells: no other thread reads them before the barrier)
+        sb += gt[a][e];
       }
     float yt[6][6];
     w43_gy_xform(gt, yt);
@@ -1446,12 +1448,32 @@ __global__ void __launch_bounds__(256) w43_gy_in_kernel(const float* __restrict_
 #pragma unroll
       for (int j = 0; j < 6; ++j) Ytp[((size_t)(i * 6 + j) * P + p) * M + c0 + c] = yt[i][j];
   }
+  red[512 + g * 64 + c] = sb;                       // (own region: slower threads may still be reading red[0..511] for m1 / m2)
   __syncthreads();
+  // per-(image, channel) sums of the conv's gy: the bias gradient is their sum over the images (w43_bias_sum_kernel) -- one
+  // 3 us launch instead of sg_channel_sum's two passes over gconv (round 6; 18 convs per step)
+  if (gb_part != nullptr && g == 0)
+    gb_part[(size_t)n * M + c0 + c] = ((red[512 + c] + red[576 + c]) + red[640 + c]) + red[704 + c];
   for (int i = tid * 4; i < 64 * HW; i += 1024) {
     const int ch = i / HW, q = i - ch * HW;
     const float* sp = pg + ch * pitch + q;
     *reinterpret_cast<float4*>(gconv + base + i) = make_float4(sp[0], sp[1], sp[2], sp[3]);
   }
+}
+
+// gb[m] = sum_n part[n][m], images in ascending order (deterministic)
+__global__ void w43_bias_sum_kernel(const float* __restrict__ part, float* __restrict__ gb, int N, int M) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float v = 0.f;
+  for (int n0 = 0; n0 < N; n0 += 8) {
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = n0 + e < N ? part[(size_t)(n0 + e) * M + m] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v += t[e];
+  }
+  gb[m] = v;
 }
 
 // gw[m][c][3][3] = G^T T G,  T[m][xi*C + c]
@@ -2165,7 +2187,8 @@ extern "C" int sg_conv2d_wino_fwd_instnorm(const sgConvDesc* d, const float* x, 
 
 extern "C" int sg_conv2d_wino_dgrad_instnorm(const sgConvDesc* d, const float* gout, const float* ypre, const float* mean,
                                              const float* rstd, int act, float slope, const float* w, float* gconv, float* gx,
-                                             const float* ut_saved, float* ytp_save, void* ws, size_t ws_bytes, sgStream stream) {
+                                             float* gb, const float* ut_saved, float* ytp_save, void* ws, size_t ws_bytes,
+                                             sgStream stream) {
   SG_ARG_CHECK(sg_conv2d_wino_in_supported(d), "sg_conv2d_wino_dgrad_instnorm: unsupported desc");
   SG_ARG_CHECK(gout && ypre && mean && rstd && w && gconv && ws && ws_bytes >= sg_conv2d_wino_ws_bytes(d),
                "sg_conv2d_wino_dgrad_instnorm: bad arguments");
@@ -2178,11 +2201,14 @@ extern "C" int sg_conv2d_wino_dgrad_instnorm(const sgConvDesc* d, const float* g
   float* Ytp_ws = Uw + 36 * (size_t)M * K;
   float* G = Ytp_ws + 36 * P * (size_t)(K > M ? K : M);
   float* Ytp = ytp_save ? ytp_save : Ytp_ws;
+  // [N][Cout] partial bias gradients: behind G in the workspace (the weight gradient's T region: free during this call)
+  float* gb_part = gb ? G + 36 * P * (size_t)M : nullptr;
   { SgProfScope xf(SG_K_INSTNORM_BWD, s, 0, 4.0 * ((double)d->N * K * HW * 3.0 + 36.0 * (double)P * K));
-    const size_t lds = (size_t)(128 * (HW + 1) + 512) * sizeof(float);
+    const size_t lds = (size_t)(128 * (HW + 1) + 768) * sizeof(float);
     w43_lds_attr(&w43_gy_in_kernel, lds);
-    hipLaunchKernelGGL(w43_gy_in_kernel, dim3(K / 64, d->N), dim3(256), lds, s, gout, ypre, mean, rstd, gconv, Ytp, d->N, K, d->H, d->W,
-                       act, slope); }
+    hipLaunchKernelGGL(w43_gy_in_kernel, dim3(K / 64, d->N), dim3(256), lds, s, gout, ypre, mean, rstd, gconv, Ytp, gb_part, d->N, K,
+                       d->H, d->W, act, slope);
+    if (gb) hipLaunchKernelGGL(w43_bias_sum_kernel, dim3(sg_cdiv(K, 256)), dim3(256), 0, s, (const float*)gb_part, gb, d->N, K); }
   if (gx) {
     const float* U = ut_saved;
     if (U == nullptr) {
@@ -2425,3 +2451,14 @@ extern "C" int sg_linear_bwd_weight(const float* gy, const float* x, float* gw, 
   return 0;
 }
 
+
+#ifdef SG_TIMELINE
+// debugging build only (tools/probe/build_timeline.sh): hand this translation unit's igemm_kernel instantiations a stamp buffer of
+// ``cap`` workgroups x 8 x u64 (nullptr: off)
+extern "C" int sg_debug_timeline_set_igemm(void* buf, unsigned cap) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_sg_tl), &p, sizeof(p)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_sg_tl_cap), &cap, sizeof(cap)) != hipSuccess) return -1;
+  return 0;
+}
+#endif

@@ -75,6 +75,21 @@ namespace {
 using namespace sgk;
 thread_local unsigned t_variant_stride = 0;   // >0: tap t of the k-table reads from source copy t (set by kn1_run)
 
+// -DSG_TIMELINE (tools/probe/build_timeline.sh: a SEPARATE library, never the product build): wave 0 of every workgroup of an
+// igemm_kernel launch stamps s_memtime at five points -- entry, loaders initialised, first k-tile staged in LDS, main loop done,
+// epilogue stored -- plus its hardware id into a buffer the host hands over (sg_debug_timeline_set_<unit>): where a workgroup's
+// life goes, per launch (tools/probe/timeline_probe.py).  Each translation unit has its own copy of the pointer.
+#ifdef SG_TIMELINE
+__device__ unsigned long long* g_sg_tl = nullptr;
+__device__ unsigned g_sg_tl_cap = 0;
+#define SG_TL_STAMP(slot)                                                                       \
+  do {                                                                                          \
+    if (tl_on) tl_rec[slot] = __builtin_amdgcn_s_memtime();                                     \
+  } while (0)
+#else
+#define SG_TL_STAMP(slot) do { } while (0)
+#endif
+
 #ifndef SG_NSUB
 #define SG_NSUB 1    // sub-tiles per workgroup k-tile (see CfgFor below for why 1)
 #endif
@@ -1073,6 +1088,9 @@ struct BatchInfo {
   int batch_major;
   // xcd_z: plain split-K launch whose grid.z is a multiple of 8: k-chunk z runs on XCD z % 8 (see the kernel)
   int xcd_z;
+  // par_chunk (parity-class launches): tiles go to the XCDs in chunks of this many (power of two) instead of one contiguous
+  // eighth of the tile range per XCD; prio: raise the wave priority outside the main loop (both: see the kernel; set by launch_cfg)
+  int par_chunk, prio;
   ParityClasses par;
 };
 // per-class hooks: loaders / epilogues that can run a parity class overload these; everything else ignores the call
@@ -1125,13 +1143,47 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   __shared__ int tapB[BL::LDS_INTS > 0 ? BL::LDS_INTS : 1];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm0 = (wid / CFG::WGN) * CFG::WM, wn0 = (wid % CFG::WGN) * CFG::WN;
+#ifdef SG_TIMELINE
+  const unsigned tl_wg = blockIdx.x + gridDim.x * blockIdx.z;
+  const bool tl_on = g_sg_tl != nullptr && tid == 0 && tl_wg < g_sg_tl_cap;
+  unsigned long long* tl_rec = g_sg_tl + (size_t)tl_wg * 8;
+  SG_TL_STAMP(0);
+  if (tl_on) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    tl_rec[5] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
 
   // XCD-aware, bijective tile remap: consecutive tiles (same weight rows, overlapping gathers) share an L2
   const int tiles_pb = bi.cols_per_batch > 0 ? (bi.cols_per_batch + BN - 1) / BN : 0;
   const int tiles_n = bi.cols_per_batch > 0 ? bi.nbatch * tiles_pb : (N + BN - 1) / BN;
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
-  {
+  // Prologue and epilogue of a workgroup are a few hundred vector-ALU / scalar instructions (index arithmetic, store addresses)
+  // on a SIMD whose other resident waves issue 64-cycle f32 MFMAs back to back; the f32 MFMA does not co-execute with VALU
+  // work and the arbiter serves the oldest wave first, so the NEW wave's instructions each waited for a whole MFMA slot:
+  // s_memtime stamps (tools/probe/timeline_probe.py, profiles/r06_timeline_*.txt) showed 12-25 k cycles of "init" and 7-8 k of
+  // epilogue in workgroups whose main loop is 28-130 k.  Raised priority outside the main loop (option wave_prio) gets those
+  // phases out of the way -- and was measured a net LOSS: what the new wave wins, the waves in their main loops lose (most classes
+  // +-1 %, the 3x3 transposed gather at 128x128 +11 %, the x-contiguous F(4x4,3x3) GEMMs +7 %, the step -0.3 %:
+  // profiles/r06_gemm_prio.md).  The switch stays for the record, default off.
+  if (bi.prio) __builtin_amdgcn_s_setprio(3);
+  if (bi.par.ncls > 0 && bi.par_chunk > 0) {
+    // Parity classes of a 3x3 stride-2 transposed gather have 4 / 2 / 2 / 1 taps, i.e. K extents 4 : 2 : 2 : 1, and their tiles
+    // are numbered class by class (heaviest first).  With one contiguous eighth of the tile range per XCD (below), XCDs 0-1 ran
+    // ALL tiles of the 4-tap class and XCDs 6-7 only 1-tap tiles whenever M fits one tile row: the launch took as long as XCD 0
+    // (timeline probe: 300 us where the balanced schedule needs ~180).  Chunks of par_chunk consecutive tiles (same weights,
+    // neighbouring pixels: they still share an L2) are dealt to the XCDs round-robin instead: every XCD gets an eighth of every
+    // class, the heavy class is still dispatched first.
+    const int G = bi.par_chunk, full = nwg / (8 * G) * (8 * G);
+    if (bid < full) {
+      const int xcd = bid & 7, idx = bid >> 3;
+      bid = ((idx / G) * 8 + xcd) * G + (idx % G);
+    }
+  } else {
     const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   }
@@ -1189,6 +1241,10 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   al.init(m0, tid, tapA, kbeg, kend);
   bl.init(n0, tid, tapB, kbeg, kend);
   rowsum_begin(al, n0 == 0);
+#ifdef SG_TIMELINE
+  if (tl_on) { tl_rec[6] = ((unsigned long long)(unsigned)(kend - kbeg) << 32) | (unsigned)n0; tl_rec[7] = (unsigned)m0; }
+#endif
+  SG_TL_STAMP(1);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -1210,6 +1266,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
 #pragma unroll
   for (int u = 0; u < NSUB; ++u) { al.store(sa[u], As[0] + u * BM * LDK); bl.store(sb[u], Bs[0] + u * BN * LDK); }
   __syncthreads();
+  SG_TL_STAMP(2);
+  if (bi.prio) __builtin_amdgcn_s_setprio(0);
 
   const int lr = lane & 31, lk = lane >> 5;
   int buf = 0;
@@ -1340,8 +1398,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][j][r] = acc2[i][j][r] + acc[i][j][r];
     }
+    SG_TL_STAMP(3);
+    if (bi.prio) __builtin_amdgcn_s_setprio(3);
     rowsum_finish(al, zblk);
     ep.store(acc, m0 + wm0, n0 + wn0, lane, zblk);
+#ifdef SG_TIMELINE
+    __builtin_amdgcn_s_waitcnt(0);                 // (vmcnt(0): the stamp is taken when this wave's stores have been accepted)
+#endif
+    SG_TL_STAMP(4);
     return;
   }
   for (int k0 = kbeg; k0 < kend; k0 += BKT) {
@@ -1392,8 +1456,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     __syncthreads();
     buf ^= 1;
   }
+  SG_TL_STAMP(3);
+  if (bi.prio) __builtin_amdgcn_s_setprio(3);
   rowsum_finish(al, zblk);
   ep.store(acc, m0 + wm0, n0 + wn0, lane, zblk);
+#ifdef SG_TIMELINE
+  __builtin_amdgcn_s_waitcnt(0);
+#endif
+  SG_TL_STAMP(4);
 }
 
 // tile configurations.  Measured on MI355X (tools/bench_conv.py): these kernels are limited by the vector-memory
@@ -1457,6 +1527,12 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
   dim3 grid(tiles, 1, t_grid_z > 0 ? t_grid_z : ((splits > 1 || t_fixed_kchunk > 0) ? sg_cdiv(K, kchunk) : 1));
   if (t_min_z > 0 && (int)grid.z < t_min_z && t_grid_z == 0) grid.z = t_min_z;
   BatchInfo bi = t_batch;
+  bi.prio = sg_opt(SG_OPT_WAVE_PRIO) ? 1 : 0;
+  bi.par_chunk = 0;
+  {
+    const int g = sg_opt(SG_OPT_PAR_XCD_CHUNK);
+    if (bi.par.ncls > 0 && g > 0 && (g & (g - 1)) == 0) bi.par_chunk = g;
+  }
   // k-chunks pinned to XCDs: plain split-K launches, and the per-image k-chunks (ksplit) of the factored stem's weight gradient
   // (grid.z = images x chunks: its column tiles re-read the same gy chunk from seven L2s -- 6.5x the algorithmic bytes in round 4)
   const bool plain_z = t_grid_z == 0 && t_fixed_kchunk == 0 && bi.ksplit == 0;
@@ -1516,8 +1592,7 @@ __global__ void slab_reduce_nchw_kernel(const float* ws, float* out, size_t n, i
                                         int act, float slope) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float v = 0.f;
-  for (int z = 0; z < S; ++z) v += ws[(size_t)z * n + i];
+  float v = sg_sum_strided(ws + i, n, S);           // (eight slab loads in flight, added in slab order)
   if (bias) v += bias[((unsigned)i / (unsigned)PHW) % (unsigned)Mtot];        // (n < 2^31: 32-bit divisions)
   out[i] = sg_apply_act(v, act, slope);
 }
@@ -1527,9 +1602,13 @@ __global__ void slab_reduce_nchw_vec_kernel(const float4* ws, float4* out, size_
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   float4 v = ws[i];
-  for (int z = 1; z < S; ++z) {
-    const float4 t = ws[(size_t)z * n4 + i];
-    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  for (int z0 = 1; z0 < S; z0 += 4) {               // four slab loads in flight, added in slab order (S <= 8)
+    float4 t[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = z0 + e < S ? ws[(size_t)(z0 + e) * n4 + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (z0 + e < S) { v.x += t[e].x; v.y += t[e].y; v.z += t[e].z; v.w += t[e].w; }
   }
   const float b = bias ? bias[((unsigned)i / (unsigned)PHW4) % (unsigned)Mtot] : 0.f;
   v.x = sg_apply_act(v.x + b, act, slope); v.y = sg_apply_act(v.y + b, act, slope);

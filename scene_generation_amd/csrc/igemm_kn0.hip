@@ -90,3 +90,14 @@ int sgk::kn_sparse_run(int KS, const float* W, int M, int K, const Gather& g, in
   }
   return -1;
 }
+
+#ifdef SG_TIMELINE
+// debugging build only (tools/probe/build_timeline.sh): hand this translation unit's igemm_kernel instantiations a stamp buffer of
+// ``cap`` workgroups x 8 x u64 (nullptr: off)
+extern "C" int sg_debug_timeline_set_igemm_kn0(void* buf, unsigned cap) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_sg_tl), &p, sizeof(p)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_sg_tl_cap), &cap, sizeof(cap)) != hipSuccess) return -1;
+  return 0;
+}
+#endif

@@ -149,3 +149,14 @@ int sgk::kn_parity_run(int KS, const float* W, int Rdim, int B, int m0, int M, c
                        float* out, int Mtot, int act, float slope, double flops, void* ws, size_t ws_bytes, hipStream_t s) {
   return run_kn_parity_ks(KS, W, Rdim, B, m0, M, g, NB, bias, out, Mtot, act, slope, flops, ws, ws_bytes, s);
 }
+
+#ifdef SG_TIMELINE
+// debugging build only (tools/probe/build_timeline.sh): hand this translation unit's igemm_kernel instantiations a stamp buffer of
+// ``cap`` workgroups x 8 x u64 (nullptr: off)
+extern "C" int sg_debug_timeline_set_igemm_kn1(void* buf, unsigned cap) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_sg_tl), &p, sizeof(p)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_sg_tl_cap), &cap, sizeof(cap)) != hipSuccess) return -1;
+  return 0;
+}
+#endif

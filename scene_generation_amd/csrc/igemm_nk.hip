@@ -57,16 +57,16 @@ __global__ void wgrad_unpermute_reduce_kernel(const float* __restrict__ slabs, f
   const unsigned j = blockIdx.x * blockDim.x + threadIdx.x;
   const int m = blockIdx.y;
   if (gb && j == 0) {                     // bias gradient: the k-chunks' row sums of gy (LoadPixK*::rowsum), fixed order
-    float b = 0.f;
-    for (int z = 0; z < S; ++z) b += rowsum[(size_t)z * M + m];
+    const float b = sg_sum_strided(rowsum + m, (size_t)M, S);
     gb[m] = b;
   }
   if (j >= (unsigned)(C * KS2)) return;
   const unsigned c = j / (unsigned)KS2, t = j - c * (unsigned)KS2;
   const size_t zs = (size_t)M * KS2 * cpad;
   const float* p = slabs + ((size_t)m * KS2 + t) * cpad + c;
-  float v = 0.f;
-  for (int z = 0; z < S; ++z) v += p[(size_t)z * zs];
+  // eight slab loads in flight per thread, added in slab order (sg_sum_strided; the plain loop compiled to one dependent load /
+  // wait / add per slab: 95 % of the wave cycles parked in s_waitcnt on 8..64 L2 round trips, profiles/r06_pmc_classes_cycles.md)
+  const float v = sg_sum_strided(p, zs, S);
   gw[(size_t)m * C * KS2 + j] = v;
 }
 // general (c, tap)-ordered loader: only for few-channel inputs (RGB crops / images)
@@ -239,3 +239,14 @@ int sgk::nk_run(int KS, const float* A, int M, int Mtot, const Gather& g, int NB
                 double flops, hipStream_t s, const Sparse* sp, float* gb, bool* gb_done) {
   return run_nk_ks(KS, A, M, Mtot, g, NB, out, ws, ws_bytes, flops, s, sp, gb, gb_done);
 }
+
+#ifdef SG_TIMELINE
+// debugging build only (tools/probe/build_timeline.sh): hand this translation unit's igemm_kernel instantiations a stamp buffer of
+// ``cap`` workgroups x 8 x u64 (nullptr: off)
+extern "C" int sg_debug_timeline_set_igemm_nk(void* buf, unsigned cap) {
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_sg_tl), &p, sizeof(p)) != hipSuccess) return -1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_sg_tl_cap), &cap, sizeof(cap)) != hipSuccess) return -1;
+  return 0;
+}
+#endif

@@ -677,9 +677,7 @@ __global__ void __launch_bounds__(256) channel_sum_partial_kernel(const float* _
 __global__ void channel_sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int C, int S) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float s = 0.f;
-  for (int z = 0; z < S; ++z) s += part[(size_t)c * S + z];
-  out[c] = s;
+  out[c] = sg_sum_strided(part + (size_t)c * S, 1, S);       // (eight partials in flight, added in order)
 }
 
 __global__ void channel_sum_kernel(const float* __restrict__ g, float* __restrict__ out, int N, int C, int HW) {

@@ -261,19 +261,18 @@ class ConvInstNormFn(Function):
         yn = _q(d, 'sg_conv2d_wino_ytp_floats') if (need_w and ctx.wino_v is not None) else 0
         ytp = torch.empty(yn, dtype=torch.float32, device=dev) if yn else None
         wsb = _q(d, 'sg_conv2d_wino_ws_bytes')
+        # the bias gradient comes out of the same launch (per-image plane sums of the conv's gy + one small launch over the images)
+        ob = GradOut(ctx.bias_ref) if need_b else None
         _call('sg_conv2d_wino_dgrad_instnorm', d._ref, _p(gout), _p(ypre), _p(mean), _p(rstd), act, slope, _p(weight), _p(gconv),
-              _p(gx), _p(ctx.wino_ut), _p(ytp), _p(workspace(wsb, dev)), wsb, s)
+              _p(gx), _p(ob.buf) if need_b else None, _p(ctx.wino_ut), _p(ytp), _p(workspace(wsb, dev)), wsb, s)
         gw = gb = None
         if need_w or need_b:
             ow = GradOut(weight) if need_w else None
-            ob = GradOut(ctx.bias_ref) if need_b else None
             wsb2 = max(wsb, _L().sg_channel_sum_ws_bytes(d.Cout))
             ws = workspace(wsb2, dev)
             if need_w:
                 _call('sg_conv2d_wino_wgrad', d._ref, _p(gconv), _p(x), _p(ow.buf), _p(ctx.wino_v) if ytp is not None else None,
                       _p(ytp), _p(ws), wsb2, s)
-            if need_b:
-                _call('sg_channel_sum', _p(gconv), _p(ob.buf), d.N, d.Cout, d.OH * d.OW, _p(ws), wsb2, s)
             gw = ow.finish() if need_w else None
             gb = ob.finish() if need_b else None
         return gx, gw, gb, (gout if has_skip and ctx.needs_input_grad[3] else None), None, None, None
