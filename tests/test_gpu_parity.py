@@ -152,6 +152,7 @@ CONV_CASES = [
     (4, 64, 0, 16, 16, 64, 3, 1, 1, False, 1, 1),      # 64 channels: stays on the direct kernel (VGG conv1_2)
     (2, 3, 0, 32, 32, 64, 3, 1, 1, False, 1, 1),       # VGG conv1_1
     (2, 16, 0, 15, 17, 8, 3, 2, 1, False, 1, 0),       # stride-2 dgrad: four parity classes of different sizes in one launch
+    (8, 16, 0, 64, 64, 8, 3, 2, 1, False, 1, 0),       # stride-2 dgrad with >= 128 parity tiles in one tile row: classes dealt to the XCDs in chunks
     (2, 8, 0, 12, 12, 24, 4, 2, 1, False, 1, 0),       # k4 s2 p1: equal classes
     (3, 512, 0, 18, 18, 1, 4, 1, 2, False, 1, 0),      # PatchGAN score head (vector-ALU head kernels), full width
     (4, 40, 0, 9, 11, 1, 4, 1, 2, False, 1, 2),        # head kernels: ragged channel chunk, non-square, fused LeakyReLU
@@ -269,8 +270,11 @@ def test_winograd_f43_trunk_shape_vs_f23_and_fp64(hip):
     finally:
         _hip.set_option('wino43', saved)
     _dump('winograd_f43_errors.json', errs)
-    for name in ('y', 'gx', 'gw'):
-        assert errs['f43_' + name] <= 6e-5, errs             # 2x the asserted conv bound, whatever F(2x2,3x3) shows
+    # per-layer error budget of the trunk conv (all 18 trunk convs have this shape): ~2x what the form measures
+    # with the channel sum accumulated in 256-chunks (TileCfg::KFOLD, round 6: y 3.4e-6, gx 2.4e-6, gw 2.9e-6 of the maxima -- one
+    # fma chain over 1024 channels gave 9.9e-6 / 6.0e-6).  A regression of the accumulation order shows HERE, not as a whole-step drift.
+    for name, bound in (('y', 7e-6), ('gx', 5e-6), ('gw', 6e-6)):
+        assert errs['f43_' + name] <= bound, errs
 
 
 @pytest.mark.parametrize('N,C,H,Cout,act,with_skip', [(16, 128, 8, 128, 1, True), (8, 128, 16, 256, 2, False), (32, 256, 8, 128, 0, True)])
@@ -455,7 +459,9 @@ def test_upconv_subpixel_form_equals_folded_upsample_gather(hip):
         close(a, c, 2e-5, name)
 
 
-@pytest.mark.parametrize('N,Cin,Cout,H', [(2, 16, 8, 8), (3, 32, 16, 5), (2, 128, 64, 16)])
+# (8, 64, 32, 32): one tile row (Cout <= 64) and 4 x 128 pixel tiles of 64 -- the launch shape whose parity classes are dealt to the XCDs in
+#  chunks (BatchInfo::par_chunk: the forward of generators.py:84-87 at 64x64 -> 128x128 ran all 4-tap tiles on two XCDs)
+@pytest.mark.parametrize('N,Cin,Cout,H', [(2, 16, 8, 8), (3, 32, 16, 5), (2, 128, 64, 16), (8, 64, 32, 32)])
 def test_conv_transpose2d(hip, N, Cin, Cout, H):
     x, w, b = det((N, Cin, H, H), 31), det((Cin, Cout, 3, 3), 32, 0.2), det((Cout,), 33, 0.2)
     xr, wr, br = [t.clone().requires_grad_() for t in (x, w, b)]

@@ -88,11 +88,15 @@ def main():
     if not len(rec):
         return
     t = rec[:, :5].astype(np.int64)
-    t0 = t[:, 0].min()
-    t -= t0
-    span = t[:, 4].max()
     kext = (rec[:, 6] >> np.uint64(32)).astype(np.int64)
     hw = rec[:, 5]
+    # s_memtime counters of different XCDs have different bases (seen: spans of 1e12 ticks): times are made relative to the first
+    # workgroup entry of the SAME XCD -- the eight XCDs start a launch within a microsecond of each other
+    xcc0 = ((hw >> np.uint64(32)) & np.uint64(0xF)).astype(np.int64)
+    for xc in set(xcc0.tolist()):
+        sel = xcc0 == xc
+        t[sel] -= t[sel, 0].min()
+    span = t[:, 4].max()
     # HW_ID (gfx9): wave [3:0], simd [5:4], pipe [7:6], cu [11:8], sh [12], se [15:13]; XCC id in the high word
     cu = ((hw >> np.uint64(8)) & np.uint64(0xF)).astype(np.int64)
     sh = ((hw >> np.uint64(12)) & np.uint64(0x1)).astype(np.int64)
