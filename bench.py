@@ -226,10 +226,11 @@ def cpu_baseline(image_size, n_images, n_steps):
 
 PMC_KERNELS = {
     # profiler kind -> regex of the kernel symbol (the two dense Winograd instantiations: stores at the top / interleaved)
-    'wino_bgemm_t128': r'igemm_kernel.*TileCfg<128, 128, 2, 2, [12](?:, \d+)?>.*EpRowMajorPlain',
+    # (rocprofv3's --kernel-include-regex is not PCRE: no \d, no (?:...) -- character classes only)
+    'wino_bgemm_t128': r'igemm_kernel.*TileCfg<128, 128, 2, 2, [12][, 0-9]*>.*EpRowMajorPlain',
     # the three 64x64-tile instantiations of the F(4x4,3x3) GEMMs (forward, data gradient, weight gradient)
     # (16- or 32-deep k-tiles, with or without the chunked channel sum: TileCfg<64, 64, 2, NSUB, 2, KFOLD>)
-    'wino43_bgemm_t64': r'igemm_kernel.*TileCfg<64, 64, 2, [12], 2(?:, \d+)?>.*EpRowMajorPlain',
+    'wino43_bgemm_t64': r'igemm_kernel.*TileCfg<64, 64, 2, [12], 2[, 0-9]*>.*EpRowMajorPlain',
 }
 
 
