@@ -723,6 +723,7 @@ struct LoadGatherNK {
   Gather g; int Ncols;
   const int* chan_list; const int* chan_cnt; int L;     // optional per-image active-channel lists
   int zdiv;                                             // k-chunks per image (informational: the image comes from kbeg)
+  FastDiv dphw, dpw;                                    // k -> (image, pixel row) without integer divisions: host_prepare()
   static constexpr int KS2 = KS * KS;
   // per k-tile LDS table (separable): rowoff[KS][16] (= ih*SW or -1), coloff[KS][16] (= iw or -1), one all -1 row,
   // img1[16], img2[16]
@@ -773,8 +774,10 @@ struct LoadGatherNK {
       const int k = k0 + p;
       const bool kok = k < kend_;
       const int kk = kok ? k : 0;
-      const int img = kk / phw, pix = kk - img * phw;
-      const int ph = pix / g.PW, pw = pix - ph * g.PW;
+      // (two emulated 32-bit divisions per table entry, ~272 entries per 16-pixel k-tile, sat in front of every tile's MFMAs:
+      //  round 6 -- multiply-high + shift with host-prepared constants, as in the other loaders)
+      const int img = (int)dphw.div((unsigned)kk), pix = kk - img * phw;
+      const int ph = (int)dpw.div((unsigned)pix), pw = pix - ph * g.PW;
       int val = -1;
       if (row < KS) {
         const int i = axis_offset(ph * g.stride - g.pad, row, g.LH, g.reflect, g.ushift);
@@ -1127,6 +1130,11 @@ template <class T> inline void host_prepare(T&) {}
 inline void host_prepare(EpNCHW& e) {
   e.dPHW = FastDiv((unsigned)(e.PHW > 0 ? e.PHW : 1));
   e.dPWs = FastDiv((unsigned)(e.PWs > 0 ? e.PWs : 1));
+}
+template <int BN, int KS, bool TWO, bool MASK, int NS> inline void host_prepare(LoadGatherNK<BN, KS, TWO, MASK, NS>& l) {
+  const int phw = l.g.PH * l.g.PW;
+  l.dphw = FastDiv((unsigned)(phw > 0 ? phw : 1));
+  l.dpw = FastDiv((unsigned)(l.g.PW > 0 ? l.g.PW : 1));
 }
 template <int BN, int MODE> inline void host_prepare(LoadFixedKN<BN, MODE>& l) {
   const int phw = l.g.PH * l.g.PW;
@@ -1504,7 +1512,11 @@ inline int pick_tile(int M, int N) {
   const long t128 = (long)sg_cdiv(M, 128) * sg_cdiv(N, 128);
   const bool low_waste = sg_cdiv(M, 128) * 128 * 20 <= M * 23 && N >= 512;
   const int t128_min = sg_opt(SG_OPT_T128_MIN), wide_min = sg_opt(SG_OPT_TILE3_MIN), wide = sg_opt(SG_OPT_TILE3);     // tuning aids
-  if (M >= 96 && low_waste && (M >= 512 || t128 >= t128_min)) return 0;
+  // (two 128x128 workgroups are resident per CU: a launch of a few more than 512 / 1024 of them runs a nearly empty extra round --
+  //  545 tiles, the first PatchGAN layer on the 2N batch, took 207 us against 189 us on 64x64 tiles: profiles/r06_gemm_tile_sweep.md)
+  const long over = t128 % 512;
+  const bool ragged128 = t128 > 512 && t128 < 1536 && over > 0 && over < 128;
+  if (M >= 96 && low_waste && !ragged128 && (M >= 512 || t128 >= t128_min)) return 0;
   if (wide && (long)sg_cdiv(M, 64) * sg_cdiv(N, 128) >= wide_min) return 3;
   return 1;
 }

@@ -92,17 +92,22 @@ def main():
     hw = rec[:, 5]
     # s_memtime counters of different XCDs have different bases (seen: spans of 1e12 ticks): times are made relative to the first
     # workgroup entry of the SAME XCD -- the eight XCDs start a launch within a microsecond of each other
-    xcc0 = ((hw >> np.uint64(32)) & np.uint64(0xF)).astype(np.int64)
-    for xc in set(xcc0.tolist()):
-        sel = xcc0 == xc
+    # (HW_REG_XCC_ID read back 0 on every XCD in this build: the groups are found as clusters of the entry stamps instead -- bases
+    #  differ by >= 1e9 ticks, a launch lasts < 1e6)
+    order = np.argsort(t[:, 0])
+    gaps = np.diff(t[order, 0])
+    grp = np.zeros(len(order), dtype=np.int64)
+    grp[order[1:]] = np.cumsum(gaps > 50_000_000)
+    grp[order[0]] = 0
+    for gq in set(grp.tolist()):
+        sel = grp == gq
         t[sel] -= t[sel, 0].min()
     span = t[:, 4].max()
     # HW_ID (gfx9): wave [3:0], simd [5:4], pipe [7:6], cu [11:8], sh [12], se [15:13]; XCC id in the high word
     cu = ((hw >> np.uint64(8)) & np.uint64(0xF)).astype(np.int64)
     sh = ((hw >> np.uint64(12)) & np.uint64(0x1)).astype(np.int64)
     se = ((hw >> np.uint64(13)) & np.uint64(0x7)).astype(np.int64)
-    xcc = ((hw >> np.uint64(32)) & np.uint64(0xF)).astype(np.int64)
-    cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    cuid = ((grp * 8 + se) * 2 + sh) * 16 + cu
     ph = {'init': t[:, 1] - t[:, 0], 'first tile': t[:, 2] - t[:, 1], 'main loop': t[:, 3] - t[:, 2], 'epilogue': t[:, 4] - t[:, 3],
           'life': t[:, 4] - t[:, 0]}
     print('launch span %d ticks (first entry -> last exit).  s_memtime ticks; 100 MHz reference clock if span*10ns ~ wall, else shader '
