@@ -237,6 +237,9 @@ __global__ void embedding_bwd_kernel(const float* __restrict__ g, const int64_t*
   __shared__ int hits[CAP];
   __shared__ int nhit;
   const int row = blockIdx.x;
+  // blockIdx.y: the column range [col_lo, col_hi) of this workgroup (the table has only ~180 rows: one workgroup per row left a
+  // third of the chip idle and took 288 us at configs[4]'s 1056 objects; every workgroup rebuilds the row's hit list -- cheap)
+  const int cper = (dim + gridDim.y - 1) / gridDim.y, col_lo = blockIdx.y * cper, col_hi = min(dim, col_lo + cper);
   for (int base = 0; base < n; base += CAP) {            // chunks of CAP indices (one chunk in practice)
     __syncthreads();
     if (threadIdx.x < 64) {                            // wave 0: ordered compaction, 64 indices per round (one thread
@@ -253,14 +256,21 @@ __global__ void embedding_bwd_kernel(const float* __restrict__ g, const int64_t*
     }
     __syncthreads();
     const int c = nhit;
-    for (int col = threadIdx.x; col < dim; col += blockDim.x) {
+    for (int col = col_lo + threadIdx.x; col < col_hi; col += blockDim.x) {
       float acc = base == 0 ? 0.f : gt[(size_t)row * dim + col];
-      for (int h = 0; h < c; ++h) acc += g[(size_t)hits[h] * dim + col];
+      for (int h0 = 0; h0 < c; h0 += 8) {              // eight rows in flight, added in ascending i (the index_add order)
+        float t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = h0 + e < c ? g[(size_t)hits[h0 + e] * dim + col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (h0 + e < c) acc += t[e];
+      }
       gt[(size_t)row * dim + col] = acc;
     }
   }
   if (n == 0)
-    for (int col = threadIdx.x; col < dim; col += blockDim.x) gt[(size_t)row * dim + col] = 0.f;
+    for (int col = col_lo + threadIdx.x; col < col_hi; col += blockDim.x) gt[(size_t)row * dim + col] = 0.f;
 }
 
 __global__ void copy_cols_kernel(const float* __restrict__ src, int src_ld, int src_off, float* __restrict__ dst,
@@ -419,7 +429,11 @@ extern "C" int sg_embedding_fwd(const float* table, const int64_t* idx, float* o
 extern "C" int sg_embedding_bwd(const float* g, const int64_t* idx, float* g_table, int n, int num_rows, int dim,
                                 sgStream stream) {
   SG_ARG_CHECK(g && idx && g_table && num_rows > 0 && dim > 0, "sg_embedding_bwd: bad arguments");
-  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(num_rows), dim3(row_threads(dim)), 0, (hipStream_t)stream, g, idx, g_table,
+  // column chunks so that ~1024 workgroups are in flight (at least 256 columns each)
+  int ysplit = (1024 + num_rows - 1) / num_rows;
+  const int maxy = dim / 256 > 0 ? dim / 256 : 1;
+  if (ysplit > maxy) ysplit = maxy;
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(num_rows, ysplit), dim3(row_threads(dim)), 0, (hipStream_t)stream, g, idx, g_table,
                      n, dim);
   SG_LAUNCH_CHECK("sg_embedding_bwd");
   return 0;

@@ -629,6 +629,11 @@ inline int bn_slices(int N, int C, int HW) {
   int S = (target + C - 1) / C;
   const long maxS = cnt / 1024 > 0 ? cnt / 1024 : 1;      // at least 1024 elements per slice
   if (S > maxS) S = (int)maxS;
+  // ... and few enough per slice for the register-resident statistics kernel (BN_REG x 256 elements: x is read ONCE).  At
+  // configs[4] -- 1056 crops, 64 x 31 x 31 after the first conv -- 64 slices held 15.9 K elements each and bn_stats_kernel fell to
+  // its two-pass loop of dependent loads: 85 us per launch at 3 TB/s (round 6)
+  const long need = (cnt + (long)BN_REG * 256 - 1) / ((long)BN_REG * 256);
+  if (S < need && need <= 512) S = (int)need;
   return S < 1 ? 1 : S;
 }
 
