@@ -69,6 +69,18 @@ def physical_cores():
         return os.cpu_count()
 
 
+def cpu_throttle_count():
+    """``nr_throttled`` of the cgroup this process runs in: how many 100 ms scheduler periods ended with the process frozen because
+    it had spent its CPU quota (None without cgroup v2 accounting).  A throttle inside a timed region starves the GPU."""
+    try:
+        for line in open('/sys/fs/cgroup/cpu.stat'):
+            if line.startswith('nr_throttled'):
+                return int(line.split()[1])
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 class ClockSampler(object):
     """sclk / mclk / socket power of one GPU sampled on a background thread while the timed region runs (two
     boxes of the pool differ by ~5 % in kernel time at equal host speed; the line now says at what clocks and power it was
@@ -208,17 +220,28 @@ def cpu_baseline(image_size, n_images, n_steps):
     from scene_generation_amd.synthetic import make_batch, make_vocab
     args = parser.parse_args(['--image_size', '%d,%d' % (image_size, image_size), '--batch_size', str(n_images),
                               '--vgg_features_weight', '0', '--output_dir', '/tmp/o'])
+    from scene_generation_amd.utils import cpu_quota
+    # as many threads as the process may actually run: the cgroup's CPU quota when there is one (16 CPUs on the GPU boxes of this
+    # project, on a 128-core host).  torch's default -- one thread per physical core -- oversubscribes the quota 8x; the kernel
+    # then freezes the process for most of every 100 ms period and the "128-core" figure of rounds 1-5 was really a throttled one
+    quota = cpu_quota()
+    threads0 = torch.get_num_threads()
+    threads = max(1, min(threads0, int(quota))) if quota else threads0
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     tr = O.Trainer(args, make_vocab())
     batches = [make_batch(N=n_images, min_objs=3, max_objs=8, size=image_size, seed=i) for i in range(2)]
     random.seed(0)
-    tr.step(batches[0], use_gt=True)
-    t0 = time.perf_counter()
-    for i in range(n_steps):
-        tr.step(batches[(i + 1) % 2], use_gt=random.randint(0, 1) != 0)
-    dt = time.perf_counter() - t0
-    return {'value': n_images * n_steps / dt, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'physical_cores': physical_cores(), 'logical_cpus': os.cpu_count(),
+    try:
+        tr.step(batches[0], use_gt=True)
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            tr.step(batches[(i + 1) % 2], use_gt=random.randint(0, 1) != 0)
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(threads0)
+    return {'value': n_images * n_steps / dt, 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+            'physical_cores': physical_cores(), 'logical_cpus': os.cpu_count(), 'cgroup_cpu_quota': quota,
             'sample': 'full G+D step (same widths and flags as the headline pass, fp32, torch-CPU oracle), %d images of the '
                       '%dx%d workload per step, 1 warm-up + %d timed steps, %.1f s' % (n_images, image_size, image_size,
                                                                                         n_steps, dt)}
@@ -365,6 +388,7 @@ def main():
     from scene_generation_amd.synthetic import make_batch, make_vocab
     from scene_generation_amd.pipeline import DeviceBatchPrefetcher
     from scene_generation_amd.trainer import Trainer
+    from scene_generation_amd.utils import cpu_quota
 
     S, B = a.image_size, a.batch_per_gpu
     vocab = make_vocab()
@@ -448,7 +472,9 @@ def main():
     calls0, replays0 = ops.CALLS[0], graphs.REPLAYS[0]
     blocks = split_blocks(a.steps)
     sampler = ClockSampler(local).start()
+    thr0 = cpu_throttle_count()
     dt = timed(tr, a.steps, a.warmup, blocks=blocks)
+    thr1 = cpu_throttle_count()
     clocks = sampler.stop(timed.t0, timed.t1)
     host_issue = issue[0]
     # value = the MEDIAN block: the K steps run back to back exactly as the contract says, cut into >= 5
@@ -534,6 +560,11 @@ def main():
         'repeat_spread': repeat['spread'], 'repeat': repeat,
         'whole_region': {'value': B * world * a.steps / dt, 'ms_per_step': 1e3 * dt / a.steps, 'seconds': dt},
         'clocks': clocks,
+        # host side of the measurement: the cgroup's CPU quota (CPUs per period; None = unlimited) and how many scheduler periods
+        # ended with the process frozen by it while the timed steps ran (0 = the host was never taken away from the launch thread)
+        'host': {'cgroup_cpu_quota': cpu_quota(), 'cpu_throttled_periods_in_timed_region':
+                 (thr1 - thr0) if thr0 is not None and thr1 is not None else None,
+                 'logical_cpus': os.cpu_count(), 'torch_threads': torch.get_num_threads()},
     }
     if world > 1:
         out['rccl_ranks'] = dist.get_world_size()
@@ -642,8 +673,9 @@ def main():
                                            'note': '--vgg_features_weight 10 (args.py:73), He-normal VGG19 weights'}
             del tr2
         # (1b) the boundary as the reference's loop has it (train.py:190-193): every step is handed a HOST batch.  The K host
-        # batches go through pipeline.DeviceBatchPrefetcher INSIDE the timed region (validation, host summaries, pinned
-        # staging, H2D on the copy stream one batch ahead) -- the PCIe-inclusive rate; never the headline ``value``
+        # batches go through pipeline.DeviceBatchPrefetcher INSIDE the timed region (validation, host summaries, packing into a
+        # page-locked slot on the staging thread, one copy kernel per batch on the launch stream) -- the PCIe-inclusive rate;
+        # never the headline ``value``
         nh, nwarm = max(4, a.steps), 4
         it = iter(DeviceBatchPrefetcher([host_batches[i % 2] for i in range(nwarm + nh)], dev))
 
@@ -651,7 +683,7 @@ def main():
             db = next(it)
             tr.model.objs_host, tr.model.obj_to_img_host = db.objs_host, db.obj_to_img_host
             tr.step(db.batch, use_gt=tr.draw_use_gt())
-        for _ in range(nwarm):                # fills the pipeline: pinned staging slots and the copy stream's device blocks exist
+        for _ in range(nwarm):                # fills the pipeline: the page-locked staging slots exist
             host_step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -663,8 +695,9 @@ def main():
         sec['host_buffers'] = {'images_per_s': B * nh / dh, 'ms_per_step': 1e3 * dh / nh, 'steps': nh,
                                'host_bytes_per_batch': hb_bytes,
                                'note': 'headline configuration fed from pageable HOST batches through DeviceBatchPrefetcher '
-                                       'inside the timed loop (collate-contract validation + copy into re-used pinned slots + '
-                                       'H2D on a copy stream, one batch ahead), after %d untimed steps of the same iterator' % nwarm}
+                                       'inside the timed loop (collate-contract validation + single-threaded packing into re-used '
+                                       'page-locked slots on a staging thread + one sg_stage_copy kernel per batch on the launch '
+                                       'stream), after %d untimed steps of the same iterator' % nwarm}
         # (2) Trainer.step's own defaults: fast paths on AND the three dense (N,204,H,W) layouts of Model.forward written
         tr.dense_layout_outputs = True
         one_step(tr, 0)

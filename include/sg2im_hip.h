@@ -413,6 +413,11 @@ int sg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
                  float eps, float bias_corr1, float bias_corr2_sqrt, float grad_scale, sgStream stream);
 int sg_fill(float* p, float value, int64_t n, sgStream stream);
 int sg_scale(float* p, float alpha, int64_t n, sgStream stream);
+/* dst (device) <- src (PAGE-LOCKED host memory, read through its device mapping) by a kernel on ``stream``: how a collated host
+ * batch reaches the device (replaces the eight ``tensor.cuda()`` of train.py:192 for batches packed into one page-locked buffer;
+ * scene_generation_amd/pipeline.py).  Both pointers 16-byte aligned, nbytes a multiple of 16. */
+int sg_stage_copy(void* dst, const void* src_host_mapped, int64_t nbytes, sgStream stream);
+
 /* y += alpha * x : a second gradient contribution to a parameter slice of the flat gradient buffer (the first one is
  * written in place by the weight-gradient kernels; replaces autograd's AccumulateGrad add, trainer.py:262,278,299,324) */
 int sg_axpy(float* y, const float* x, float alpha, int64_t n, sgStream stream);

@@ -3,6 +3,8 @@
 // (losses.py:26-44,135-175; trainer.py:215,331-340; discriminators.py:35) and torch.optim.Adam
 // (trainer.py:60,80,106,133).
 #include "common.h"
+#include <algorithm>
+#include <stdint.h>
 
 namespace {
 
@@ -434,6 +436,41 @@ extern "C" int sg_fill(float* p, float value, int64_t n, sgStream stream) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(fill_kernel, dim3(sg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, value, (size_t)n);
   SG_LAUNCH_CHECK("sg_fill");
+  return 0;
+}
+
+// Host batch -> device: a kernel that READS page-locked host memory through its device mapping (hipHostMalloc memory is
+// mapped into the device's address space) and writes HBM.  16 B per lane and load, four loads in flight; the grid is kept small
+// (the PCIe link, not the CUs, bounds it: ~8 MB per batch).  See scene_generation_amd/pipeline.py for why the input batch does
+// not go through hipMemcpyAsync on a copy stream.
+typedef unsigned int stage_u4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) stage_copy_kernel(stage_u4* __restrict__ dst, const stage_u4* __restrict__ src, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const stage_u4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
+                c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
+extern "C" int sg_stage_copy(void* dst, const void* src_host_mapped, int64_t nbytes, sgStream stream) {
+  SG_ARG_CHECK(dst && src_host_mapped && nbytes >= 0 && nbytes % 16 == 0 && ((uintptr_t)dst % 16) == 0 &&
+               ((uintptr_t)src_host_mapped % 16) == 0, "sg_stage_copy: operands must be 16-byte aligned, nbytes a multiple of 16");
+  if (nbytes == 0) return 0;
+  // the device-side address of the page-locked buffer (identical to the host address for hipHostMalloc memory, possibly not
+  // for hipHostRegister-ed memory); fails for pageable memory, which a kernel must not be pointed at
+  void* src_dev = nullptr;
+  if (hipHostGetDevicePointer(&src_dev, const_cast<void*>(src_host_mapped), 0) != hipSuccess || !src_dev) {
+    (void)hipGetLastError();
+    sg_set_error("sg_stage_copy: the source is not page-locked, device-mapped host memory");
+    return -1;
+  }
+  const size_t n16 = (size_t)nbytes / 16;
+  const unsigned blocks = (unsigned)std::min<size_t>(sg_cdiv(n16, 256), 1024);
+  hipLaunchKernelGGL(stage_copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (stage_u4*)dst, (const stage_u4*)src_dev, n16);
+  SG_LAUNCH_CHECK("sg_stage_copy");
   return 0;
 }
 

@@ -356,6 +356,16 @@ def fill_(t, value):
     return t
 
 
+def stage_copy(dst, src_pinned, nbytes):
+    """dst (uint8, device) <- the first ``nbytes`` of ``src_pinned`` (uint8, page-locked host memory) by ONE kernel on the current
+    stream that reads the host buffer through its device mapping (pipeline.DeviceBatchPrefetcher)."""
+    assert dst.is_cuda and dst.dtype == torch.uint8 and src_pinned.dtype == torch.uint8 and not src_pinned.is_cuda
+    assert dst.numel() >= nbytes and src_pinned.numel() >= nbytes
+    with torch.cuda.device(dst.device):
+        _call('sg_stage_copy', ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src_pinned.data_ptr()), int(nbytes), _stream())
+    return dst
+
+
 def add_clear_(y, x):
     """y += x ; x = 0 (optim.FusedAdam._fold_spill)"""
     assert y.numel() == x.numel()

@@ -9,11 +9,28 @@ The reference moves every tensor of a collated batch with a synchronous ``tensor
     ``_pool_samples`` silently relies on, layout.py:153-154),
   * summarised into the host lists the step needs (class ids for the VectorPool plan, obj_to_img for the factored layout
     planes, per-image segment offsets), so nothing is copied BACK from the device,
-  * copied through PINNED staging buffers on a side stream, one batch ahead of the step that consumes it.
+  * PACKED into one page-locked staging buffer, ``depth`` batches ahead of the step that consumes it (background thread: pure
+    host work, no runtime call), and
+  * brought to the device by ONE kernel on the consumer's own stream that reads the page-locked buffer through its device mapping
+    (``sg_stage_copy``); the eight tensors of the device batch are views of one allocation.
+
+What rounds 4-5 got wrong (pinned per-tensor buffers filled with ``Tensor.copy_``, hipMemcpyAsync on a copy stream, event
+hand-over): fed from host batches the step ran 33-75 ms instead of 32 -- box-dependent, 498-967 images/s for the same code, 830.8 of
+924.3 on the driver's box.  Found in round 6 (tools/probe/host_stall_probe.py, profiles/r06_host_stall.md): the GPU boxes run
+this process in a cgroup with a CPU QUOTA (``cpu.max`` = 16 CPUs per 100 ms period, on a 256-CPU host), ``Tensor.copy_`` of the
+6 MB image tensor fans out over torch's OpenMP pool (128 threads, which then spin), the burst spends the quota, and the kernel
+freezes EVERY thread of the process -- the one issuing the launches included -- until the next period: a 20-60 ms stall every
+~100 ms (``nr_throttled`` in cpu.stat counts them), during which the GPU runs dry.  Not the copies, not the second stream, not the
+interpreter lock, not the garbage collector (each ruled out by its own A/B).  The staging below therefore uses a plain
+single-threaded ``memmove`` per tensor; the copy-kernel form of the transfer was kept from the hunt because it is the simpler
+hand-over (one queue: no second stream, no cross-stream event, no ``record_stream`` bookkeeping, no DMA engine) and costs
+0.17 ms of a 32 ms step (8 MB over PCIe at 47 GB/s on the launch stream).  Measured after the fix: 32.24-32.30 ms/step from host
+batches against 32.05 resident, threaded or inline staging alike.
 
 Works for any iterable of collated batches: a torch DataLoader with the reference's ``coco_collate_fn`` or the synthetic
 generator (scene_generation_amd.synthetic.make_batch).
 """
+import ctypes
 from collections import namedtuple
 
 import torch
@@ -54,24 +71,25 @@ def threading_current():
 
 
 class DeviceBatchPrefetcher(object):
-    """Iterates DeviceBatch objects; the H2D copies of batch k+1 are in flight (pinned memory, side stream) while the
-    caller trains on batch k.
+    """Iterates DeviceBatch objects; batch k+1 .. k+depth are validated, summarised and packed into page-locked memory while the
+    caller trains on batch k; ``__next__`` issues the one copy kernel of the batch it returns on the current stream.
 
-    ``threaded`` (default on a GPU): validation, the host summaries and the copy into the pinned slots run on a background
-    thread, ``depth`` batches ahead.  Measured on MI355X (tools/probe/host_buffers_probe.py): staging a 7.97 MB batch costs ~7 ms
-    of host time, and the thread that issues the step's ~1 100 launches has only ~3 ms of slack per 32.5 ms step -- staged
-    inline, the step went from 32.5 to 42 ms."""
+    ``threaded`` (default on a GPU): validation, the host summaries and the packing run on a background thread, ``depth``
+    batches ahead: staging a 7.97 MB batch costs ~7 ms of host time (tools/probe/host_buffers_probe.py), the thread that issues
+    the step's launches should not pay it."""
+
+    ALIGN = 256
 
     def __init__(self, batches, device, validate=True, depth=2, threaded=None):
         self.src = iter(batches)
         self.device = torch.device(device)
         self.validate = validate
         self.cuda = self.device.type == 'cuda'
-        self.stream = torch.cuda.Stream(self.device) if self.cuda else None
         self.depth = max(1, int(depth))
         self._queue = []
-        # pinned staging buffers, re-used: ``t.pin_memory()`` page-locks a fresh allocation per tensor and batch; a slot holds one
-        # buffer per tensor of the 8-tuple and the event behind its last H2D copies, depth + 2 slots rotate
+        # page-locked staging buffers, re-used (``t.pin_memory()`` would page-lock a fresh allocation per tensor and batch): one
+        # buffer per slot holds the whole packed batch; 'ev' = the event behind the copy kernel that last read it.  depth + 2
+        # slots rotate: when slot j % S is packed again, the consumer has long issued the copy of batch j - S (see _stage_one)
         self._slots = [dict() for _ in range(self.depth + 2)]
         self._staged = 0
         self.threaded = self.cuda if threaded is None else bool(threaded)
@@ -87,7 +105,8 @@ class DeviceBatchPrefetcher(object):
             self._thread.start()
 
     def _stage_one(self):
-        """next host batch -> (DeviceBatch, event) with its copies queued on the copy stream; None at the end of the source"""
+        """next host batch -> (DeviceBatch of HOST tensors, packing) with the batch packed into a page-locked slot; None at the
+        end of the source.  ``packing`` = (slot, total bytes, [(offset, bytes, dtype, shape)] per tensor); None on a CPU device."""
         try:
             hb = next(self.src)
         except StopIteration:
@@ -97,28 +116,49 @@ class DeviceBatchPrefetcher(object):
         N = hb.imgs.size(0)
         objs_host = hb.objs.tolist()
         seg = segment_offsets(o2i, N)
+        packing = None
         if self.cuda:
             slot = self._slots[self._staged % len(self._slots)]
             self._staged += 1
             if slot.get('ev') is not None:
-                slot['ev'].synchronize()           # the copies that last read this slot's buffers (depth + 2 batches ago)
-            moved = []
-            with torch.cuda.stream(self.stream):
-                for i, t in enumerate(hb):
-                    t = t.contiguous()
-                    buf = slot.get(i)
-                    if buf is None or buf.dtype != t.dtype or buf.numel() < t.numel():
-                        buf = slot[i] = torch.empty(t.numel() * 5 // 4 + 16, dtype=t.dtype, pin_memory=True)
-                    view = buf[:t.numel()].view(t.shape)
-                    view.copy_(t)                  # host memcpy into page-locked memory
-                    moved.append(view.to(self.device, non_blocking=True))
-            dev = Batch(*moved)
+                slot['ev'].synchronize()           # the copy kernel that last read this slot (depth + 2 batches ago)
+                slot['ev'] = None
+            fields, total = [], 0
+            for t in hb:
+                total = (total + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+                n = t.numel() * t.element_size()
+                fields.append((total, n, t.dtype, tuple(t.shape)))
+                total += n
+            total = (total + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            buf = slot.get('buf')
+            if buf is None or buf.numel() < total:
+                buf = slot['buf'] = torch.empty(total * 5 // 4 + 4096, dtype=torch.uint8, pin_memory=True)
+            base = buf.data_ptr()
+            for t, (off, n, dtype, shape) in zip(hb, fields):
+                if n:
+                    # plain single-threaded memcpy with the interpreter lock released -- NOT ``Tensor.copy_``, whose OpenMP
+                    # burst gets the whole process frozen by the cgroup's CPU quota (module docstring)
+                    t = t if t.is_contiguous() else t.contiguous()
+                    ctypes.memmove(base + off, t.data_ptr(), n)
+            packing = (slot, total, fields)
+        return DeviceBatch(hb, objs_host, o2i, seg, N), packing
+
+    def _to_device(self, db, packing):
+        """the consumer's side: one allocation, one copy kernel on the current stream, eight views"""
+        if packing is None:
+            return db
+        from . import ops
+        slot, total, fields = packing
+        with torch.cuda.device(self.device):
+            dev = torch.empty(total, dtype=torch.uint8, device=self.device)
+            ops.stage_copy(dev, slot['buf'], total)
             ev = torch.cuda.Event()
-            ev.record(self.stream)
-            slot['ev'] = ev
-        else:
-            dev, ev = hb, None
-        return DeviceBatch(dev, objs_host, o2i, seg, N), ev
+            ev.record()
+        slot['ev'] = ev
+        moved = []
+        for off, n, dtype, shape in fields:
+            moved.append(dev[off:off + n].view(dtype).view(shape))
+        return DeviceBatch(Batch(*moved), db.objs_host, db.obj_to_img_host, db.seg_offsets_host, db.num_images)
 
     @staticmethod
     def _worker_main(wref, q, stop):
@@ -173,18 +213,14 @@ class DeviceBatchPrefetcher(object):
                 if item is None:
                     raise StopIteration
                 raise item
-            db, ev = item
+            db, packing = item
         else:
             while len(self._queue) < self.depth and self._stage():
                 pass
             if not self._queue:
                 raise StopIteration
-            db, ev = self._queue.pop(0)
-        if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)     # stream-side wait: the host does not block
-            for t in db.batch:
-                t.record_stream(torch.cuda.current_stream(self.device))
-        return db
+            db, packing = self._queue.pop(0)
+        return self._to_device(db, packing)
 
     def close(self):
         """stop the staging thread and release what it holds (pinned slots, the source iterator).  Call it -- or use the

@@ -11,6 +11,7 @@ Same attributes and step functions as the reference Trainer; differences in HOW 
   * the image discriminator's real and wrong-texture passes (trainer.py:250,304-308) run as ONE 2N batch over the stacked
     factored layouts (_real_and_wrong_pass): the launches of the discriminators are occupancy-starved at N = 32
   * optional data parallelism: per-optimiser GradReducer (RCCL all-reduce of the flat gradient buffers)
+  * optional host-side flow control (``max_lead_steps`` / SG_LEAD_STEPS, default off): see ``_lead_point``
 TensorBoard / image logging of the reference (trainer.py:342-397) is glue outside the hot path: ``write_losses``
 prints; checkpoints keep the reference schema (trainer.py:136-203, train.py:132-162).
 """
@@ -25,7 +26,7 @@ from .losses import get_gan_losses, GANLoss, VGGLoss
 from .model import Model
 from .optim import FusedAdam
 from .parallel import GradReducer, broadcast_params, broadcast_int, control_group
-from .utils import LossManager, weighted_sum
+from .utils import LossManager, respect_cpu_quota, weighted_sum
 
 
 class _NullWriter(object):
@@ -84,6 +85,7 @@ class Trainer:
     def __init__(self, args, vocab, checkpoint=None, device=None, distributed=False, model_extra=None):
         self.vocab = vocab
         self.args = args
+        respect_cpu_quota()          # host threads <= the container's CPU quota: an OpenMP burst must not freeze the launch thread
         # the reference moves everything to 'cuda' (trainer.py:54,77,103,130).  Without a device the object can still be
         # CONSTRUCTED (state_dict surgery, checkpoint conversion); any forward raises: there is no CPU compute path
         self.device = device if device is not None else ('cuda' if torch.cuda.is_available() else 'cpu')
@@ -106,6 +108,9 @@ class Trainer:
         self.share_d_forward = True
         # the real and wrong-texture passes of the image discriminator as one 2N batch (_real_and_wrong_pass; A/B: SG_BATCH_REAL_WRONG=0)
         self.batch_real_wrong = os.environ.get('SG_BATCH_REAL_WRONG', '1') != '0'
+        # how many iterations the launching thread may run ahead of the GPU (0 = the runtime's own limit: ~2.3 iterations)
+        self.max_lead_steps = int(os.environ.get('SG_LEAD_STEPS', '0'))
+        self._lead_events = {}
         self.reducers = []
         if distributed:
             control_group()                      # collective: create the host-side agreement group on every rank now
@@ -124,6 +129,28 @@ class Trainer:
                     # the 1 / world of the mean is applied by the Adam kernel while it reads the gradient (no scaling pass)
                     opt.pre_step_hooks.append(r.wait_deferred_scale)
                     self.reducers.append(r)
+
+    def _lead_point(self, k):
+        """Host-side flow control (opt-in), called at fixed places of an iteration: wait until the GPU has passed THIS place of
+        the iteration ``max_lead_steps`` before the current one, then mark the place in the stream.
+
+        Left alone the launching thread runs ~2.3 iterations ahead (it needs 11-13 ms to issue what the GPU executes in 32 ms)
+        until a launch blocks inside the runtime for 15-20 ms -- a per-queue resource of ~1 300 eager launches is handed back a
+        quarter at a time.  That costs nothing (the GPU always has > 1.5 iterations queued; 32.02 vs 32.05 ms/step with the
+        bound at one iteration, profiles/r06_host_stall.md), so the bound is OFF by default; it exists as an instrument: with it
+        no launch ever blocks, every wait is one ``Event.synchronize`` at a known place (interpreter lock released), which is
+        what separated the runtime's back-pressure from the stall round 6 was hunting (a CPU-quota freeze of the whole process
+        caused by an OpenMP burst in the input staging: scene_generation_amd/pipeline.py).  Host-only: nothing is added to the
+        stream except an event record."""
+        n = self.max_lead_steps
+        if n <= 0 or torch.device(self.device).type != 'cuda' or torch.cuda.is_current_stream_capturing():
+            return
+        q = self._lead_events.setdefault(k, [])
+        if len(q) >= n:
+            q.pop(0).synchronize()
+        ev = torch.cuda.Event()
+        ev.record()
+        q.append(ev)
 
     def _adam(self, module, lr):
         return FusedAdam(module.parameters(), lr=lr, betas=(self.args.beta1, 0.999))
@@ -274,6 +301,7 @@ class Trainer:
         (the reference computes and then discards those gradients, trainer.py:262 vs :298,323).  The object
         discriminator has BatchNorm running statistics that every forward updates, so it is not shared."""
         args = self.args
+        self._lead_point(0)
         self.generator_losses = L = LossManager()
         self._shared = shared = {}
         share = getattr(self, 'share_d_forward', True)
@@ -395,6 +423,7 @@ class Trainer:
 
     def train_image_discriminator(self, imgs, imgs_pred, layout, layout_wrong):
         if self.netD is not None:
+            self._lead_point(1)
             self.d_img_losses = L = LossManager()
             shared = getattr(self, '_shared', {})
             alpha = (1 / 2) * (.5)

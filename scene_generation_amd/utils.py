@@ -33,6 +33,48 @@ def bool_flag(s):
     raise ValueError('Invalid value "%s" for bool flag (should be 0 or 1)' % s)
 
 
+def cpu_quota():
+    """CPUs this process may use per scheduler period: the cgroup's ``cpu.max`` quota (v2; ``cpu.cfs_quota_us`` for v1) in units of
+    CPUs, or None without a quota.  On the MI355X boxes of this project the container gets 16 CPUs of a 256-CPU host; a burst of
+    more runnable threads than that (torch's OpenMP pool defaults to one thread per physical core) spends the quota within a few
+    milliseconds and the kernel then freezes the WHOLE process until the next 100 ms period -- the launching thread included
+    (scene_generation_amd/pipeline.py)."""
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        return None if q == 'max' else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+_QUOTA_APPLIED = [False]
+
+
+def respect_cpu_quota(verbose=True):
+    """Lower torch's intra-op thread count to the cgroup's CPU quota when it exceeds it (once per process; SG_KEEP_TORCH_THREADS=1
+    opts out).  Called by Trainer.__init__: any host-side torch operator large enough to fan out over the default pool (one
+    thread per physical core) while the step runs would otherwise get the whole process -- launch thread included -- frozen by
+    the quota for the rest of a 100 ms period (``cpu_quota``).  Returns the thread count in effect."""
+    import os
+    if _QUOTA_APPLIED[0] or os.environ.get('SG_KEEP_TORCH_THREADS', '0') == '1':
+        return torch.get_num_threads()
+    _QUOTA_APPLIED[0] = True
+    q = cpu_quota()
+    n = torch.get_num_threads()
+    if q is not None and n > max(1, int(q)):
+        torch.set_num_threads(max(1, int(q)))
+        if verbose:
+            import sys
+            print('scene_generation_amd: torch intra-op threads %d -> %d (cgroup CPU quota %.1f CPUs; SG_KEEP_TORCH_THREADS=1 keeps '
+                  'the default)' % (n, torch.get_num_threads(), q), file=sys.stderr)
+    return torch.get_num_threads()
+
+
 def to_device_async(t, device):
     """Small host -> device copy that does not stall the host: a copy from PAGEABLE memory makes the host wait until the
     stream has drained (measured: ~3.5 ms each, 8 per step), a copy from pinned memory is just enqueued."""

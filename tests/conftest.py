@@ -40,6 +40,10 @@ def pytest_sessionstart(session):
     from scene_generation_amd import synthetic
     if synthetic.HASH_CACHE is None:
         synthetic.HASH_CACHE = {}
+    # the CPU oracle with one thread per physical core inside a 16-CPU cgroup quota (the GPU boxes) spends most of every scheduler
+    # period frozen: run the whole session -- oracle and HIP path alike -- with as many threads as the quota allows
+    from scene_generation_amd.utils import respect_cpu_quota
+    respect_cpu_quota(verbose=False)
 
 
 import contextlib

@@ -2077,14 +2077,22 @@ def test_masks_to_layout_gradients_wrt_masks_and_boxes(hip, pooling):
 # f3 / f4: the collate -> device adapter on the GPU, the validation loop and the feature bank
 # ------------------------------------------------------------------------------------------
 def test_device_batch_prefetcher_equals_direct_copies_and_steps_identically(hip):
-    """f3 (coco.py:501-547 -> train.py:190-193): the pinned, side-stream, double-buffered adapter delivers exactly
-    ``batch_to`` of the collated batch plus host lists that match it, and a training step fed through it (host lists handed
-    to the model, as bench.py does) is bit-identical to a step fed the device batch directly."""
+    """f3 (coco.py:501-547 -> train.py:190-193): the adapter (batch packed into a re-used page-locked slot on a staging thread, one
+    sg_stage_copy kernel on the consumer's stream, eight views of one allocation) delivers exactly ``batch_to`` of the collated
+    batch plus host lists that match it -- also when the slots rotate (7 batches through depth + 2 = 4 slots, threaded and
+    inline) --, and a training step fed through it (host lists handed to the model, as bench.py does) is bit-identical to a
+    step fed the device batch directly.  Pageable memory is refused by the copy kernel's entry point."""
+    from scene_generation_amd import ops
     from scene_generation_amd.pipeline import DeviceBatchPrefetcher
     from scene_generation_amd.trainer import Trainer
-    host = [make_batch(N=4, min_objs=2, max_objs=5, size=64, seed=70 + i) for i in range(3)]
+    host = [make_batch(N=4, min_objs=2, max_objs=5, size=64, seed=70 + i) for i in range(7)]
     staged = list(DeviceBatchPrefetcher(host, DEV))
-    assert len(staged) == 3
+    assert len(staged) == 7
+    for hb, db in zip(host, DeviceBatchPrefetcher(host, DEV, threaded=False, depth=1)):
+        for a, b in zip(batch_to(hb, DEV), db.batch):
+            assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        ops.stage_copy(torch.empty(4096, dtype=torch.uint8, device=DEV), torch.zeros(4096, dtype=torch.uint8), 4096)
     for hb, db in zip(host, staged):
         for a, b in zip(batch_to(hb, DEV), db.batch):
             assert a.dtype == b.dtype and torch.equal(a, b)

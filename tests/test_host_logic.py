@@ -639,3 +639,37 @@ def test_winograd_f43_matrices_in_the_kernel_source_satisfy_the_identities():
     gw = G.T @ (Yt * V) @ G                         # d/dg of sum(y * gy)
     gw_ref = np.array([[(gy * d[a:a + 4, b:b + 4]).sum() for b in range(3)] for a in range(3)])
     assert np.abs(gw - gw_ref).max() < 1e-12
+
+
+def test_cpu_quota_parsing_and_thread_cap(tmp_path, monkeypatch):
+    """utils.cpu_quota reads the cgroup v2 quota in CPUs (None when unlimited / absent); respect_cpu_quota lowers torch's intra-op
+    thread count to it once, never raises it, and SG_KEEP_TORCH_THREADS=1 opts out (round 6: a 128-thread OpenMP burst inside a
+    16-CPU quota froze the launching thread for 20-60 ms of every 100 ms)."""
+    import builtins
+    import torch
+    from scene_generation_amd import utils
+    real_open = builtins.open
+    content = {'v': '1600000 100000\n'}
+
+    def fake_open(path, *a, **k):
+        if path == '/sys/fs/cgroup/cpu.max':
+            import io
+            return io.StringIO(content['v'])
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, 'open', fake_open)
+    assert utils.cpu_quota() == 16.0
+    content['v'] = 'max 100000\n'
+    assert utils.cpu_quota() is None
+    content['v'] = '200000 100000\n'
+    n0 = torch.get_num_threads()
+    try:
+        monkeypatch.setattr(utils, '_QUOTA_APPLIED', [False])
+        monkeypatch.setenv('SG_KEEP_TORCH_THREADS', '1')
+        assert utils.respect_cpu_quota(verbose=False) == n0
+        monkeypatch.setenv('SG_KEEP_TORCH_THREADS', '0')
+        got = utils.respect_cpu_quota(verbose=False)
+        assert got == min(n0, 2) and torch.get_num_threads() == got
+        content['v'] = '100000 100000\n'
+        assert utils.respect_cpu_quota(verbose=False) == got          # once per process
+    finally:
+        torch.set_num_threads(n0)
