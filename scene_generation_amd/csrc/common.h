@@ -74,6 +74,9 @@ enum SgOpt {
   SG_OPT_WAVE_PRIO,       // GEMM kernels: s_setprio 3 outside the main loop (prologue / epilogue VALU work does not queue behind other waves' MFMAs).
                           // OFF: measured on MI355X, profiles/r06_gemm_prio.md -- most classes +-1 %, Gup4 fwd +11 %, F(4x4,3x3) dgrad / wgrad +7 %, step -0.3 %
   SG_OPT_PAR_XCD_CHUNK,   // parity-class launches: tiles dealt to the XCDs in chunks of this many (power of two; 0 = one contiguous eighth per XCD)
+  SG_OPT_W43_TAIL_SPLIT,  // F(4x4,3x3) forward / data-gradient GEMMs whose tile count leaves half a round per CU (36 x 32 tiles on 256 CUs):
+                          // the tiles of the half round run as two workgroups of half the k range each (igemm_kernel, TileCfg::TAILSPLIT)
+  SG_OPT_W43_WGRAD_TILE,  // tile of the F(4x4,3x3) weight-gradient GEMMs (K = the 128 Winograd tiles): 0 = 64x64 (9216 workgroups), 1 = 128x128, 2 = 64x128
   SG_OPT_COUNT
 };
 extern std::atomic<int> g_sg_opt[SG_OPT_COUNT];
@@ -191,7 +194,10 @@ __device__ __forceinline__ bool sg_arrive_last(int* counter, int narrive, int* f
 }
 // a zeroed 4-byte counter in library-owned device memory for ONE launch on stream ``s`` (runtime.hip); nullptr: none available
 // (the caller then runs its two-kernel form).  ``n`` consecutive counters.
-int* sg_counter_alloc(hipStream_t s, int n = 1);
+int* sg_counter_alloc(hipStream_t s, int n = 1, bool always = false);     // always: also when the option last_block is off
+// library-owned device scratch of the tail-split GEMM launches (raw accumulator dumps), one buffer per (device, stream), grown
+// outside stream captures only; nullptr: not available (the caller launches the plain schedule)
+float* sg_tail_scratch(hipStream_t s, size_t bytes);
 
 // block reduction of up to 1024 threads; result valid in every thread. `red` = >=16 floats of LDS.
 __device__ __forceinline__ float sg_block_sum(float v, float* red) {

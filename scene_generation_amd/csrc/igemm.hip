@@ -852,10 +852,10 @@ using CfgDI64 = TileCfg<64, 64, 2, 2, 2>;
 // all resident at once (32-deep: 4 per CU by LDS = 1024 slots, the other 128 run as a second, nearly empty round)
 using CfgDI64S = TileCfg<64, 64, 2, 1, 2>;
 // ... with the channel sum accumulated in chunks (TileCfg::KFOLD): the F(4x4,3x3) forward / data-gradient GEMMs (w43_kfold)
-using CfgDI64F256 = TileCfg<64, 64, 2, 2, 2, 256>;
-using CfgDI64SF256 = TileCfg<64, 64, 2, 1, 2, 256>;
-using CfgDI64F128 = TileCfg<64, 64, 2, 2, 2, 128>;
-using CfgDI64SF128 = TileCfg<64, 64, 2, 1, 2, 128>;
+using CfgDI64F256 = TileCfg<64, 64, 2, 2, 2, 256, 1>;
+using CfgDI64SF256 = TileCfg<64, 64, 2, 1, 2, 256, 1>;
+using CfgDI64F128 = TileCfg<64, 64, 2, 2, 2, 128, 1>;
+using CfgDI64SF128 = TileCfg<64, 64, 2, 1, 2, 128, 1>;
 // kfold (0 / 128 / 256) x k-tile depth -> one of the six 64x64 instantiations
 template <class AL, class BL>
 int launch_w43(const AL& al, const BL& bl, const EpRowMajorPlain& ep, int M, int N, int K, hipStream_t s) {
@@ -1519,7 +1519,12 @@ void w43_gemm_wgrad(const float* Ytp, const float* V, float* T, int M, int C, in
   t_batch.batch_major = 1;
   {
     SgProfScope prof(SG_K_WINO43_GEMM, s, 2.0 * 36.0 * M * (double)C * P, 0);
-    if (sg_opt(SG_OPT_W43_NSUB) == 1)
+    const int wt = sg_opt(SG_OPT_W43_WGRAD_TILE);
+    if (wt == 1 && M % 128 == 0 && C % 128 == 0 && P % 32 == 0)
+      launch_cfg<CfgDI128>(LoadXContigS<128>{Ytp, M, 0}, LoadXContigS<128>{V, C, C}, EpRowMajorPlain{T, 36 * C}, M, 36 * C, P, 1, s);
+    else if (wt == 2 && C % 128 == 0 && P % 32 == 0)
+      launch_cfg<CfgDI64W>(LoadXContigS<64>{Ytp, M, 0}, LoadXContigS<128>{V, C, C}, EpRowMajorPlain{T, 36 * C}, M, 36 * C, P, 1, s);
+    else if (sg_opt(SG_OPT_W43_NSUB) == 1)
       launch_cfg<CfgDI64S>(LoadXContigS<64>{Ytp, M, 0}, LoadXContigS<64>{V, C, C}, EpRowMajorPlain{T, 36 * C}, M, 36 * C, P, 1, s);
     else
       launch_cfg<CfgDI64>(LoadXContigS<64>{Ytp, M, 0}, LoadXContigS<64>{V, C, C}, EpRowMajorPlain{T, 36 * C}, M, 36 * C, P, 1, s);

@@ -109,10 +109,12 @@ constexpr int BK = 16;     // sub-tile depth: the unit one loader call stages (1
 // study with tools/winograd_f43.py: all-fp32 3.9e-6 of max|y| at K = 1024, 2.5e-6 with 256-chunks, 1.4e-6 with 128-chunks,
 // 0.6e-6 with an fp64 accumulator; transforms in fp64 instead: no change).  Cost: 2 x 16 vector-ALU instructions per wave and
 // chunk boundary and 16 more registers per 32x32 accumulator.  Deterministic; the order is a function of K alone.
-template <int BM_, int BN_, int WGM_, int NSUB_, int PIPE_ = SG_PIPE_DEFAULT, int KFOLD_ = 0>
+// TS_ = 1: the kernel carries the TAIL-SPLIT schedule (BatchInfo::tail_*; batched full-tile launches only): see igemm_kernel.
+template <int BM_, int BN_, int WGM_, int NSUB_, int PIPE_ = SG_PIPE_DEFAULT, int KFOLD_ = 0, int TS_ = 0>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = 4 / WGM_, NSUB = NSUB_, BKT = BK * NSUB_, PIPE = PIPE_;
-  static constexpr int KFOLD = KFOLD_;
+  static constexpr int KFOLD = KFOLD_, TAILSPLIT = TS_;
+  static_assert(TS_ == 0 || PIPE_ != 0, "tail split: pipelined loop only");
   static_assert(KFOLD_ == 0 || (PIPE_ != 0 && KFOLD_ % (BK * NSUB_) == 0), "KFOLD: whole k-tiles of the pipelined loop");
   static constexpr int WM = BM / WGM, WN = BN / WGN;
   static constexpr int TM = WM / 32, TN = WN / 32;
@@ -165,6 +167,7 @@ __device__ __forceinline__ float4 sg_bufload4(__amdgpu_buffer_rsrc_t r, unsigned
   return f;
 }
 #endif
+typedef unsigned int sg_u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned ELEM_INVALID = 1u << 29;      // element offset that the range check of a buffer load rejects
 // Largest tensor (in elements) an operand loader may address.  Buffer loads carry a BYTE offset in 32 bits against
 // num_records = 2^31 bytes, so element indices must stay below 2^29 (an index in [2^29, 2^31) would be range-rejected and
@@ -1094,6 +1097,11 @@ struct BatchInfo {
   // par_chunk (parity-class launches): tiles go to the XCDs in chunks of this many (power of two) instead of one contiguous
   // eighth of the tile range per XCD; prio: raise the wave priority outside the main loop (both: see the kernel; set by launch_cfg)
   int par_chunk, prio;
+  // tail split (TileCfg::TAILSPLIT kernels, batch_major launches whose tile count leaves HALF a round of workgroups per CU:
+  // 36 x 32 = 1152 tiles of the F(4x4,3x3) GEMMs on 256 CUs = 4.5 per CU): tail_sx > 0 = tiles per XCD that run as TWO workgroups
+  // of half the k range each; grid.x = tiles + 8 * tail_sx.  tail_slab: 2 x 16 KB x TM x TN per split tile of raw accumulators,
+  // tail_cnt: one arrival counter per split tile (zero, reset by the last arriver).
+  int tail_sx; float* tail_slab; int* tail_cnt;
   ParityClasses par;
 };
 // per-class hooks: loaders / epilogues that can run a parity class overload these; everything else ignores the call
@@ -1170,6 +1178,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   const int tiles_n = bi.cols_per_batch > 0 ? bi.nbatch * tiles_pb : (N + BN - 1) / BN;
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
+  int ts_half = -1, ts_slot = 0;               // tail split: which half of the k range this workgroup runs (-1: all of it)
   // Prologue and epilogue of a workgroup are a few hundred vector-ALU / scalar instructions (index arithmetic, store addresses)
   // on a SIMD whose other resident waves issue 64-cycle f32 MFMAs back to back; the f32 MFMA does not co-execute with VALU
   // work and the arbiter serves the oldest wave first, so the NEW wave's instructions each waited for a whole MFMA slot:
@@ -1191,6 +1200,24 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
       const int xcd = bid & 7, idx = bid >> 3;
       bid = ((idx / G) * 8 + xcd) * G + (idx % G);
     }
+  } else if (CFG::TAILSPLIT && bi.tail_sx > 0) {
+    // Tail split.  T tiles on 256 CUs with T % 256 == 128: every CU runs 4 workgroups and half of the CUs a 5th -- five resident
+    // workgroups share the matrix pipe of those CUs (2560 cycles per k-tile instead of 2170: tools/probe/timeline_probe.py) and
+    // the launch ends when THEY end, the other half of the chip idle for the last ~10 % (profiles/r06_timeline_after_Gres_fwd.txt).
+    // Instead sx = T / 16 / 8 tiles per XCD run as TWO workgroups of half the k range each, numbered FIRST so that every CU gets
+    // one of them next to its four whole tiles: 4.5 tiles of work on every CU.  The halves meet in the epilogue (below).
+    const int per_x = nwg >> 3, xcd = bid & 7, idx = bid >> 3, sx = bi.tail_sx, tx = per_x - sx;      // tx tiles per XCD
+    int lt;
+    if (idx < 2 * sx) {
+      ts_half = idx & 1;
+      const int q = idx >> 1;
+      ts_slot = xcd * sx + q;
+      lt = (xcd & 1) ? q : tx - sx + q;                  // the half batch at the seam between XCD 2i and 2i + 1
+    } else {
+      const int f = idx - 2 * sx;
+      lt = (xcd & 1) ? sx + f : f;
+    }
+    bid = xcd * tx + lt;
   } else {
     const int q = nwg >> 3, rem = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
@@ -1230,10 +1257,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     kbeg = img * bi.kimg + q * bi.kcs;
     kend = min((img + 1) * bi.kimg, kbeg + bi.kcs);
   }
+  if (CFG::TAILSPLIT && ts_half >= 0) {
+    const int kh = (kend - kbeg) >> 1;         // (host: a multiple of the k-tile and of KFOLD)
+    if (ts_half) kbeg += kh; else kend = kbeg + kh;
+  }
   if (bi.cols_per_batch > 0) {
     int tn = bid % tiles_n, batch = tn / tiles_pb;
     if (bi.batch_major) {
-      const int per_batch = (int)(gridDim.x / (unsigned)bi.nbatch);       // = tiles_m * tiles_pb
+      const int per_batch = (int)((gridDim.x - 8u * (unsigned)(CFG::TAILSPLIT ? bi.tail_sx : 0)) / (unsigned)bi.nbatch);   // = tiles_m * tiles_pb
       batch = bid / per_batch;
       const int r = bid - batch * per_batch;
       m0 = (r / tiles_pb) * BM;
@@ -1408,6 +1439,42 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     }
     SG_TL_STAMP(3);
     if (bi.prio) __builtin_amdgcn_s_setprio(3);
+    if constexpr (CFG::TAILSPLIT != 0) {
+      if (ts_half >= 0) {
+        // The two halves of a split tile: each dumps its raw accumulators (write-through 16-byte stores, lane-contiguous: 1 KB per
+        // wave instruction) and takes a ticket; the one that arrives LAST adds the other's dump to its registers and stores the
+        // tile.  No waiting, no pre-zeroed output; x + y is commutative, so the result does not depend on who arrives last.
+        // (Visibility: sc1 stores drained before the ticket, sc1 loads after it -- the recipe of sg_arrive_last, common.h.)
+        __shared__ int ts_flag;
+        constexpr int PERW = TM * TN * 16 * 64;                                  // floats one wave dumps
+        float* mine = bi.tail_slab + ((size_t)(ts_slot * 2 + ts_half) * 4 + wid) * PERW;
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(mine, 0, PERW * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              sg_u32x4 d;
+              __builtin_memcpy(&d, reinterpret_cast<const char*>(&acc[i][j]) + 16 * v, 16);
+              __builtin_amdgcn_raw_buffer_store_b128(d, rm, (((i * TN + j) * 4 + v) * 64 + lane) * 16, 0, 16 /* sc1 */);
+            }
+        if (!sg_arrive_last(bi.tail_cnt + ts_slot, 2, &ts_flag)) return;
+        const float* theirs = bi.tail_slab + ((size_t)(ts_slot * 2 + (1 - ts_half)) * 4 + wid) * PERW;
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(theirs), 0, PERW * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const auto d = __builtin_amdgcn_raw_buffer_load_b128(rt, (((i * TN + j) * 4 + v) * 64 + lane) * 16, 0, 16 /* sc1 */);
+              float4 f;
+              __builtin_memcpy(&f, &d, 16);
+              acc[i][j][4 * v + 0] += f.x; acc[i][j][4 * v + 1] += f.y; acc[i][j][4 * v + 2] += f.z; acc[i][j][4 * v + 3] += f.w;
+            }
+      }
+    }
     rowsum_finish(al, zblk);
     ep.store(acc, m0 + wm0, n0 + wn0, lane, zblk);
 #ifdef SG_TIMELINE
@@ -1550,6 +1617,21 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
   const bool plain_z = t_grid_z == 0 && t_fixed_kchunk == 0 && bi.ksplit == 0;
   const bool image_z = t_grid_z > 0 && bi.ksplit > 0 && t_xcd_z == 2;
   bi.xcd_z = (t_xcd_z && (plain_z || image_z) && bi.cols_per_batch == 0 && bi.par.ncls == 0 && grid.z >= 8 && grid.z % 8 == 0) ? 1 : 0;
+  bi.tail_sx = 0; bi.tail_slab = nullptr; bi.tail_cnt = nullptr;
+  if constexpr (CFG::TAILSPLIT != 0) {
+    // half a round of workgroups per CU left over (tiles % 256 == 128 on the 256 CUs of an MI355X: the 36 x 32 tiles of the
+    // F(4x4,3x3) GEMMs at the benchmark shape): split those tiles' k range in two (see the kernel)
+    static const int n_cu = [] { int d = 0, v = 0; hipGetDevice(&d); hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v; }();
+    const int kh = K / 2;
+    if (sg_opt(SG_OPT_W43_TAIL_SPLIT) && n_cu == 256 && bi.batch_major && bi.cols_per_batch > 0 && bi.kcnt == nullptr && grid.z == 1 &&
+        splits <= 1 && tiles % 256 == 128 && tiles >= 384 && K % 2 == 0 && kh % CFG::BKT == 0 && kh >= 4 * CFG::BKT &&
+        (CFG::KFOLD == 0 || kh % CFG::KFOLD == 0) && M % CFG::BM == 0 && bi.cols_per_batch % CFG::BN == 0) {
+      const int sx = 16, nsplit = 8 * sx;
+      float* slab = sg_tail_scratch(s, (size_t)nsplit * 2 * 4 * CFG::TM * CFG::TN * 16 * 64 * sizeof(float));
+      int* cnt = slab ? sg_counter_alloc(s, nsplit, true) : nullptr;
+      if (slab && cnt) { bi.tail_sx = sx; bi.tail_slab = slab; bi.tail_cnt = cnt; grid.x = tiles + nsplit; }
+    }
+  }
   AL al2 = al; BL bl2 = bl; EP ep2 = ep;
   host_prepare(al2); host_prepare(bl2); host_prepare(ep2);
   for (int c = 0; c < bi.par.ncls && c < 4; ++c) {

@@ -176,6 +176,111 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) instnorm_bwd_reg_kernel(con
   }
 }
 
+// ---------------- InstanceNorm, register-resident form with 16-byte accesses -------------------------------------------------------
+// Same ownership as above (G threads per plane, the whole plane in registers), but every lane moves float4s: lane tg holds elements
+// 4 (tg + G j) .. + 3.  The scalar form issues one 256-byte request per wave and load -- measured at 0.41 of the HBM peak on its
+// algorithmic bytes (3.3 TB/s, 43 + 51 launches of ~50-60 MB per step); 16-byte accesses are what the memory pipeline is built for
+// (MI355X_MICROARCH.md: 8-byte accesses run at 0.54-0.70 of the 16-byte rate, 4-byte ones below that).  Needs HW % 4 == 0 and
+// 16-byte aligned operands (every plane then starts on a 16-byte boundary); E4 = float4s per thread.
+typedef float in_f4 __attribute__((ext_vector_type(4)));
+
+template <int G, int E4>
+__global__ void __launch_bounds__(G > 256 ? G : 256) instnorm_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ skip,
+                                                                            float* __restrict__ y, float* __restrict__ mean_o,
+                                                                            float* __restrict__ rstd_o, int NC, int HW, float eps,
+                                                                            int act, float slope) {
+  __shared__ float red[16];
+  constexpr int PPB = G >= 256 ? 1 : 256 / G;
+  const int tg = threadIdx.x % G;
+  const int plane = blockIdx.x * PPB + threadIdx.x / G;
+  const bool live = plane < NC;
+  const int HW4 = HW >> 2;
+  const in_f4* xp = reinterpret_cast<const in_f4*>(x + (size_t)(live ? plane : 0) * HW);
+  in_f4 v[E4];
+#pragma unroll
+  for (int j = 0; j < E4; ++j) {
+    const int i = tg + G * j;
+    v[j] = (live && i < HW4) ? xp[i] : in_f4{0.f, 0.f, 0.f, 0.f};
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < E4; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  s = group_sum<G>(s, red);
+  const float mean = s / (float)HW;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < E4; ++j) {
+    const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+    q += (tg + G * j < HW4) ? (a * a + b * b) + (c * c + d * d) : 0.f;
+  }
+  q = group_sum<G>(q, red);
+  const float rstd = 1.f / sqrtf(q / (float)HW + eps);
+  if (!live) return;
+  if (tg == 0) { mean_o[plane] = mean; rstd_o[plane] = rstd; }
+  const in_f4* sp = skip ? reinterpret_cast<const in_f4*>(skip + (size_t)plane * HW) : nullptr;
+  in_f4* yp = reinterpret_cast<in_f4*>(y + (size_t)plane * HW);
+#pragma unroll
+  for (int j = 0; j < E4; ++j) {
+    const int i = tg + G * j;
+    if (i < HW4) {
+      in_f4 o;
+      o.x = sg_apply_act((v[j].x - mean) * rstd, act, slope);
+      o.y = sg_apply_act((v[j].y - mean) * rstd, act, slope);
+      o.z = sg_apply_act((v[j].z - mean) * rstd, act, slope);
+      o.w = sg_apply_act((v[j].w - mean) * rstd, act, slope);
+      if (sp) o += sp[i];
+      yp[i] = o;
+    }
+  }
+}
+
+template <int G, int E4>
+__global__ void __launch_bounds__(G > 256 ? G : 256) instnorm_bwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                            const float* __restrict__ mean_i,
+                                                                            const float* __restrict__ rstd_i, float* __restrict__ gx,
+                                                                            int NC, int HW, int act, float slope) {
+  __shared__ float red[16];
+  constexpr int PPB = G >= 256 ? 1 : 256 / G;
+  const int tg = threadIdx.x % G;
+  const int plane = blockIdx.x * PPB + threadIdx.x / G;
+  const bool live = plane < NC;
+  const int HW4 = HW >> 2;
+  const size_t base = (size_t)(live ? plane : 0) * HW;
+  const in_f4* xp = reinterpret_cast<const in_f4*>(x + base);
+  const in_f4* gp = reinterpret_cast<const in_f4*>(gy + base);
+  const float mean = mean_i[live ? plane : 0], rstd = rstd_i[live ? plane : 0];
+  in_f4 z[E4], g[E4];
+#pragma unroll
+  for (int j = 0; j < E4; ++j) {
+    const int i = tg + G * j;
+    const bool ok = live && i < HW4;
+    z[j] = ok ? xp[i] : in_f4{mean, mean, mean, mean};
+    g[j] = ok ? gp[i] : in_f4{0.f, 0.f, 0.f, 0.f};
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < E4; ++j) {
+    z[j] = (z[j] - mean) * rstd;
+    g[j].x *= act_grad_from_pre(z[j].x, act, slope);
+    g[j].y *= act_grad_from_pre(z[j].y, act, slope);
+    g[j].z *= act_grad_from_pre(z[j].z, act, slope);
+    g[j].w *= act_grad_from_pre(z[j].w, act, slope);
+    s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+    s2 += (g[j].x * z[j].x + g[j].y * z[j].y) + (g[j].z * z[j].z + g[j].w * z[j].w);
+  }
+  s1 = group_sum<G>(s1, red);
+  s2 = group_sum<G>(s2, red);
+  if (!live) return;
+  const float inv = 1.f / (float)HW;
+  const float m1 = s1 * inv, m2 = s2 * inv;
+  in_f4* op = reinterpret_cast<in_f4*>(gx + base);
+#pragma unroll
+  for (int j = 0; j < E4; ++j) {
+    const int i = tg + G * j;
+    if (i < HW4) op[i] = rstd * (g[j] - m1 - z[j] * m2);
+  }
+}
+
 // ---------------- InstanceNorm, large planes (beyond the register budget of 1024 threads: 256 x 256 at configs[3]) ---------------
 // One workgroup of 1024 threads per plane, float4 streams with four loads in flight per thread; the plane (256 KB at 256^2, plus
 // gy in the backward) stays in the XCD's L2 between the passes, so the extra passes are L2 reads.  The register kernels above
@@ -330,6 +435,30 @@ inline void instnorm_shape(int HW, int maxE, int& G, int& E) {
     case 256: SG_IN_DISPATCH_E(KERNEL, 256, __VA_ARGS__) break;           \
     default: SG_IN_DISPATCH_E1024(KERNEL, TOP, __VA_ARGS__) break;        \
   }
+
+// vector form: (G, E4) for a plane of HW = 4 HW4 elements; max4 = float4s per thread the instantiations allow
+inline void instnorm_shape_vec(int HW, int max4, int& G, int& E4) {
+  const int HW4 = HW / 4;
+  G = HW4 <= 16 ? 16 : (HW4 <= 64 * 4 ? 64 : (HW4 <= 256 * max4 ? 256 : (HW4 <= 1024 * (max4 / 2) ? 1024 : 0)));
+  if (HW % 4 != 0 || G == 0) { G = 0; E4 = 0; return; }
+  const int e = (HW4 + G - 1) / G;
+  E4 = e <= 1 ? 1 : (e <= 2 ? 2 : (e <= 4 ? 4 : (e <= 8 ? 8 : 16)));
+}
+#define SG_INV_CASE(KERNEL, Gv, Ev, ...)                                                                              \
+  hipLaunchKernelGGL((KERNEL<Gv, Ev>), dim3(sg_cdiv(NC, Gv >= 256 ? 1 : 256 / Gv)), dim3(Gv > 256 ? Gv : 256), 0, s, __VA_ARGS__)
+// every (G, E4) pair instnorm_shape_vec can return for the given max4 -- and no other instantiation (a 1024-thread group has 128
+// registers per thread: 8 float4s of plane data forward, 2 x 4 backward)
+#define SG_INV_ROW(KERNEL, Gv, ...)                                        \
+  switch (E4) {                                                            \
+    case 1: SG_INV_CASE(KERNEL, Gv, 1, __VA_ARGS__); break;                \
+    case 2: SG_INV_CASE(KERNEL, Gv, 2, __VA_ARGS__); break;                \
+    default: SG_INV_CASE(KERNEL, Gv, 4, __VA_ARGS__); break;               \
+  }
+inline bool instnorm_vec_ok(int HW, const void* a, const void* b, const void* c, const void* d) {
+  const uintptr_t u = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+                      reinterpret_cast<uintptr_t>(d);
+  return HW % 4 == 0 && (u & 15) == 0;
+}
 
 // ---------------- BatchNorm2d: one block per channel ---------------------------------------------
 // ---- BatchNorm2d (+ fused activation), three stages so that a 64..256-channel layer fills the chip ---------------------
@@ -1021,7 +1150,20 @@ extern "C" int sg_instnorm_fwd(const float* x, const float* skip, float* y, floa
   const int reg = sg_opt(SG_OPT_INSTNORM_REG);      // 0: the three-pass kernels
   int G = 0, E = 0;
   instnorm_shape(HW, 64, G, E);
-  if (reg && G > 0) {
+  int G4 = 0, E4 = 0;
+  if (reg >= 2 && instnorm_vec_ok(HW, x, y, skip, nullptr)) instnorm_shape_vec(HW, 16, G4, E4);
+  if (G4 > 0) {
+    // forward: up to 16 float4s (64 values) per thread in groups of <= 256 threads, 8 in groups of 1024
+#define SG_INV_FWD(Gv, Ev) SG_INV_CASE(instnorm_fwd_vec_kernel, Gv, Ev, x, skip, y, mean, rstd, NC, HW, eps, act, slope)
+    if (G4 == 16) { SG_INV_FWD(16, 1); }
+    else if (G4 == 64) { SG_INV_ROW(instnorm_fwd_vec_kernel, 64, x, skip, y, mean, rstd, NC, HW, eps, act, slope) }
+    else if (G4 == 256 && E4 == 16) { SG_INV_FWD(256, 16); }
+    else if (G4 == 256 && E4 == 8) { SG_INV_FWD(256, 8); }
+    else if (G4 == 256) { SG_INV_ROW(instnorm_fwd_vec_kernel, 256, x, skip, y, mean, rstd, NC, HW, eps, act, slope) }
+    else if (E4 == 8) { SG_INV_FWD(1024, 8); }
+    else { SG_INV_ROW(instnorm_fwd_vec_kernel, 1024, x, skip, y, mean, rstd, NC, HW, eps, act, slope) }
+#undef SG_INV_FWD
+  } else if (reg && G > 0) {
     SG_IN_DISPATCH(instnorm_fwd_reg_kernel, 32, x, skip, y, mean, rstd, NC, HW, eps, act, slope)
   } else if (reg && instnorm_big_ok(HW, x, y, skip, nullptr)) {
     hipLaunchKernelGGL(instnorm_fwd_big_kernel, dim3(NC), dim3(1024), 0, s, x, skip, y, mean, rstd, HW, eps, act, slope);
@@ -1039,7 +1181,18 @@ extern "C" int sg_instnorm_bwd(const float* x, const float* gy, const float* mea
   const int reg = sg_opt(SG_OPT_INSTNORM_REG);
   int G = 0, E = 0;
   instnorm_shape(HW, 32, G, E);                        // (two register arrays: 2 x 32 values per thread at most)
-  if (reg && G > 0) {
+  int G4 = 0, E4 = 0;
+  if (reg >= 2 && instnorm_vec_ok(HW, x, gy, gx, nullptr)) instnorm_shape_vec(HW, 8, G4, E4);
+  if (G4 > 0) {
+    // backward (two register arrays): up to 8 float4s per array and thread in groups of <= 256 threads, 4 in groups of 1024
+#define SG_INV_BWD(Gv, Ev) SG_INV_CASE(instnorm_bwd_vec_kernel, Gv, Ev, x, gy, mean, rstd, gx, NC, HW, act, slope)
+    if (G4 == 16) { SG_INV_BWD(16, 1); }
+    else if (G4 == 64) { SG_INV_ROW(instnorm_bwd_vec_kernel, 64, x, gy, mean, rstd, gx, NC, HW, act, slope) }
+    else if (G4 == 256 && E4 == 8) { SG_INV_BWD(256, 8); }
+    else if (G4 == 256) { SG_INV_ROW(instnorm_bwd_vec_kernel, 256, x, gy, mean, rstd, gx, NC, HW, act, slope) }
+    else { SG_INV_ROW(instnorm_bwd_vec_kernel, 1024, x, gy, mean, rstd, gx, NC, HW, act, slope) }
+#undef SG_INV_BWD
+  } else if (reg && G > 0) {
     SG_IN_DISPATCH(instnorm_bwd_reg_kernel, 16, x, gy, mean, rstd, gx, NC, HW, act, slope)
   } else if (reg && instnorm_big_ok(HW, x, gy, gx, nullptr)) {
     hipLaunchKernelGGL(instnorm_bwd_big_kernel, dim3(NC), dim3(1024), 0, s, x, gy, mean, rstd, gx, HW, act, slope);

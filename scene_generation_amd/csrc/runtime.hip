@@ -30,8 +30,8 @@ const OptDef kOpts[SG_OPT_COUNT] = {
     {"tile", -1}, {"t128_min", 384}, {"tile3", 1}, {"tile3_min", 768}, {"split_target", 1536}, {"split_kmin", 1024}, {"splits", -1}, {"fixedtap", 1}, {"wino_wt", 1},
     {"w24_small", 1}, {"w24_s", -1}, {"w24_pmin", 256}, {"wino_adjoint", 1}, {"wino24", 1}, {"linear_nsub", 2},
     {"linear_skinny", 2048}, {"wgrad_rowsum", 1}, {"layout_reg", 1}, {"layout_dsplit", 1}, {"bn_blocks", 4096},
-    {"instnorm_reg", 1}, {"wgrad_xcd", 1}, {"wino_reuse", 1}, {"wino_fold_cells", 1}, {"wino_pipe", 2},
-    {"check_indices", 0}, {"last_block", 0}, {"wino_gemm_tile", 0}, {"wino43", 1}, {"gconv_fused_gather", 1}, {"w24_gemm_tile", 2}, {"wino_in_fuse", 1}, {"w43_nsub", 1}, {"w43_kfold", 256}, {"wave_prio", 0}, {"par_xcd_chunk", 16}};
+    {"instnorm_reg", 2}, {"wgrad_xcd", 1}, {"wino_reuse", 1}, {"wino_fold_cells", 1}, {"wino_pipe", 2},
+    {"check_indices", 0}, {"last_block", 0}, {"wino_gemm_tile", 0}, {"wino43", 1}, {"gconv_fused_gather", 1}, {"w24_gemm_tile", 2}, {"wino_in_fuse", 1}, {"w43_nsub", 1}, {"w43_kfold", 256}, {"wave_prio", 0}, {"par_xcd_chunk", 16}, {"w43_tail_split", 1}, {"w43_wgrad_tile", 0}};
 // runs when the shared library is loaded, before any entry point can be called: the ONLY place the environment is read
 struct OptInit {
   OptInit() {
@@ -84,8 +84,8 @@ unsigned g_cnt_ring[CNT_DEVICES] = {};
 int g_cnt_cap[CNT_DEVICES] = {};
 }  // namespace
 
-int* sg_counter_alloc(hipStream_t s, int n) {
-  if (!sg_opt(SG_OPT_LAST_BLOCK) || n < 1 || n > 4096) return nullptr;
+int* sg_counter_alloc(hipStream_t s, int n, bool always) {
+  if ((!always && !sg_opt(SG_OPT_LAST_BLOCK)) || n < 1 || n > 4096) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CNT_DEVICES) return nullptr;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -109,6 +109,35 @@ int* sg_counter_alloc(hipStream_t s, int n) {
   if (at + (unsigned)n > (unsigned)CNT_RING) at = 0;
   g_cnt_ring[dev] = at + (unsigned)n;
   return g_cnt_pool[dev] + at;
+}
+
+namespace {
+struct TailScratch { int dev; hipStream_t s; float* p; size_t bytes; };
+std::vector<TailScratch> g_tail;
+}  // namespace
+
+float* sg_tail_scratch(hipStream_t s, size_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  std::lock_guard<std::mutex> lk(g_cnt_mu);
+  for (auto& t : g_tail)
+    if (t.dev == dev && t.s == s) {
+      if (t.bytes >= bytes) return t.p;
+      // a larger request: the old buffer may be baked into a captured graph or still be read by a launch in flight -- it is kept
+      // (a few MB), a new one takes its place
+      if (capturing) return nullptr;
+      float* q = nullptr;
+      if (hipMalloc((void**)&q, bytes) != hipSuccess) return nullptr;
+      t.p = q; t.bytes = bytes;
+      return q;
+    }
+  if (capturing) return nullptr;
+  float* q = nullptr;
+  if (hipMalloc((void**)&q, bytes) != hipSuccess) return nullptr;
+  g_tail.push_back(TailScratch{dev, s, q, bytes});
+  return q;
 }
 
 namespace {

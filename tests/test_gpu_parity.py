@@ -277,6 +277,46 @@ def test_winograd_f43_trunk_shape_vs_f23_and_fp64(hip):
         assert errs['f43_' + name] <= bound, errs
 
 
+def test_winograd_f43_tail_split_at_the_benchmark_shape(hip):
+    """N = 32: the 36 x 32 = 1152 tiles of the F(4x4,3x3) forward / data-gradient GEMMs leave half a round of workgroups per CU on
+    the 256 CUs of an MI355X, and the launch runs the tail-split schedule (igemm_kernel, TileCfg::TAILSPLIT: the tiles of the half
+    round as two workgroups of half the channel range, the last arriver adds the other's accumulators).  Against an fp64
+    reference at the per-layer budget of the trunk conv, and against the plain schedule (option w43_tail_split = 0): the two differ
+    only in where the 256-chunks of the channel sum meet ((c0 + c1) + (c2 + c3) instead of ((c0 + c1) + c2) + c3 in 128 of the
+    1152 tiles).  Ten repeats of the split launch are bit-identical (whichever half arrives last, x + y = y + x)."""
+    from scene_generation_amd import _hip
+    N, C, H = 32, 1024, 8
+    x, w, b = det((N, C, H, H), 321), det((C, C, 3, 3), 322, 0.05), det((C,), 323, 0.2)
+    gy = det((N, C, H, H), 324)
+    xr, wr, br = [t.double().requires_grad_() for t in (x, w, b)]
+    yr = F.conv2d(F.pad(xr, (1,) * 4, mode='reflect'), wr, br)
+    yr.backward(gy.double())
+    saved = _hip.get_option('w43_tail_split')
+    res = {}
+    try:
+        for flag in (1, 0):
+            _hip.set_option('w43_tail_split', flag)
+            xg, wg, bg = [t.to(DEV).requires_grad_() for t in (x, w, b)]
+            yg = hip.conv2d(xg, wg, bg, pad=1, reflect=True)
+            yg.backward(gy.to(DEV))
+            res[flag] = (yg.detach().clone(), xg.grad.clone(), wg.grad.clone())
+            for name, got, want, bound in (('y', yg, yr, 7e-6), ('gx', xg.grad, xr.grad, 5e-6), ('gw', wg.grad, wr.grad, 6e-6)):
+                e = float((got.detach().double().cpu() - want.detach()).abs().max() / want.detach().abs().max())
+                assert e <= bound, (flag, name, e)
+            if flag == 1:
+                for _ in range(10):
+                    x2 = x.to(DEV).requires_grad_()
+                    y2 = hip.conv2d(x2, wg.detach(), bg.detach(), pad=1, reflect=True)
+                    y2.backward(gy.to(DEV))
+                    assert torch.equal(y2, res[1][0]) and torch.equal(x2.grad, res[1][1])
+    finally:
+        _hip.set_option('w43_tail_split', saved)
+    for a, c, name in zip(res[1], res[0], ('y', 'gx', 'gw')):
+        d = float((a - c).abs().max() / c.abs().max())
+        assert d <= 2e-6, (name, d)
+    assert not torch.equal(res[1][0], res[0][0]) or not torch.equal(res[1][1], res[0][1]), 'the split schedule did not run'
+
+
 @pytest.mark.parametrize('N,C,H,Cout,act,with_skip', [(16, 128, 8, 128, 1, True), (8, 128, 16, 256, 2, False), (32, 256, 8, 128, 0, True)])
 def test_conv_instnorm_fused_vs_fp64_and_unfused(hip, N, C, H, Cout, act, with_skip):
     """ReflectionPad(1) + Conv3x3 + InstanceNorm (+ ReLU / LeakyReLU) (+ residual) of a ResnetBlock (layers.py:251-270) as the fused
