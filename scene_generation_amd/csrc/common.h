@@ -74,8 +74,10 @@ enum SgOpt {
   SG_OPT_WAVE_PRIO,       // GEMM kernels: s_setprio 3 outside the main loop (prologue / epilogue VALU work does not queue behind other waves' MFMAs).
                           // OFF: measured on MI355X, profiles/r06_gemm_prio.md -- most classes +-1 %, Gup4 fwd +11 %, F(4x4,3x3) dgrad / wgrad +7 %, step -0.3 %
   SG_OPT_PAR_XCD_CHUNK,   // parity-class launches: tiles dealt to the XCDs in chunks of this many (power of two; 0 = one contiguous eighth per XCD)
-  SG_OPT_W43_TAIL_SPLIT,  // F(4x4,3x3) forward / data-gradient GEMMs whose tile count leaves half a round per CU (36 x 32 tiles on 256 CUs):
+  SG_OPT_W43_TAIL_SPLIT,  // tail split (igemm_kernel): 0 = off; 1 = F(4x4,3x3) forward / data-gradient GEMMs whose tile count leaves half a round per CU (36 x 32 tiles on 256 CUs); 2 = also the general form (plain conv GEMM launches with a ragged last round):
                           // the tiles of the half round run as two workgroups of half the k range each (igemm_kernel, TileCfg::TAILSPLIT)
+  SG_OPT_TAIL_SMAX,       // tail split, general form: at most this many pieces per tile (2..8)
+  SG_OPT_TAIL_KTMIN,      // ... and no piece shorter than this many k-tiles
   SG_OPT_W43_WGRAD_TILE,  // tile of the F(4x4,3x3) weight-gradient GEMMs (K = the 128 Winograd tiles): 0 = 64x64 (9216 workgroups), 1 = 128x128, 2 = 64x128
   SG_OPT_COUNT
 };

@@ -4,6 +4,7 @@
 // file took 3.5 minutes).  Templates and kernels have internal linkage (one copy per unit); the plain structs and the
 // shape-table cache shared between units live in namespace sgk.
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include <stdlib.h>
 #include <array>
@@ -109,8 +110,8 @@ constexpr int BK = 16;     // sub-tile depth: the unit one loader call stages (1
 // study with tools/winograd_f43.py: all-fp32 3.9e-6 of max|y| at K = 1024, 2.5e-6 with 256-chunks, 1.4e-6 with 128-chunks,
 // 0.6e-6 with an fp64 accumulator; transforms in fp64 instead: no change).  Cost: 2 x 16 vector-ALU instructions per wave and
 // chunk boundary and 16 more registers per 32x32 accumulator.  Deterministic; the order is a function of K alone.
-// TS_ = 1: the kernel carries the TAIL-SPLIT schedule (BatchInfo::tail_*; batched full-tile launches only): see igemm_kernel.
-template <int BM_, int BN_, int WGM_, int NSUB_, int PIPE_ = SG_PIPE_DEFAULT, int KFOLD_ = 0, int TS_ = 0>
+// TS_ = 1 (every pipelined instantiation): the kernel carries the TAIL-SPLIT schedule (BatchInfo::tail_*): see igemm_kernel.
+template <int BM_, int BN_, int WGM_, int NSUB_, int PIPE_ = SG_PIPE_DEFAULT, int KFOLD_ = 0, int TS_ = (PIPE_ != 0 ? 1 : 0)>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = 4 / WGM_, NSUB = NSUB_, BKT = BK * NSUB_, PIPE = PIPE_;
   static constexpr int KFOLD = KFOLD_, TAILSPLIT = TS_;
@@ -1102,6 +1103,9 @@ struct BatchInfo {
   // of half the k range each; grid.x = tiles + 8 * tail_sx.  tail_slab: 2 x 16 KB x TM x TN per split tile of raw accumulators,
   // tail_cnt: one arrival counter per split tile (zero, reset by the last arriver).
   int tail_sx; float* tail_slab; int* tail_cnt;
+  // general form (plain launches: grid.z == 1, no batches, no parity classes): the LAST tail_n tiles run as tail_s workgroups of
+  // 1 / tail_s of the k range each, numbered before (tail_first) or after the whole tiles; grid.x = tiles + tail_n (tail_s - 1)
+  int tail_n, tail_s, tail_first;
   ParityClasses par;
 };
 // per-class hooks: loaders / epilogues that can run a parity class overload these; everything else ignores the call
@@ -1178,7 +1182,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   const int tiles_n = bi.cols_per_batch > 0 ? bi.nbatch * tiles_pb : (N + BN - 1) / BN;
   const int nwg = gridDim.x;
   int bid = blockIdx.x;
-  int ts_half = -1, ts_slot = 0;               // tail split: which half of the k range this workgroup runs (-1: all of it)
+  int ts_half = -1, ts_slot = 0, ts_s = 2;     // tail split: which piece of the k range this workgroup runs (-1: all of it), of how many
   // Prologue and epilogue of a workgroup are a few hundred vector-ALU / scalar instructions (index arithmetic, store addresses)
   // on a SIMD whose other resident waves issue 64-cycle f32 MFMAs back to back; the f32 MFMA does not co-execute with VALU
   // work and the arbiter serves the oldest wave first, so the NEW wave's instructions each waited for a whole MFMA slot:
@@ -1199,6 +1203,27 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     if (bid < full) {
       const int xcd = bid & 7, idx = bid >> 3;
       bid = ((idx / G) * 8 + xcd) * G + (idx % G);
+    }
+  } else if (CFG::TAILSPLIT && bi.tail_n > 0) {
+    // Tail split, general form.  A launch of T tiles runs as rounds of (CUs x resident workgroups) and its last round is rarely
+    // full: the workgroups of that round run with the CU nearly to themselves -- a lone wave per SIMD drives the matrix pipe at
+    // 48 % (timeline probe) -- while the rest of the chip idles; with 1.3-4.5 rounds per launch (every conv GEMM of the step) that
+    // is 10-30 % of the launch.  The last tail_n tiles therefore run as tail_s workgroups of 1 / tail_s of the k range each:
+    // more, shorter workgroups in the ragged round (dispatched last), or -- when everything is resident at once -- short extra
+    // workgroups next to the whole tiles of every CU (dispatched first).  The pieces of a tile meet in the epilogue.
+    const int s_ = bi.tail_s, P = bi.tail_n * s_, nfull = nwg - P;
+    const int b = bid;
+    const bool piece = bi.tail_first ? b < P : b >= nfull;
+    if (piece) {
+      const int pb = bi.tail_first ? b : b - nfull;
+      ts_slot = pb / s_;
+      ts_half = pb - ts_slot * s_;
+      ts_s = s_;
+      bid = nfull + ts_slot;
+    } else {
+      const int f = bi.tail_first ? b - P : b;      // (host: P % 8 == 0 when the pieces come first, so f & 7 is still the XCD)
+      const int q = nfull >> 3, rem = nfull & 7, xcd = f & 7, idx = f >> 3;
+      bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
     }
   } else if (CFG::TAILSPLIT && bi.tail_sx > 0) {
     // Tail split.  T tiles on 256 CUs with T % 256 == 128: every CU runs 4 workgroups and half of the CUs a 5th -- five resident
@@ -1258,8 +1283,12 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     kend = min((img + 1) * bi.kimg, kbeg + bi.kcs);
   }
   if (CFG::TAILSPLIT && ts_half >= 0) {
-    const int kh = (kend - kbeg) >> 1;         // (host: a multiple of the k-tile and of KFOLD)
-    if (ts_half) kbeg += kh; else kend = kbeg + kh;
+    // piece p of ts_s: whole k-tiles, ceil(tiles / ts_s) each (host: boundaries are multiples of KFOLD where the kernel has one);
+    // a piece beyond the end of the range is empty (it still takes its ticket)
+    const int kt = (kend - kbeg + BKT - 1) / BKT, per = (kt + ts_s - 1) / ts_s;
+    const int kb = min(kend, kbeg + ts_half * per * BKT);
+    kend = min(kend, kb + per * BKT);
+    kbeg = kb;
   }
   if (bi.cols_per_batch > 0) {
     int tn = bid % tiles_n, batch = tn / tiles_pb;
@@ -1441,13 +1470,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     if (bi.prio) __builtin_amdgcn_s_setprio(3);
     if constexpr (CFG::TAILSPLIT != 0) {
       if (ts_half >= 0) {
-        // The two halves of a split tile: each dumps its raw accumulators (write-through 16-byte stores, lane-contiguous: 1 KB per
-        // wave instruction) and takes a ticket; the one that arrives LAST adds the other's dump to its registers and stores the
-        // tile.  No waiting, no pre-zeroed output; x + y is commutative, so the result does not depend on who arrives last.
+        // The pieces of a split tile: each dumps its raw accumulators (write-through 16-byte stores, lane-contiguous: 1 KB per
+        // wave instruction) and takes a ticket; the one that arrives LAST combines and stores the tile.  No waiting, no pre-zeroed
+        // output.  Two pieces: the last arriver adds the other's dump to its registers (x + y is commutative: the result does not
+        // depend on who arrives last); more: it re-reads ALL dumps, its own included, and adds them in piece order.
         // (Visibility: sc1 stores drained before the ticket, sc1 loads after it -- the recipe of sg_arrive_last, common.h.)
         __shared__ int ts_flag;
         constexpr int PERW = TM * TN * 16 * 64;                                  // floats one wave dumps
-        float* mine = bi.tail_slab + ((size_t)(ts_slot * 2 + ts_half) * 4 + wid) * PERW;
+        float* mine = bi.tail_slab + ((size_t)(ts_slot * ts_s + ts_half) * 4 + wid) * PERW;
         const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(mine, 0, PERW * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -1459,20 +1489,32 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
               __builtin_memcpy(&d, reinterpret_cast<const char*>(&acc[i][j]) + 16 * v, 16);
               __builtin_amdgcn_raw_buffer_store_b128(d, rm, (((i * TN + j) * 4 + v) * 64 + lane) * 16, 0, 16 /* sc1 */);
             }
-        if (!sg_arrive_last(bi.tail_cnt + ts_slot, 2, &ts_flag)) return;
-        const float* theirs = bi.tail_slab + ((size_t)(ts_slot * 2 + (1 - ts_half)) * 4 + wid) * PERW;
-        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(theirs), 0, PERW * 4, 0x00020000);
+        if (!sg_arrive_last(bi.tail_cnt + ts_slot, ts_s, &ts_flag)) return;
+        const bool two = ts_s == 2;
+        if (!two) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-              const auto d = __builtin_amdgcn_raw_buffer_load_b128(rt, (((i * TN + j) * 4 + v) * 64 + lane) * 16, 0, 16 /* sc1 */);
-              float4 f;
-              __builtin_memcpy(&f, &d, 16);
-              acc[i][j][4 * v + 0] += f.x; acc[i][j][4 * v + 1] += f.y; acc[i][j][4 * v + 2] += f.z; acc[i][j][4 * v + 3] += f.w;
-            }
+              for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+        for (int pc = 0; pc < ts_s; ++pc) {
+          if (two && pc == ts_half) continue;
+          const float* theirs = bi.tail_slab + ((size_t)(ts_slot * ts_s + pc) * 4 + wid) * PERW;
+          const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(theirs), 0, PERW * 4, 0x00020000);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                const auto d = __builtin_amdgcn_raw_buffer_load_b128(rt, (((i * TN + j) * 4 + v) * 64 + lane) * 16, 0, 16 /* sc1 */);
+                float4 f;
+                __builtin_memcpy(&f, &d, 16);
+                acc[i][j][4 * v + 0] += f.x; acc[i][j][4 * v + 1] += f.y; acc[i][j][4 * v + 2] += f.z; acc[i][j][4 * v + 3] += f.w;
+              }
+        }
       }
     }
     rowsum_finish(al, zblk);
@@ -1617,19 +1659,55 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
   const bool plain_z = t_grid_z == 0 && t_fixed_kchunk == 0 && bi.ksplit == 0;
   const bool image_z = t_grid_z > 0 && bi.ksplit > 0 && t_xcd_z == 2;
   bi.xcd_z = (t_xcd_z && (plain_z || image_z) && bi.cols_per_batch == 0 && bi.par.ncls == 0 && grid.z >= 8 && grid.z % 8 == 0) ? 1 : 0;
-  bi.tail_sx = 0; bi.tail_slab = nullptr; bi.tail_cnt = nullptr;
+  bi.tail_sx = 0; bi.tail_slab = nullptr; bi.tail_cnt = nullptr; bi.tail_n = 0; bi.tail_s = 0; bi.tail_first = 0;
   if constexpr (CFG::TAILSPLIT != 0) {
-    // half a round of workgroups per CU left over (tiles % 256 == 128 on the 256 CUs of an MI355X: the 36 x 32 tiles of the
-    // F(4x4,3x3) GEMMs at the benchmark shape): split those tiles' k range in two (see the kernel)
     static const int n_cu = [] { int d = 0, v = 0; hipGetDevice(&d); hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v; }();
+    // workgroups of THIS instantiation a CU holds at once (registers / LDS)
+    static const int resident = [] {
+      int c = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, reinterpret_cast<const void*>(&igemm_kernel<CFG, AL, BL, EP>), 256, 0) != hipSuccess) c = 0;
+      return c;
+    }();
+    const int mode = sg_opt(SG_OPT_W43_TAIL_SPLIT);     // 0: off, 1: the F(4x4,3x3) half-round case only, 2: + the general form
+    constexpr size_t PIECE_BYTES = (size_t)4 * CFG::TM * CFG::TN * 16 * 64 * sizeof(float);
+    const bool plain = grid.z == 1 && splits <= 1 && bi.kcnt == nullptr && bi.ksplit == 0 && bi.par.ncls == 0 && !bi.xcd_z;
     const int kh = K / 2;
-    if (sg_opt(SG_OPT_W43_TAIL_SPLIT) && n_cu == 256 && bi.batch_major && bi.cols_per_batch > 0 && bi.kcnt == nullptr && grid.z == 1 &&
-        splits <= 1 && tiles % 256 == 128 && tiles >= 384 && K % 2 == 0 && kh % CFG::BKT == 0 && kh >= 4 * CFG::BKT &&
+    if (mode >= 1 && n_cu == 256 && plain && bi.batch_major && bi.cols_per_batch > 0 &&
+        tiles % 256 == 128 && tiles >= 384 && K % 2 == 0 && kh % CFG::BKT == 0 && kh >= 4 * CFG::BKT &&
         (CFG::KFOLD == 0 || kh % CFG::KFOLD == 0) && M % CFG::BM == 0 && bi.cols_per_batch % CFG::BN == 0) {
+      // half a round of workgroups per CU left over (the 36 x 32 tiles of the F(4x4,3x3) GEMMs at the benchmark shape): the tiles
+      // of the half round as two half-k workgroups each, one next to the four whole tiles of every CU (see the kernel)
       const int sx = 16, nsplit = 8 * sx;
-      float* slab = sg_tail_scratch(s, (size_t)nsplit * 2 * 4 * CFG::TM * CFG::TN * 16 * 64 * sizeof(float));
+      float* slab = sg_tail_scratch(s, (size_t)nsplit * 2 * PIECE_BYTES);
       int* cnt = slab ? sg_counter_alloc(s, nsplit, true) : nullptr;
       if (slab && cnt) { bi.tail_sx = sx; bi.tail_slab = slab; bi.tail_cnt = cnt; grid.x = tiles + nsplit; }
+    } else if (mode >= 2 && n_cu > 0 && resident > 0 && plain && bi.cols_per_batch == 0 && CFG::KFOLD == 0 &&
+               !std::is_same<EP, EpWgrad>::value) {
+      const int smax = sg_opt(SG_OPT_TAIL_SMAX) < 2 ? 2 : (sg_opt(SG_OPT_TAIL_SMAX) > 8 ? 8 : sg_opt(SG_OPT_TAIL_SMAX));
+      const int kt = sg_cdiv(K, CFG::BKT), slots = n_cu * resident;
+      int n = 0, sp = 0, first = 0;
+      if (tiles <= slots) {                      // everything resident at once: r CUs carry one workgroup more than the others
+        const int r = tiles % n_cu;
+        if (r > 0 && tiles > n_cu) { n = r; sp = (n_cu + r / 2) / r; first = 1; }
+      } else {                                   // the last round holds R of `slots` workgroups
+        const int R = tiles % slots;
+        if (R > 0 && 4 * R < 3 * slots) { n = R; sp = slots / R; first = 0; }
+      }
+      if (sp > smax) sp = smax;
+      while (sp >= 2 && kt / sp < sg_opt(SG_OPT_TAIL_KTMIN)) --sp;      // pieces of at least this many k-tiles
+      if (first && sp >= 2) {                    // pieces first: n * sp must be a multiple of 8 (the whole tiles keep their XCDs)
+        int g = sp, h = 8;
+        while (h) { const int t = g % h; g = h; h = t; }
+        n -= n % (8 / g);
+      }
+      if (n > 0 && sp >= 2 && n <= 4096) {
+        float* slab = sg_tail_scratch(s, (size_t)n * sp * PIECE_BYTES);
+        int* cnt = slab ? sg_counter_alloc(s, n, true) : nullptr;
+        if (slab && cnt) {
+          bi.tail_n = n; bi.tail_s = sp; bi.tail_first = first; bi.tail_slab = slab; bi.tail_cnt = cnt;
+          grid.x = tiles + n * (sp - 1);
+        }
+      }
     }
   }
   AL al2 = al; BL bl2 = bl; EP ep2 = ep;
