@@ -317,6 +317,35 @@ def test_winograd_f43_tail_split_at_the_benchmark_shape(hip):
     assert not torch.equal(res[1][0], res[0][0]) or not torch.equal(res[1][1], res[0][1]), 'the split schedule did not run'
 
 
+@pytest.mark.parametrize('shape', [(32, 64, 65, 65, 128, 4, 2, 2), (24, 192, 16, 16, 192, 3, 1, 1), (32, 128, 33, 33, 256, 4, 2, 2)])
+def test_tail_split_general_form_vs_plain_schedule(hip, shape):
+    """Option w43_tail_split = 2 (opt-in): a plain conv GEMM launch whose last round of resident workgroups is ragged runs its last
+    tiles as 2-4 workgroups of a fraction of the k range each; the last arriver re-reads all dumps and adds them in piece order.  At
+    layer shapes of the step (PatchGAN scale-0 convs, an object-side 3x3 conv): forward and data gradient equal the plain schedule to
+    fp32 summation order, and five repeats are bit-identical (the combine order does not depend on who arrives last)."""
+    from scene_generation_amd import _hip
+    N, C, H, W, Cout, KS, stride, pad = shape
+    x, w, b = det((N, C, H, W), 331), det((Cout, C, KS, KS), 332, 0.05), det((Cout,), 333, 0.2)
+    saved = _hip.get_option('w43_tail_split')
+    out = {}
+    try:
+        for mode in (2, 0):
+            _hip.set_option('w43_tail_split', mode)
+            reps = []
+            for _ in range(5 if mode == 2 else 1):
+                xg, wg, bg = [t.to(DEV).requires_grad_() for t in (x, w, b)]
+                yg = hip.conv2d(xg, wg, bg, stride=stride, pad=pad)
+                yg.backward(det(tuple(yg.shape), 334).to(DEV))
+                reps.append((yg.detach().clone(), xg.grad.clone(), wg.grad.clone()))
+            for r in reps[1:]:
+                assert all(torch.equal(a, c) for a, c in zip(r, reps[0]))
+            out[mode] = reps[0]
+    finally:
+        _hip.set_option('w43_tail_split', saved)
+    for a, c, name in zip(out[2], out[0], ('y', 'gx', 'gw')):
+        close(a, c, 2e-6, 'tail split ' + name)
+
+
 @pytest.mark.parametrize('N,C,H,Cout,act,with_skip', [(16, 128, 8, 128, 1, True), (8, 128, 16, 256, 2, False), (32, 256, 8, 128, 0, True)])
 def test_conv_instnorm_fused_vs_fp64_and_unfused(hip, N, C, H, Cout, act, with_skip):
     """ReflectionPad(1) + Conv3x3 + InstanceNorm (+ ReLU / LeakyReLU) (+ residual) of a ResnetBlock (layers.py:251-270) as the fused
