@@ -1217,7 +1217,10 @@ def _seg_norms(v, hg):
     return torch.stack([v[o:o + n].norm() for o, n in zip(hg.offsets, hg.numels)]).cpu()
 
 
-def _compare_grads(snaps, tag):
+_GRAD_LOG = {}
+
+
+def _compare_grads(snaps, tag, rel_tol=3e-2, cos_tol=0.9995, small_floor=1e-3):
     """HIP gradients of a whole step vs the fp32 oracle's.
 
     Single operators agree to ~1e-5 (tests above).  Through the 40-layer generator the forward activations differ
@@ -1232,7 +1235,7 @@ def _compare_grads(snaps, tag):
         gh = snaps['hip'][n]
         fa, fb = gh.flat_pair(gr)                     # float64, on the device
         cos = float(fa @ fb / (fa.norm() * fb.norm() + 1e-30))
-        assert cos > 0.9995, '%s %s: flat gradient cosine %.6f' % (tag, n, cos)
+        assert cos > cos_tol, '%s %s: flat gradient cosine %.6f' % (tag, n, cos)
         gmax, gnorm = float(fb.abs().max()), float(fb.norm())
         dn, bn = _seg_norms(fa - fb, gh), _seg_norms(fb, gh)
         dmax = torch.stack([(fa[o:o + k] - fb[o:o + k]).abs().max() for o, k in zip(gh.offsets, gh.numels)]).cpu()
@@ -1242,9 +1245,11 @@ def _compare_grads(snaps, tag):
             lim = 0.5 * float(bmax[i]) + 1e-4 * gmax + 1e-9      # single entries only; (2) bounds the bulk
             assert err <= lim, '%s %s param %d: grad err %.3e > %.3e (|g|max %.3e, global %.3e)' % (
                 tag, n, i, err, lim, float(bmax[i]), gmax)
-            if float(bn[i]) > 1e-3 * gnorm:
+            if float(bn[i]) > small_floor * gnorm:
                 rel = float(dn[i] / bn[i])
-                assert rel <= 3e-2, '%s %s param %d: relative L2 gradient error %.3e' % (tag, n, i, rel)
+                key = '%s/%s' % (tag, n)
+                _GRAD_LOG[key] = max(_GRAD_LOG.get(key, 0.0), rel)
+                assert rel <= rel_tol, '%s %s param %d: relative L2 gradient error %.3e' % (tag, n, i, rel)
 
 
 def _compare_outputs(tr, ref, out, out_ref, tol):
@@ -1299,8 +1304,16 @@ def test_full_step_vs_oracle(hip, cfg):
         random.seed(5 + it)
         out = tr.step(batch_to(batch, DEV), use_gt=(it == 0))
         _compare_outputs(tr, ref, out, out_ref, 2e-4)
-        _compare_grads(snaps, 'it%d' % it)
+        # 'reduced' (every kernel family at small widths: few units sit within fp32 noise of a ReLU kink) is compared TIGHTLY, tensor
+        # by tensor, down to tensors of 1e-6 of the flat gradient's norm: measured worst relative L2 8.4e-6 (generator), 2-5e-6
+        # (discriminators), gpurun_out/grad_rel_l2_reduced.json -- a 1 % systematic error in ANY parameter tensor, however small,
+        # fails here (the full-width bounds below cannot see one)
+        if cfg == 'reduced':
+            _compare_grads(snaps, '%s_it%d' % (cfg, it), rel_tol=1e-4, cos_tol=0.9999999, small_floor=1e-6)
+        else:
+            _compare_grads(snaps, '%s_it%d' % (cfg, it))
         _sync_state(ref, tr)
+    _dump('grad_rel_l2_%s.json' % cfg, {k: v for k, v in _GRAD_LOG.items() if k.startswith(cfg)})
 
 
 # ------------------------------------------------------------------------------------------
