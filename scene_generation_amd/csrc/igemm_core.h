@@ -1157,6 +1157,9 @@ template <class CFG, class AL, class BL, class EP>
 __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, int N, int K, int kchunk, BatchInfo bi) {
   constexpr int BM = CFG::BM, BN = CFG::BN, TM = CFG::TM, TN = CFG::TN, LDA = CFG::LDA, LDB = CFG::LDB;
   constexpr int NSUB = CFG::NSUB, BKT = CFG::BKT;
+  // tail split compiled in (weight-gradient launches are split-K launches with row sums: never eligible, and the extra code cost
+  // the 128x128 tap-major instantiation its second wave per SIMD)
+  constexpr bool TSPLIT = CFG::TAILSPLIT != 0 && !std::is_same<EP, EpWgrad>::value;
   __shared__ __attribute__((aligned(16))) float As[2][NSUB * BM * LDK];
   __shared__ __attribute__((aligned(16))) float Bs[2][NSUB * BN * LDK];
   __shared__ int tapA[AL::LDS_INTS > 0 ? AL::LDS_INTS : 1];
@@ -1204,7 +1207,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
       const int xcd = bid & 7, idx = bid >> 3;
       bid = ((idx / G) * 8 + xcd) * G + (idx % G);
     }
-  } else if (CFG::TAILSPLIT && bi.tail_n > 0) {
+  } else if (TSPLIT && bi.tail_n > 0) {
     // Tail split, general form.  A launch of T tiles runs as rounds of (CUs x resident workgroups) and its last round is rarely
     // full: the workgroups of that round run with the CU nearly to themselves -- a lone wave per SIMD drives the matrix pipe at
     // 48 % (timeline probe) -- while the rest of the chip idles; with 1.3-4.5 rounds per launch (every conv GEMM of the step) that
@@ -1225,7 +1228,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
       const int q = nfull >> 3, rem = nfull & 7, xcd = f & 7, idx = f >> 3;
       bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
     }
-  } else if (CFG::TAILSPLIT && bi.tail_sx > 0) {
+  } else if (TSPLIT && bi.tail_sx > 0) {
     // Tail split.  T tiles on 256 CUs with T % 256 == 128: every CU runs 4 workgroups and half of the CUs a 5th -- five resident
     // workgroups share the matrix pipe of those CUs (2560 cycles per k-tile instead of 2170: tools/probe/timeline_probe.py) and
     // the launch ends when THEY end, the other half of the chip idle for the last ~10 % (profiles/r06_timeline_after_Gres_fwd.txt).
@@ -1282,7 +1285,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     kbeg = img * bi.kimg + q * bi.kcs;
     kend = min((img + 1) * bi.kimg, kbeg + bi.kcs);
   }
-  if (CFG::TAILSPLIT && ts_half >= 0) {
+  if (TSPLIT && ts_half >= 0) {
     // piece p of ts_s: whole k-tiles, ceil(tiles / ts_s) each (host: boundaries are multiples of KFOLD where the kernel has one);
     // a piece beyond the end of the range is empty (it still takes its ticket)
     const int kt = (kend - kbeg + BKT - 1) / BKT, per = (kt + ts_s - 1) / ts_s;
@@ -1293,7 +1296,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
   if (bi.cols_per_batch > 0) {
     int tn = bid % tiles_n, batch = tn / tiles_pb;
     if (bi.batch_major) {
-      const int per_batch = (int)((gridDim.x - 8u * (unsigned)(CFG::TAILSPLIT ? bi.tail_sx : 0)) / (unsigned)bi.nbatch);   // = tiles_m * tiles_pb
+      const int per_batch = (int)((gridDim.x - 8u * (unsigned)(TSPLIT ? bi.tail_sx : 0)) / (unsigned)bi.nbatch);   // = tiles_m * tiles_pb
       batch = bid / per_batch;
       const int r = bid - batch * per_batch;
       m0 = (r / tiles_pb) * BM;
@@ -1468,14 +1471,17 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     }
     SG_TL_STAMP(3);
     if (bi.prio) __builtin_amdgcn_s_setprio(3);
-    if constexpr (CFG::TAILSPLIT != 0) {
+    if constexpr (TSPLIT) {
       if (ts_half >= 0) {
         // The pieces of a split tile: each dumps its raw accumulators (write-through 16-byte stores, lane-contiguous: 1 KB per
         // wave instruction) and takes a ticket; the one that arrives LAST combines and stores the tile.  No waiting, no pre-zeroed
         // output.  Two pieces: the last arriver adds the other's dump to its registers (x + y is commutative: the result does not
         // depend on who arrives last); more: it re-reads ALL dumps, its own included, and adds them in piece order.
         // (Visibility: sc1 stores drained before the ticket, sc1 loads after it -- the recipe of sg_arrive_last, common.h.)
-        __shared__ int ts_flag;
+        // (the ticket flag lives in the first word of the A tile: the main loop is over, and sg_arrive_last passes a barrier before
+        //  it writes -- a separate __shared__ int pushed the 128x128 instantiations from 81920 to 81924 bytes of LDS, i.e. from two
+        //  workgroups per CU to one)
+        int* ts_flag = reinterpret_cast<int*>(&As[0][0]);
         constexpr int PERW = TM * TN * 16 * 64;                                  // floats one wave dumps
         float* mine = bi.tail_slab + ((size_t)(ts_slot * ts_s + ts_half) * 4 + wid) * PERW;
         const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(mine, 0, PERW * 4, 0x00020000);
@@ -1489,7 +1495,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
               __builtin_memcpy(&d, reinterpret_cast<const char*>(&acc[i][j]) + 16 * v, 16);
               __builtin_amdgcn_raw_buffer_store_b128(d, rm, (((i * TN + j) * 4 + v) * 64 + lane) * 16, 0, 16 /* sc1 */);
             }
-        if (!sg_arrive_last(bi.tail_cnt + ts_slot, ts_s, &ts_flag)) return;
+        if (!sg_arrive_last(bi.tail_cnt + ts_slot, ts_s, ts_flag)) return;
         const bool two = ts_s == 2;
         if (!two) {
 #pragma unroll
@@ -1660,7 +1666,7 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
   const bool image_z = t_grid_z > 0 && bi.ksplit > 0 && t_xcd_z == 2;
   bi.xcd_z = (t_xcd_z && (plain_z || image_z) && bi.cols_per_batch == 0 && bi.par.ncls == 0 && grid.z >= 8 && grid.z % 8 == 0) ? 1 : 0;
   bi.tail_sx = 0; bi.tail_slab = nullptr; bi.tail_cnt = nullptr; bi.tail_n = 0; bi.tail_s = 0; bi.tail_first = 0;
-  if constexpr (CFG::TAILSPLIT != 0) {
+  if constexpr (CFG::TAILSPLIT != 0 && !std::is_same<EP, EpWgrad>::value) {
     static const int n_cu = [] { int d = 0, v = 0; hipGetDevice(&d); hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v; }();
     // workgroups of THIS instantiation a CU holds at once (registers / LDS)
     static const int resident = [] {
