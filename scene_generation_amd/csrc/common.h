@@ -196,7 +196,8 @@ __device__ __forceinline__ bool sg_arrive_last(int* counter, int narrive, int* f
 }
 // a zeroed 4-byte counter in library-owned device memory for ONE launch on stream ``s`` (runtime.hip); nullptr: none available
 // (the caller then runs its two-kernel form).  ``n`` consecutive counters.
-int* sg_counter_alloc(hipStream_t s, int n = 1, bool always = false);     // always: also when the option last_block is off
+int* sg_counter_alloc(hipStream_t s, int n = 1, bool always = false, int family = 1);     // always: also when the option last_block is off;
+// family: bit of the option last_block that enables the caller (1 = losses, 2 = BatchNorm statistics, 4 = channel sums)
 // library-owned device scratch of the tail-split GEMM launches (raw accumulator dumps), one buffer per (device, stream), grown
 // outside stream captures only; nullptr: not available (the caller launches the plain schedule)
 float* sg_tail_scratch(hipStream_t s, size_t bytes);

@@ -1217,7 +1217,7 @@ extern "C" int sg_batchnorm_fwd(const float* x, const float* gamma, const float*
   SgProfScope prof(SG_K_BATCHNORM, s, 0, (double)N * C * HW * 8.0);       // algorithmic: x in, y out
   const int S = bn_slices(N, C, HW);
   float* part = reinterpret_cast<float*>(ws);
-  int* counter = (training && C <= 4096) ? sg_counter_alloc(s, C) : nullptr;
+  int* counter = (training && C <= 4096) ? sg_counter_alloc(s, C, false, 2) : nullptr;
   if (training)
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, S), dim3(256), 0, s, x, part, N, C, HW, S,
                        BnFinal{counter, save_mean, save_rstd, running_mean, running_var, num_batches, eps, momentum});
@@ -1245,7 +1245,7 @@ extern "C" int sg_batchnorm_bwd(const float* x, const float* gy, const float* ga
   const int S = bn_slices(N, C, HW);
   float* part = reinterpret_cast<float*>(ws);
   float* sums = part + (size_t)C * S * 3;
-  int* counter = C <= 4096 ? sg_counter_alloc(s, C) : nullptr;
+  int* counter = C <= 4096 ? sg_counter_alloc(s, C, false, 2) : nullptr;
   hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(C, S), dim3(256), 0, s, x, gy, gamma, beta, save_mean, save_rstd, part, N, C,
                      HW, S, act, slope, counter, sums, ggamma, gbeta);
   if (!counter)
@@ -1280,7 +1280,7 @@ extern "C" int sg_channel_sum(const float* g, float* out, int N, int C, int HW, 
     hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, s, g, out, N, C, HW);
   } else {
     float* part = reinterpret_cast<float*>(ws);
-    int* counter = C <= 4096 ? sg_counter_alloc(s, C) : nullptr;
+    int* counter = C <= 4096 ? sg_counter_alloc(s, C, false, 4) : nullptr;
     hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(C, S), dim3(256), 0, s, g, part, N, C, HW, S, counter, out);
     if (!counter)
       hipLaunchKernelGGL(channel_sum_final_kernel, dim3(sg_cdiv(C, 64)), dim3(64), 0, s, (const float*)part, out, C, S);

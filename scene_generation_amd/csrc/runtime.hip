@@ -84,8 +84,8 @@ unsigned g_cnt_ring[CNT_DEVICES] = {};
 int g_cnt_cap[CNT_DEVICES] = {};
 }  // namespace
 
-int* sg_counter_alloc(hipStream_t s, int n, bool always) {
-  if ((!always && !sg_opt(SG_OPT_LAST_BLOCK)) || n < 1 || n > 4096) return nullptr;
+int* sg_counter_alloc(hipStream_t s, int n, bool always, int family) {
+  if ((!always && !(sg_opt(SG_OPT_LAST_BLOCK) & family)) || n < 1 || n > 4096) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CNT_DEVICES) return nullptr;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
