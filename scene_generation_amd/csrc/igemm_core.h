@@ -1668,12 +1668,15 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
   bi.tail_sx = 0; bi.tail_slab = nullptr; bi.tail_cnt = nullptr; bi.tail_n = 0; bi.tail_s = 0; bi.tail_first = 0;
   if constexpr (CFG::TAILSPLIT != 0 && !std::is_same<EP, EpWgrad>::value) {
     static const int n_cu = [] { int d = 0, v = 0; hipGetDevice(&d); hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v; }();
-    // workgroups of THIS instantiation a CU holds at once (registers / LDS)
-    static const int resident = [] {
-      int c = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, reinterpret_cast<const void*>(&igemm_kernel<CFG, AL, BL, EP>), 256, 0) != hipSuccess) c = 0;
+    // workgroups of THIS instantiation a CU holds at once (registers / LDS); asked for by the general form only
+    auto resident_wgs = [] {
+      static const int c = [] {
+        int v = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, reinterpret_cast<const void*>(&igemm_kernel<CFG, AL, BL, EP>), 256, 0) != hipSuccess) v = 0;
+        return v;
+      }();
       return c;
-    }();
+    };
     const int mode = sg_opt(SG_OPT_W43_TAIL_SPLIT);     // 0: off, 1: the F(4x4,3x3) half-round case only, 2: + the general form
     constexpr size_t PIECE_BYTES = (size_t)4 * CFG::TM * CFG::TN * 16 * 64 * sizeof(float);
     const bool plain = grid.z == 1 && splits <= 1 && bi.kcnt == nullptr && bi.ksplit == 0 && bi.par.ncls == 0 && !bi.xcd_z;
@@ -1687,8 +1690,8 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
       float* slab = sg_tail_scratch(s, (size_t)nsplit * 2 * PIECE_BYTES);
       int* cnt = slab ? sg_counter_alloc(s, nsplit, true) : nullptr;
       if (slab && cnt) { bi.tail_sx = sx; bi.tail_slab = slab; bi.tail_cnt = cnt; grid.x = tiles + nsplit; }
-    } else if (mode >= 2 && n_cu > 0 && resident > 0 && plain && bi.cols_per_batch == 0 && CFG::KFOLD == 0 &&
-               !std::is_same<EP, EpWgrad>::value) {
+    } else if (mode >= 2 && n_cu > 0 && plain && bi.cols_per_batch == 0 && CFG::KFOLD == 0 && resident_wgs() > 0) {
+      const int resident = resident_wgs();
       const int smax = sg_opt(SG_OPT_TAIL_SMAX) < 2 ? 2 : (sg_opt(SG_OPT_TAIL_SMAX) > 8 ? 8 : sg_opt(SG_OPT_TAIL_SMAX));
       const int kt = sg_cdiv(K, CFG::BKT), slots = n_cu * resident;
       int n = 0, sp = 0, first = 0;
