@@ -513,6 +513,7 @@ struct FixedTaps { int lg; unsigned tapcode; };      // lg < 4: tap ids of the c
 template <int BN, int MODE>
 struct LoadFixedKN {
   Gather g; int Npix; int KS; int lg; unsigned tapcode;
+  int dedup;                            // host_prepare(): 1 = compute the distinct tap offsets of a parity class once (init())
   FastDiv dphw, dpw;                    // n -> (image, pixel row): set by host_prepare() / set_class_b() (no division in init())
   static constexpr int LDS_INTS = 0;
   static constexpr int ROWS = BN * BK / 256;
@@ -539,14 +540,27 @@ struct LoadFixedKN {
     shw4_ = shw * 4u;
     const unsigned img1 = (unsigned)img * (unsigned)g.C1 * shw;
     const int nt = 1 << lg;
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-      const int ti = (kr_ + i) & (nt - 1);
+    auto tap_voff = [&](int ti) -> unsigned {
       const int t = lg == 4 ? ti : (int)((tapcode >> (4 * ti)) & 15u);
-      // t < KS*KS <= 16: the tap row without an integer division (~25 VALU each, ROWS of them per thread)
+      // t < KS*KS <= 16: the tap row without an integer division (~25 VALU per tap)
       const int kh = KS == 4 ? (t >> 2) : (KS == 3 ? ((t * 11) >> 5) : (KS == 1 ? 0 : t / KS)), kw = t - kh * KS;
       const int v = okn ? tap_offset<MODE>(g, ah, aw, kh, kw) : -1;
-      voff_[i] = v < 0 ? 0x80000000u : (img1 + (unsigned)v) * 4u;
+      return v < 0 ? 0x80000000u : (img1 + (unsigned)v) * 4u;
+    };
+    if (lg <= 2 && dedup) {
+      // parity classes (1, 2 or 4 taps): the ROWS = 4 / 8 rows of a thread repeat the class's nt taps -- kr_ is a multiple of ROWS and
+      // nt divides ROWS, so row i reads tap i & (nt - 1).  Compute nt offsets instead of ROWS (wave-uniform branch): a new wave's
+      // vector instructions each wait behind the other waves' 64-cycle MFMAs, and the 1- and 2-tap classes of a stride-2 3x3
+      // transposed gather spent 22 k cycles in this function against a 31-60 k cycle main loop (profiles/r06_timeline_*.txt)
+      unsigned o[4];
+      o[0] = tap_voff(0);
+      o[1] = nt > 1 ? tap_voff(1) : o[0];
+      if (nt > 2) { o[2] = tap_voff(2); o[3] = tap_voff(3); } else { o[2] = o[0]; o[3] = o[1]; }
+#pragma unroll
+      for (int i = 0; i < ROWS; ++i) voff_[i] = o[i & 3];
+    } else {
+#pragma unroll
+      for (int i = 0; i < ROWS; ++i) voff_[i] = tap_voff((kr_ + i) & (nt - 1));
     }
   }
   __device__ __forceinline__ void prefetch(Stage&, int) const {}
@@ -1149,6 +1163,7 @@ template <int BN, int KS, bool TWO, bool MASK, int NS> inline void host_prepare(
   l.dpw = FastDiv((unsigned)(l.g.PW > 0 ? l.g.PW : 1));
 }
 template <int BN, int MODE> inline void host_prepare(LoadFixedKN<BN, MODE>& l) {
+  l.dedup = sg_opt(SG_OPT_FIXEDTAP) != 2 ? 1 : 0;
   const int phw = l.g.PH * l.g.PW;
   l.dphw = FastDiv((unsigned)(phw > 0 ? phw : 1));
   l.dpw = FastDiv((unsigned)(l.g.PW > 0 ? l.g.PW : 1));
