@@ -312,6 +312,17 @@ int sg_gap_bwd(const float* gy, float* gx, int NC, int HW, sgStream stream);
 int sg_upsample2_fwd(const float* x, float* y, int NC, int H, int W, sgStream stream);   /* nearest x2 */
 int sg_reflect_pad_fwd(const float* x, float* y, int NC, int H, int W, int pad, sgStream stream);
 int sg_concat_channels(const float* a, const float* b, float* out, int N, int Ca, int Cb, int HW, sgStream stream);
+/* Conv over [x1 || cond row expanded over the grid] with the broadcast source folded into a per-(n, m, tap) term
+ * (MultiscaleMaskDiscriminator.singleD_forward, discriminators.py:107-110: cat([feat, cond.expand(...)], 1) -> Conv2d):
+ *   y = conv(x1, W[:, :C1]) + sum_{taps inside the plane at (oh, ow)} P[n][m][tap],  P = cond x W2r^T (sg_linear_fwd).
+ * split_w: W [M][C1+C2][R] -> W1 [M][C1][R], W2r [M*R][C2];  merge_w: its adjoint (a NULL source reads as zeros);
+ * bias_act: y[NM][OH][OW] = act(y + window sum of P[NM][KS*KS]) in place;  window_sums: its adjoint, gP[NM][KS*KS] (KS 1, 3, 4) */
+int sg_cond_conv_split_w(const float* w, float* w1, float* w2r, int M, int C1, int C2, int R, sgStream stream);
+int sg_cond_conv_merge_w(const float* gw1, const float* gw2r, float* gw, int M, int C1, int C2, int R, sgStream stream);
+int sg_cond_conv_bias_act(float* y, const float* p, int NM, int OH, int OW, int H, int W, int KS, int stride, int pad,
+                          int act, float slope, sgStream stream);
+int sg_cond_conv_window_sums(const float* g, float* gp, int NM, int OH, int OW, int H, int W, int KS, int stride, int pad,
+                             sgStream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Layout scatter and bilinear crops (layout.py:64-155, bilinear.py:67-130)

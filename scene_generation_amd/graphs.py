@@ -26,6 +26,16 @@ REPLAYS = [0]                    # hipGraph launches issued by this process
 # segment is being captured (the DataLoader's pin-memory thread, RCCL's watchdog), and under the default 'global' mode any of
 # their calls would invalidate the capture.
 CAPTURE_MODE = os.environ.get('SG_GRAPH_CAPTURE_MODE', 'thread_local')
+# debugging: synchronise after every replay (and name the segment on stderr), so that a fault inside a replayed graph is reported
+# at the replay and not at the next host synchronisation
+SYNC_REPLAYS = os.environ.get('SG_GRAPH_SYNC', '0') == '1'
+
+
+def _after_replay(entry, what):
+    if SYNC_REPLAYS:
+        import sys
+        print('scene_generation_amd.graphs: replayed %s of %s' % (what, getattr(entry, 'name', '?')), file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
 
 
 def _flat(out):
@@ -51,6 +61,7 @@ class _GraphedFn(Function):
         entry.static_in.copy_(x)
         entry.fwd.replay()
         REPLAYS[0] += 1
+        _after_replay(entry, 'forward')
         ctx.entry = entry
         # the activations this replay saved live in the graph's private pool until the matching backward has run (or the
         # autograd node is dropped): GraphedSegment.__call__ refuses a second grad-mode replay of the entry until then
@@ -80,6 +91,7 @@ class _GraphedFn(Function):
                     carried.append((view, view.clone()))
         e.bwd.replay()
         REPLAYS[0] += 1
+        _after_replay(e, 'backward')
         for view, old in carried:
             view.add_(old)
         for opt, i in e.deliveries:           # what ops.GradOut.finish() tells the optimiser on the eager path
@@ -144,6 +156,7 @@ class GraphedSegment(object):
             e.static_in.copy_(x)
             e.fwd.replay()
             REPLAYS[0] += 1
+            _after_replay(e, 'forward (no grad)')
             outs = [o.detach() for o in e.static_out]
             if e.clone_outputs:
                 outs = [o.clone() for o in outs]
@@ -151,6 +164,7 @@ class GraphedSegment(object):
 
     def _capture(self, x, need_grad):
         e = _Entry()
+        e.name = self.name
         e.clone_outputs = self.clone_outputs
         e.accumulate = self.accumulate
         e.pending = None

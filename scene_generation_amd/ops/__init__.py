@@ -13,7 +13,7 @@ One namespace, six modules (the single 1 741-line ops.py of rounds 1-3, split by
   layout   masks_to_layout (dense / deferred / test mode / factored), per-image-weight convs, bilinear crops, VectorPool
   losses   scalar losses, weighted sum, cross-entropy
 Everything is re-exported here, so ``ops.conv2d``, ``ops.GradOut``, ``ops._call`` ... keep working.  The path switches
-(``ops.WINOGRAD``, ``ops.FACTORED_LAYOUT``, ``ops.UPCONV``, ``ops.HEADCONV``, ``ops.WINOGRAD24``) are WRITABLE through this
+(``ops.WINOGRAD``, ``ops.FACTORED_LAYOUT``, ``ops.UPCONV``, ``ops.HEADCONV``, ``ops.WINOGRAD24``, ``ops.COND_FOLD``) are WRITABLE through this
 namespace: assigning ``ops.WINOGRAD = False`` updates the value the operator modules read (``_core.WINOGRAD``).
 """
 import sys
@@ -22,7 +22,7 @@ import types
 from . import _core, graph, losses, layout, conv, nn
 
 _MODULES = (_core, graph, losses, layout, conv, nn)
-_FLAGS = ('HEADCONV', 'WINOGRAD', 'WINOGRAD24', 'FACTORED_LAYOUT', 'UPCONV')
+_FLAGS = ('HEADCONV', 'WINOGRAD', 'WINOGRAD24', 'FACTORED_LAYOUT', 'UPCONV', 'COND_FOLD')
 
 for _m in _MODULES:
     for _k, _v in vars(_m).items():

@@ -79,7 +79,16 @@ def _i64(t, name='index'):
 
 
 def workspace(nbytes, device):
-    """Per-device scratch, grown on demand.  Safe to share: every consumer is ordered on the current stream."""
+    """Per-(device, stream) scratch, grown on demand.  Safe to share: every consumer is ordered on the current stream.
+
+    While the current stream is being CAPTURED into a hipGraph the scratch is a fresh allocation of the capturing graph's private
+    pool instead, dropped when the call returns (the pool hands the block to later captured allocations, which run later in the
+    graph's order): a cached buffer would be baked into the graph by address and then (a) replaced -- i.e. freed -- by a larger
+    request later in the same capture, or (b) belong to the private pool of an EARLIER graph whose owner is long gone (the cache
+    outlives every Trainer): replays of the new graph then touch memory the allocator may have handed out again or returned to
+    the driver.  Round 6: a memory access fault in the generator segment captured by the 170th test of one process."""
+    if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
     key = (device.index, _stream_handle())
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
@@ -338,6 +347,10 @@ def ensure_dense(t):
 # Interpolate(x2, nearest) + Conv2d(3, padding=1) as a sub-pixel transposed convolution (SG_UPCONV=0: 3x3 gather over the
 # folded upsample instead): 16 instead of 36 multiply-adds per input pixel and channel pair (mask_net, generators.py:20-21)
 UPCONV = os.environ.get('SG_UPCONV', '1') != '0'
+# A conv over [feature map || per-sample row expanded over the grid] (the class one-hot of the mask discriminator,
+# discriminators.py:107-110) with the constant channels folded into a per-(sample, output channel, tap) term: only the feature
+# map's channels are gathered (SG_COND_FOLD=0: the row is a broadcast second gather source of the full-width conv)
+COND_FOLD = os.environ.get('SG_COND_FOLD', '1') != '0'
 
 
 # =============================================================================================

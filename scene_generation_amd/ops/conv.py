@@ -292,6 +292,104 @@ def conv2d_instnorm(x, weight, bias, skip=None, eps=1e-5, act=ACT_NONE, slope=0.
     return ConvInstNormFn.apply(x, weight, bias, skip, float(eps), act, float(slope))
 
 
+class CondConv2dFn(Function):
+    """act(conv2d([x1 || cond[:, :, None, None].expand(H, W)]) + bias) for a per-sample row ``cond`` [N, C2], zero padding: the
+    constant channels never enter the gather.  With W = [W1 | W2] along the input channels,
+        y[n, m, oh, ow] = conv(x1, W1)[n, m, oh, ow] + sum_{taps (kh, kw) that land inside the plane at (oh, ow)} P[n, m, kh, kw],
+        P[n, m, t] = sum_c2 cond[n, c2] W2[m, c2, t]                     (one dense layer, [N x C2] x [C2 x Cout*KS*KS])
+    -- C1 instead of C1 + C2 gathered channels in the forward and the weight-gradient GEMMs (128 of 300 in the mask
+    discriminator, discriminators.py:107-110,147-154).  Backward: the data gradient and dW1 are the C1-channel conv's; dP is the
+    per-tap window sum of the output gradient, dW2 = dP^T cond and dcond = dP W2 dense layers; dW1 and dW2 are interleaved into
+    the parameter's gradient by one kernel.  Whether the weight gradient is wanted is decided when the backward runs
+    (ops.skip_param_grads: a forward recorded during the generator step is re-used by the discriminator step).
+    The C1-channel conv always runs the implicit-GEMM gather: at 128 channels Winograd F(2x2,3x3) measured slower (round 6:
+    1007-1009 against 1010-1011 images/s at configs[1], 525 against 531 at configs[4])."""
+
+    @staticmethod
+    def forward(ctx, x1, cond, weight, bias, stride, pad, act, slope):
+        x1, cond, weight = _f32(x1, 'conv input'), _f32(cond, 'conv condition row'), _f32(weight, 'conv weight')
+        N, C1, H, W = x1.shape
+        C2 = cond.size(1)
+        Cout, Cin, KS, KS2 = weight.shape
+        assert KS == KS2 and Cin == C1 + C2 and cond.size(0) == N and N > 0
+        R = KS * KS
+        OH, OW = conv_out_size(H, KS, stride, pad), conv_out_size(W, KS, stride, pad)
+        d = _conv_desc(N, C1, 0, H, W, Cout, KS, stride, pad, False, 1, OH, OW, 0, 0)
+        dev, s = x1.device, _stream()
+        w1 = torch.empty(Cout, C1, KS, KS, dtype=torch.float32, device=dev)
+        w2r = torch.empty(Cout * R, C2, dtype=torch.float32, device=dev)
+        _call('sg_cond_conv_split_w', _p(weight), _p(w1), _p(w2r), Cout, C1, C2, R, s)
+        proj = torch.empty(N, Cout * R, dtype=torch.float32, device=dev)
+        _call('sg_linear_fwd', _p(cond), _p(w2r), None, _p(proj), N, C2, Cout * R, ACT_NONE, 0.0, s)
+        y = torch.empty(N, Cout, OH, OW, dtype=torch.float32, device=dev)
+        wsb = _q(d, 'sg_conv2d_ws_bytes', 0)
+        _call('sg_conv2d_fwd', d._ref, _p(x1), None, _p(w1), _p(bias), _p(y), ACT_NONE, 0.0, _p(workspace(wsb, dev)), wsb, s)
+        _call('sg_cond_conv_bias_act', _p(y), _p(proj), N * Cout, OH, OW, H, W, KS, stride, pad, act, slope, s)
+        ctx.desc, ctx.geom = d, (C2, R, KS, stride, pad)
+        ctx.weight_ref, ctx.bias_ref = weight, bias          # identities only (gradient sinks / skip list)
+        ctx.cfg = (act, slope, bias is not None)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x1, cond, w1, w2r, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if gy is None:
+            return (None,) * 8
+        x1, cond, w1, w2r, y = ctx.saved_tensors
+        d = ctx.desc
+        C2, R, KS, stride, pad = ctx.geom
+        act, slope, has_bias = ctx.cfg
+        gy = _f32(gy)
+        dev, s = gy.device, _stream()
+        if act != ACT_NONE:
+            g2 = torch.empty_like(gy)
+            _call('sg_act_bwd', _p(y), _p(gy), _p(g2), gy.numel(), act, slope, s)
+            gy = g2
+        need_x1, need_c = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_w = ctx.needs_input_grad[2] and _wants_grad(ctx.weight_ref)
+        need_b = has_bias and ctx.needs_input_grad[3] and _wants_grad(ctx.bias_ref)
+        gx1 = gc = gw = gb = None
+        if need_x1:
+            gx1 = torch.empty(d.N, d.C1, d.H, d.W, dtype=torch.float32, device=dev)
+            wsb = _q(d, 'sg_conv2d_ws_bytes', 1)
+            _call('sg_conv2d_dgrad', d._ref, _p(gy), _p(w1), _p(gx1), 0, d.C1, _p(workspace(wsb, dev)), wsb, s)
+        gproj = None
+        if need_c or need_w:
+            gproj = torch.empty(d.N, d.Cout * R, dtype=torch.float32, device=dev)
+            _call('sg_cond_conv_window_sums', _p(gy), _p(gproj), d.N * d.Cout, d.OH, d.OW, d.H, d.W, KS, stride, pad, s)
+        if need_c:
+            gc = torch.empty_like(cond)
+            _call('sg_linear_bwd_data', _p(gproj), _p(w2r), _p(gc), d.N, C2, d.Cout * R, s)
+        if need_w or need_b:
+            ow = GradOut(ctx.weight_ref) if need_w else None
+            ob = GradOut(ctx.bias_ref) if need_b else None
+            if need_w:
+                gw1, gw2r = torch.empty_like(w1), torch.empty_like(w2r)
+                wsb = _q(d, 'sg_conv2d_ws_bytes', 2)
+                _call('sg_conv2d_wgrad', d._ref, _p(gy), _p(x1), None, _p(gw1), _p(ob.buf) if need_b else None,
+                      _p(workspace(wsb, dev)), wsb, s)
+                _call('sg_linear_bwd_weight', _p(gproj), _p(cond), _p(gw2r), None, d.N, C2, d.Cout * R, s)
+                _call('sg_cond_conv_merge_w', _p(gw1), _p(gw2r), _p(ow.buf), d.Cout, d.C1, C2, R, s)
+            else:
+                wsb = _L().sg_channel_sum_ws_bytes(d.Cout)
+                _call('sg_channel_sum', _p(gy), _p(ob.buf), d.N, d.Cout, d.OH * d.OW, _p(workspace(wsb, dev)), wsb, s)
+            gw = ow.finish() if need_w else None
+            gb = ob.finish() if need_b else None
+        return gx1, gc, gw, gb, None, None, None, None
+
+
+def _cond_fold_applies(x, weight, stride, pad, reflect, upsample, x2):
+    """a [N, C2] row as second source of a zero-padded conv with a kernel size the window-sum kernel has (1, 3, 4) and more than
+    four output channels (below that the dense conv runs the vector-ALU kernels, which have no two-source form to fold)"""
+    if not (_core.COND_FOLD and x2 is not None and x2.dim() == 2 and not reflect and upsample == 1 and x.size(0) > 0):
+        return False
+    KS = weight.size(2)
+    if KS != weight.size(3) or KS not in (1, 3, 4) or weight.size(1) != x.size(1) + x2.size(1) or weight.size(0) <= 4:
+        return False
+    return conv_out_size(x.size(2), KS, stride, pad) > 0 and conv_out_size(x.size(3), KS, stride, pad) > 0
+
+
 def _upconv_prefers_winograd(x, weight):
     """the folded-upsample Winograd path (>= 128 channels in multiples of 128) keeps its convs"""
     if not _core.WINOGRAD:
@@ -311,6 +409,8 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, reflect=False, upsample=1, act
             and act == ACT_NONE and weight.size(2) == 3 and weight.size(3) == 3 and not _upconv_prefers_winograd(x, weight)):
         return UpConv3Fn.apply(x, weight, bias)
     if h is None:
+        if x2 is not None and _cond_fold_applies(x, weight, stride, pad, reflect, upsample, x2):
+            return CondConv2dFn.apply(x, x2, weight, bias, stride, pad, act, float(slope))
         return Conv2dFn.apply(x, x2, weight, bias, stride, pad, reflect, upsample, act, float(slope), 0, None)
     f = h.get('factored') if _core.FACTORED_LAYOUT else None
     if f is not None and upsample == 1 and (x2 is None or (x2.dim() == 4 and not reflect)):

@@ -492,21 +492,48 @@ def test_factored_layout_conv_matches_dense(hip, KS, stride, pad, reflect, C2, H
             close(a, r.cpu(), 1e-4, nme)
 
 
-def test_conv2d_broadcast_second_source(hip):
-    """mask-D: one-hot class map broadcast over the grid == expand()+cat() of discriminators.py:107-110."""
-    N, C1, C2, H = 6, 16, 12, 8
-    x, cond, w, b = det((N, C1, H, H), 21), torch.zeros(N, C2), det((8, C1 + C2, 3, 3), 22, 0.2), det((8,), 23)
-    cond[torch.arange(N), torch.tensor([0, 3, 11, 5, 5, 1])] = 1
-    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
-    yr = F.conv2d(torch.cat([xr, cond.view(N, C2, 1, 1).expand(-1, -1, H, H)], 1), wr, b, padding=1)
+@pytest.mark.parametrize('fold', [True, False])
+@pytest.mark.parametrize('shape', [
+    # N, C1, C2, H, W, Cout, KS, stride, pad, act, one_hot
+    (6, 16, 12, 8, 8, 8, 3, 1, 1, 0, True),              # the round-1 case
+    (7, 128, 172, 8, 8, 256, 3, 1, 1, 0, True),          # the mask discriminator's conditioned conv at its real widths
+    (8, 128, 172, 8, 8, 256, 3, 1, 1, 2, True),          # ... with a multiple of 8 objects (the shape Winograd would take), LeakyReLU
+    (5, 128, 172, 4, 4, 256, 3, 1, 1, 2, True),          # ... at the coarser scale (every pixel is a border pixel), fused LeakyReLU
+    (4, 24, 10, 9, 7, 40, 3, 2, 1, 2, False),            # stride 2, odd plane, a dense condition row with its own gradient
+    (3, 20, 6, 6, 5, 12, 4, 1, 2, 0, False),             # 4x4 kernel, padding 2 (output larger than the input)
+    (3, 8, 5, 5, 5, 16, 1, 1, 0, 1, False),              # 1x1 kernel: the folded term is a per-sample bias
+])
+def test_conv2d_broadcast_second_source(hip, shape, fold):
+    """mask-D: the class row broadcast over the grid == expand()+cat() of discriminators.py:107-110 -- as a second gather source
+    of the full-width conv (fold off) and folded into a per-(sample, channel, tap) term of the C1-channel conv (ops.CondConv2dFn,
+    the default): y, dx, dcond, dW (both channel blocks) and db against torch fp32 on the CPU."""
+    N, C1, C2, H, W, Cout, KS, stride, pad, act, one_hot = shape
+    x, w, b = det((N, C1, H, W), 21), det((Cout, C1 + C2, KS, KS), 22, 0.2), det((Cout,), 23)
+    if one_hot:
+        cond = torch.zeros(N, C2)
+        cond[torch.arange(N), torch.tensor([0, 3, 11, 5, 5, 1, 9, 2][:N]) % C2] = 1
+    else:
+        cond = det((N, C2), 25)
+    xr, wr, br, cr = (t.clone().requires_grad_() for t in (x, w, b, cond))
+    yr = F.conv2d(torch.cat([xr, cr.view(N, C2, 1, 1).expand(-1, -1, H, W)], 1), wr, br, stride=stride, padding=pad)
+    yr = {0: yr, 1: F.relu(yr), 2: F.leaky_relu(yr, 0.2)}[act]
     gy = det(tuple(yr.shape), 24)
     yr.backward(gy)
-    xg, wg = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
-    yg = hip.conv2d(xg, wg, b.to(DEV), pad=1, x2=cond.to(DEV))
-    yg.backward(gy.to(DEV))
+    saved = hip.COND_FOLD
+    hip.COND_FOLD = fold
+    try:
+        xg, wg, bg, cg = (t.to(DEV).requires_grad_() for t in (x, w, b, cond))
+        yg = hip.conv2d(xg, wg, bg, stride=stride, pad=pad, act=act, slope=0.2, x2=cg)
+        assert (type(yg.grad_fn).__name__ == 'CondConv2dFnBackward') == fold
+        yg.backward(gy.to(DEV))
+    finally:
+        hip.COND_FOLD = saved
     close(yg, yr, 3e-5)
-    close(xg.grad, xr.grad, 5e-5)
-    close(wg.grad, wr.grad, 5e-5)
+    close(xg.grad, xr.grad, 5e-5, 'gx')
+    close(wg.grad[:, :C1], wr.grad[:, :C1], 5e-5, 'gw1')
+    close(wg.grad[:, C1:], wr.grad[:, C1:], 5e-5, 'gw2')
+    close(bg.grad, br.grad, 5e-5, 'gb')
+    close(cg.grad, cr.grad, 5e-5, 'gcond')
 
 
 def test_upconv_subpixel_form_equals_folded_upsample_gather(hip):
@@ -1221,7 +1248,7 @@ def _seg_norms(v, hg):
 _GRAD_LOG = {}
 
 
-def _compare_grads(snaps, tag, rel_tol=3e-2, cos_tol=0.9995, small_floor=1e-3):
+def _compare_grads(snaps, tag, rel_tol=3e-2, cos_tol=0.9995, small_floor=1e-3, collect=None):
     """HIP gradients of a whole step vs the fp32 oracle's.
 
     Single operators agree to ~1e-5 (tests above).  Through the 40-layer generator the forward activations differ
@@ -1250,6 +1277,8 @@ def _compare_grads(snaps, tag, rel_tol=3e-2, cos_tol=0.9995, small_floor=1e-3):
                 rel = float(dn[i] / bn[i])
                 key = '%s/%s' % (tag, n)
                 _GRAD_LOG[key] = max(_GRAD_LOG.get(key, 0.0), rel)
+                if collect is not None:
+                    collect.setdefault((n, i), []).append(rel)
                 assert rel <= rel_tol, '%s %s param %d: relative L2 gradient error %.3e' % (tag, n, i, rel)
 
 
@@ -1305,27 +1334,45 @@ def test_full_step_vs_oracle(hip, cfg):
         torch.set_num_threads(threads0)
 
 
+_REDUCED_SEEDS = (0, 100, 300)
+
+
 def _full_step_iterations(cfg, args, bk, ref, tr, snaps):
-    for it in range(2):
-        batch = make_batch(seed=it, **bk)
-        noise = det((1, args.mask_noise_dim), 121 + it)
-        ref.model.noise_override = tr.model.noise_override = noise
-        random.seed(5 + it)
-        out_ref = ref.step(batch, use_gt=(it == 0))
-        random.seed(5 + it)
-        out = tr.step(batch_to(batch, DEV), use_gt=(it == 0))
-        _compare_outputs(tr, ref, out, out_ref, 2e-4)
-        # 'reduced' (every kernel family at small widths: few units sit within fp32 noise of a ReLU kink) is compared TIGHTLY, tensor
-        # by tensor, down to tensors of 1e-5 of the flat gradient's norm.  Typical worst relative L2: 8.4e-6 (generator), 2-5e-6
-        # (discriminators), gpurun_out/grad_rel_l2_reduced.json; the multi-threaded CPU oracle is not bit-reproducible from run to
-        # run, and about one run in three a unit does flip: 8e-4 on one small tensor, flat cosine 0.999999 (12 repeats, round 6).
-        # Bounds: 5e-3 per tensor, cosine 0.99999 -- a 1 % systematic error in any of those tensors fails here (VERDICT r5 weak 2:
-        # the full-width bounds below, 3e-2, cannot see one)
-        if cfg == 'reduced':
-            _compare_grads(snaps, '%s_it%d' % (cfg, it), rel_tol=5e-3, cos_tol=0.99999, small_floor=1e-5)
-        else:
-            _compare_grads(snaps, '%s_it%d' % (cfg, it))
-        _sync_state(ref, tr)
+    # 'reduced' (every kernel family at small widths) is the configuration where a SYSTEMATIC error in one small parameter tensor can
+    # be told from fp32 noise: most tensors agree with the oracle to 1e-6..3e-5.  Not all of them in every step, though: a scan
+    # over six data seeds (round 6, tools/probe/r06_call39.sh) found a generator tensor at 4e-4 .. 1.5e-2 in seven of twelve
+    # iterations (discriminators: always <= 1e-5) -- a unit of the generator within fp32 noise of a kink takes the other branch --
+    # and WHICH iteration depends on every summation order of the step and on the CPU oracle's thread count (single-threaded here:
+    # bit-reproducible).  So the tight bound -- 2e-4: the worst tensor's best sample measured 2.7e-5, a 1 % error is 50 bounds away --
+    # is asked of every tensor in AT LEAST ONE of six independent samples (three data seeds x two iterations: a systematic error
+    # shows in all of them, a flipped unit in its own), the full-width bound 3e-2 in all of them (the 3e-2
+    # bound alone cannot see a 1 % error in a small tensor).
+    seeds = _REDUCED_SEEDS if cfg == 'reduced' else (0,)
+    if cfg == 'reduced' and os.environ.get('SG_TEST_REDUCED_SEED'):
+        seeds = tuple(int(v) for v in os.environ['SG_TEST_REDUCED_SEED'].split(','))
+    collect = {}
+    for seed0 in seeds:
+        for it in range(2):
+            batch = make_batch(seed=seed0 + it, **bk)
+            noise = det((1, args.mask_noise_dim), 121 + it)
+            ref.model.noise_override = tr.model.noise_override = noise
+            random.seed(5 + it)
+            out_ref = ref.step(batch, use_gt=(it == 0))
+            random.seed(5 + it)
+            out = tr.step(batch_to(batch, DEV), use_gt=(it == 0))
+            _compare_outputs(tr, ref, out, out_ref, 2e-4)
+            if cfg == 'reduced':
+                _compare_grads(snaps, '%s_s%d_it%d' % (cfg, seed0, it), cos_tol=0.9999, small_floor=1e-5, collect=collect)
+            else:
+                _compare_grads(snaps, '%s_it%d' % (cfg, it))
+            _sync_state(ref, tr)
+    if cfg == 'reduced':
+        tight = float(os.environ.get('SG_TEST_REDUCED_TOL', '2e-4'))
+        best = {k: min(v) for k, v in collect.items()}
+        worst_best = max(best.values())
+        _GRAD_LOG['reduced/best_of_samples'] = worst_best
+        bad = {k: v for k, v in best.items() if v > tight}
+        assert not bad, 'tensors off by more than %.0e in EVERY sample (optimiser, parameter index: smallest relative L2): %r' % (tight, bad)
     _dump('grad_rel_l2_%s.json' % cfg, {k: v for k, v in _GRAD_LOG.items() if k.startswith(cfg)})
 
 
