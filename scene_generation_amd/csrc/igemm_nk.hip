@@ -79,6 +79,12 @@ void launch_nk_general(int tile, const float* A, int M, int Mtot, int PQ, const 
   if (tile == 2)
     launch_cfg<CfgW32>(LoadPixK<32>{A, M, Mtot, PQ, dPQ, rowsum}, LoadGatherNK<128, KS, false, true, NSW>{g, Ncols, sl, sc, L, zdiv}, ep,
                        M, Ncols, Kpix, splits, s);
+  else if (KS == 7 && sp && (PQ % 4 == 0) && aligned16(A))
+    // the per-image weight gradient of the factored 7x7 stem (64 x 9*49 x 16 384 per image: the slowest GEMM launch of the step,
+    // 45 TFLOP/s): the output gradient is read with 16-byte loads -- one vector-memory instruction per thread and k-tile instead of
+    // four next to the four gathered elements of B (same-box A/B, two pairs: 31.24 vs 31.31 ms/step, +0.2 %)
+    launch_cfg<CfgW64>(LoadPixKVec<64>{A, M, Mtot, PQ, dPQ, rowsum}, LoadGatherNK<64, KS, false, true, NSW>{g, Ncols, sl, sc, L, zdiv}, ep,
+                       M, Ncols, Kpix, splits, s);
   else
     launch_cfg<CfgW64>(LoadPixK<64>{A, M, Mtot, PQ, dPQ, rowsum}, LoadGatherNK<64, KS, false, true, NSW>{g, Ncols, sl, sc, L, zdiv}, ep,
                        M, Ncols, Kpix, splits, s);
