@@ -79,6 +79,8 @@ enum SgOpt {
   SG_OPT_TAIL_SMAX,       // tail split, general form: at most this many pieces per tile (2..8)
   SG_OPT_TAIL_KTMIN,      // ... and no piece shorter than this many k-tiles
   SG_OPT_W43_WGRAD_TILE,  // tile of the F(4x4,3x3) weight-gradient GEMMs (K = the 128 Winograd tiles): 0 = 64x64 (9216 workgroups), 1 = 128x128, 2 = 64x128
+  SG_OPT_PAR_SPLIT,       // parity-class launches (3x3 stride-2 transposed gathers: classes of 4 / 2 / 2 / 1 taps): the tiles of the 4-tap class run as two half-k workgroups that meet through the tail-split ticket (0: off)
+  SG_OPT_TAIL_CAPTURE,    // tail-split / parity-split schedules inside a hipGraph capture (shared per-device scratch, runtime.hip): 1 on, 0 = captured launches run the unsplit form (rounds 1-5 behaviour)
   SG_OPT_COUNT
 };
 extern std::atomic<int> g_sg_opt[SG_OPT_COUNT];

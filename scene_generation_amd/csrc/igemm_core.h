@@ -1098,6 +1098,9 @@ struct ParityClasses {
   const void* ktab[4];
   int lg[4]; unsigned tapcode[4];        // LoadFixedKN: taps per channel (log2) and tap ids of each class
   unsigned dphw_m[4], dphw_s[4], dpw_m[4], dpw_s[4];      // FastDiv(PH * PW), FastDiv(PW) of each class (launch_cfg fills them)
+  // split[c] > 1 (launch_cfg): the tiles of class c run as split[c] workgroups of 1 / split[c] of its k range each (tile0 then
+  // counts WORKGROUPS, the pieces of a tile adjacent); slot0[c]: first ticket slot of the class within a tile row, nslots: per row
+  int split[4], slot0[4], nslots;
 };
 struct BatchInfo {
   int cols_per_batch; int nbatch; const int* kcnt; int a_stride; int b_stride;
@@ -1274,7 +1277,19 @@ __global__ void __launch_bounds__(256) igemm_kernel(AL al, BL bl, EP ep, int M, 
     int c = 0;
 #pragma unroll
     for (int q = 1; q < 4; ++q) c += (q < bi.par.ncls && tn >= bi.par.tile0[q]) ? 1 : 0;
-    n0 = (tn - bi.par.tile0[c]) * BN;
+    int tq = tn - bi.par.tile0[c];
+    if (TSPLIT && bi.par.split[c] > 1) {
+      // The 4-tap class of a 3x3 stride-2 transposed gather runs 4x the k range of the 1-tap class.  With every workgroup of the
+      // launch resident at once (few tiles: the generator's 8x8 -> 16x16 up-conv and its mirror) the launch ends with the 4-tap
+      // workgroups ALONE on their CUs -- one wave per SIMD drives the matrix pipe at 48 % (timeline probe).  Its tiles therefore run
+      // as two half-k workgroups that meet through the tail-split ticket below: the longest workgroup is 2 units instead of 4.
+      const int sc = bi.par.split[c];
+      ts_half = tq % sc;
+      tq /= sc;
+      ts_s = sc;
+      ts_slot = (bid / tn_all) * bi.par.nslots + bi.par.slot0[c] + tq;
+    }
+    n0 = tq * BN;
     K = bi.par.K[c];
     set_class_a(al, bi.par.aoff[c], K);
     set_class_b(bl, bi.par, c);
@@ -1681,6 +1696,8 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
   const bool image_z = t_grid_z > 0 && bi.ksplit > 0 && t_xcd_z == 2;
   bi.xcd_z = (t_xcd_z && (plain_z || image_z) && bi.cols_per_batch == 0 && bi.par.ncls == 0 && grid.z >= 8 && grid.z % 8 == 0) ? 1 : 0;
   bi.tail_sx = 0; bi.tail_slab = nullptr; bi.tail_cnt = nullptr; bi.tail_n = 0; bi.tail_s = 0; bi.tail_first = 0;
+  for (int c = 0; c < 4; ++c) { bi.par.split[c] = 1; bi.par.slot0[c] = 0; }
+  bi.par.nslots = 0;
   if constexpr (CFG::TAILSPLIT != 0 && !std::is_same<EP, EpWgrad>::value) {
     static const int n_cu = [] { int d = 0, v = 0; hipGetDevice(&d); hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d); return v; }();
     // workgroups of THIS instantiation a CU holds at once (registers / LDS); asked for by the general form only
@@ -1705,6 +1722,39 @@ int launch_cfg(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, in
       float* slab = sg_tail_scratch(s, (size_t)nsplit * 2 * PIECE_BYTES);
       int* cnt = slab ? sg_counter_alloc(s, nsplit, true) : nullptr;
       if (slab && cnt) { bi.tail_sx = sx; bi.tail_slab = slab; bi.tail_cnt = cnt; grid.x = tiles + nsplit; }
+    } else if (sg_opt(SG_OPT_PAR_SPLIT) && n_cu > 0 && bi.par.ncls > 1 && grid.z == 1 && splits <= 1 && CFG::KFOLD == 0 && !bi.xcd_z &&
+               M % CFG::BM == 0 && (CFG::BM * CFG::BN <= 64 * 64 || sg_opt(SG_OPT_PAR_SPLIT) >= 2)) {
+      // (64x64 tiles only: on 128x128 tiles -- two resident workgroups per CU, 2.5 rounds -- the same split measured +10 %:
+      //  187 -> 206 us, profiles/r06_gemm_par_split.md)
+      // parity classes: split the heaviest class in two when it runs >= 4x the k range of the lightest and the launch is small
+      // enough for its tail to matter (at most ~2 rounds of resident workgroups)
+      int kmax = 0, kmin = 1 << 30;
+      for (int c = 0; c < bi.par.ncls; ++c) { kmax = bi.par.K[c] > kmax ? bi.par.K[c] : kmax; kmin = bi.par.K[c] < kmin ? bi.par.K[c] : kmin; }
+      const int rows = sg_cdiv(M, CFG::BM);
+      int nsl = 0, old0[5];
+      for (int c = 0; c <= bi.par.ncls; ++c) old0[c] = bi.par.tile0[c];
+      bool any = false;
+      for (int c = 0; c < bi.par.ncls; ++c) {
+        const int tc = old0[c + 1] - old0[c];
+        const bool sp2 = bi.par.K[c] == kmax && kmax >= 4 * kmin && (kmax / 2) % CFG::BKT == 0 && kmax / 2 >= sg_opt(SG_OPT_TAIL_KTMIN) * CFG::BKT;
+        bi.par.split[c] = sp2 ? 2 : 1;
+        bi.par.slot0[c] = nsl;
+        if (sp2) { nsl += tc; any = true; }
+      }
+      const long wgs = (long)rows * (old0[bi.par.ncls] + nsl);
+      if (any && wgs <= 2L * n_cu * 8 && (long)rows * nsl <= 4096) {
+        float* slab = sg_tail_scratch(s, (size_t)rows * nsl * 2 * PIECE_BYTES);
+        int* cnt = slab ? sg_counter_alloc(s, rows * nsl, true) : nullptr;
+        if (slab && cnt) {
+          bi.par.nslots = nsl;
+          bi.par.tile0[0] = 0;
+          for (int c = 0; c < bi.par.ncls; ++c) bi.par.tile0[c + 1] = bi.par.tile0[c] + (old0[c + 1] - old0[c]) * bi.par.split[c];
+          for (int c = bi.par.ncls + 1; c < 5; ++c) bi.par.tile0[c] = bi.par.tile0[bi.par.ncls];
+          bi.tail_slab = slab; bi.tail_cnt = cnt;
+          grid.x = rows * bi.par.tile0[bi.par.ncls];
+        } else any = false;
+      } else any = false;
+      if (!any) for (int c = 0; c < 4; ++c) { bi.par.split[c] = 1; bi.par.slot0[c] = 0; }
     } else if (mode >= 2 && n_cu > 0 && plain && bi.cols_per_batch == 0 && CFG::KFOLD == 0 && resident_wgs() > 0) {
       const int resident = resident_wgs();
       const int smax = sg_opt(SG_OPT_TAIL_SMAX) < 2 ? 2 : (sg_opt(SG_OPT_TAIL_SMAX) > 8 ? 8 : sg_opt(SG_OPT_TAIL_SMAX));

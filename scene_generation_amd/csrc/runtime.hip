@@ -31,7 +31,7 @@ const OptDef kOpts[SG_OPT_COUNT] = {
     {"w24_small", 1}, {"w24_s", -1}, {"w24_pmin", 256}, {"wino_adjoint", 1}, {"wino24", 1}, {"linear_nsub", 2},
     {"linear_skinny", 2048}, {"wgrad_rowsum", 1}, {"layout_reg", 1}, {"layout_dsplit", 1}, {"bn_blocks", 4096},
     {"instnorm_reg", 2}, {"wgrad_xcd", 1}, {"wino_reuse", 1}, {"wino_fold_cells", 1}, {"wino_pipe", 2},
-    {"check_indices", 0}, {"last_block", 0}, {"wino_gemm_tile", 0}, {"wino43", 1}, {"gconv_fused_gather", 1}, {"w24_gemm_tile", 2}, {"wino_in_fuse", 1}, {"w43_nsub", 1}, {"w43_kfold", 256}, {"wave_prio", 0}, {"par_xcd_chunk", 16}, {"w43_tail_split", 1}, {"tail_smax", 4}, {"tail_ktmin", 8}, {"w43_wgrad_tile", 0}};
+    {"check_indices", 0}, {"last_block", 0}, {"wino_gemm_tile", 0}, {"wino43", 1}, {"gconv_fused_gather", 1}, {"w24_gemm_tile", 2}, {"wino_in_fuse", 1}, {"w43_nsub", 1}, {"w43_kfold", 256}, {"wave_prio", 0}, {"par_xcd_chunk", 16}, {"w43_tail_split", 1}, {"tail_smax", 4}, {"tail_ktmin", 8}, {"w43_wgrad_tile", 0}, {"par_split", 1}, {"tail_capture", 1}};
 // runs when the shared library is loaded, before any entry point can be called: the ONLY place the environment is read
 struct OptInit {
   OptInit() {
@@ -116,24 +116,42 @@ struct TailScratch { int dev; hipStream_t s; float* p; size_t bytes; };
 std::vector<TailScratch> g_tail;
 }  // namespace
 
+// Launches that are being CAPTURED into a hipGraph cannot allocate, and the stream they are captured on is not the stream the
+// graph will be replayed on: they share one buffer per device (g_tail_cap), grown whenever an EAGER launch on any stream asks for
+// more than it holds -- the warm-up iterations that precede every capture (graphs.py) run the same shapes eagerly, so the buffer is
+// large enough by the time the capture asks.  Replays of captured graphs are ordered with each other on the replaying stream
+// (graphs.py replays every segment on the current stream); eager launches use their own stream's buffer.  Until round 6 a capture
+// got nullptr here, i.e. every tail-split schedule was silently OFF inside the graphed generator segments -- the headline pass
+// never ran it (the event-profiled pass, which runs eagerly, did: 0.15-0.3 ms per step).
+namespace {
+struct TailCap { float* p; size_t bytes; };
+TailCap g_tail_cap[CNT_DEVICES] = {};
+void tail_cap_reserve(int dev, size_t bytes) {          // g_cnt_mu held; outside captures only
+  if (dev < 0 || dev >= CNT_DEVICES || g_tail_cap[dev].bytes >= bytes) return;
+  float* q = nullptr;
+  if (hipMalloc((void**)&q, bytes) != hipSuccess) return;
+  g_tail_cap[dev].p = q; g_tail_cap[dev].bytes = bytes;   // (the old buffer may be baked into a captured graph: kept)
+}
+}  // namespace
+
 float* sg_tail_scratch(hipStream_t s, size_t bytes) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
   std::lock_guard<std::mutex> lk(g_cnt_mu);
+  if (capturing)
+    return (sg_opt(SG_OPT_TAIL_CAPTURE) && dev >= 0 && dev < CNT_DEVICES && g_tail_cap[dev].bytes >= bytes) ? g_tail_cap[dev].p : nullptr;
+  tail_cap_reserve(dev, bytes);
   for (auto& t : g_tail)
     if (t.dev == dev && t.s == s) {
       if (t.bytes >= bytes) return t.p;
-      // a larger request: the old buffer may be baked into a captured graph or still be read by a launch in flight -- it is kept
-      // (a few MB), a new one takes its place
-      if (capturing) return nullptr;
+      // a larger request: the old buffer may still be read by a launch in flight -- it is kept (a few MB), a new one takes its place
       float* q = nullptr;
       if (hipMalloc((void**)&q, bytes) != hipSuccess) return nullptr;
       t.p = q; t.bytes = bytes;
       return q;
     }
-  if (capturing) return nullptr;
   float* q = nullptr;
   if (hipMalloc((void**)&q, bytes) != hipSuccess) return nullptr;
   g_tail.push_back(TailScratch{dev, s, q, bytes});

@@ -18,6 +18,9 @@ def pytest_collection_modifyitems(config, items):
     """-m gpu tests must never silently pass without a device: skip them on CPU-only hosts only when
     the user did not ask for them explicitly."""
     import torch
+    # the multi-process cases (N ranks sharing the box's one GPU over gloo: the stress configuration of the suite) run LAST, so
+    # that under ``-x`` a failure there cannot leave the parity cases unexecuted
+    items.sort(key=lambda it: 1 if 'test_gpu_distributed' in it.nodeid else 0)
     if torch.cuda.is_available():
         return
     mexpr = config.getoption('-m') or ''

@@ -347,6 +347,49 @@ def test_tail_split_general_form_vs_plain_schedule(hip, shape):
         close(a, c, 2e-6, 'tail split ' + name)
 
 
+@pytest.mark.parametrize('kind,N,Cin,Cout,H', [('up', 32, 512, 256, 8), ('up', 32, 256, 128, 16), ('down', 32, 256, 512, 16), ('up', 2, 512, 256, 8)])
+def test_parity_class_split_vs_plain_schedule(hip, kind, N, Cin, Cout, H):
+    """Option par_split (default on): 3x3 stride-2 transposed gathers -- the forward of the generator's up path (generators.py:84-87)
+    and the data gradient of its stride-2 encoder convs (generators.py:73-76) -- run as four parity classes of 4 / 2 / 2 / 1 taps;
+    with few tiles the 4-tap class's tiles run as two half-k workgroups that meet through the tail-split ticket (igemm_core.h,
+    ParityClasses::split).  At the step's shapes (and at the two-image shapes of the multi-rank bench case): against torch fp32, against
+    the unsplit schedule to fp32 summation order, and five repeats bit-identical (the sum of the two halves does not depend on who
+    arrives last)."""
+    from scene_generation_amd import _hip
+    saved = _hip.get_option('par_split')
+    if kind == 'up':
+        x, w, b = det((N, Cin, H, H), 341), det((Cin, Cout, 3, 3), 342, 0.05), det((Cout,), 343, 0.2)
+        ref = lambda xr, wr, br: F.conv_transpose2d(xr, wr, br, stride=2, padding=1, output_padding=1)
+        run = lambda xg, wg, bg: hip.conv_transpose2d(xg, wg, bg, stride=2, pad=1, out_pad=1)
+    else:
+        x, w, b = det((N, Cin, H, H), 344), det((Cout, Cin, 3, 3), 345, 0.05), det((Cout,), 346, 0.2)
+        ref = lambda xr, wr, br: F.conv2d(xr, wr, br, stride=2, padding=1)
+        run = lambda xg, wg, bg: hip.conv2d(xg, wg, bg, stride=2, pad=1)
+    xr, wr, br = [t.clone().requires_grad_() for t in (x, w, b)]
+    yr = ref(xr, wr, br)
+    gy = det(tuple(yr.shape), 347)
+    yr.backward(gy)
+    out = {}
+    try:
+        for mode in (1, 0):
+            _hip.set_option('par_split', mode)
+            reps = []
+            for _ in range(5 if mode == 1 else 1):
+                xg, wg, bg = [t.to(DEV).requires_grad_() for t in (x, w, b)]
+                yg = run(xg, wg, bg)
+                yg.backward(gy.to(DEV))
+                reps.append((yg.detach().clone(), xg.grad.clone(), wg.grad.clone()))
+            for r in reps[1:]:
+                assert all(torch.equal(a, c) for a, c in zip(r, reps[0]))
+            out[mode] = reps[0]
+            for a, c, name in zip(reps[0], (yr, xr.grad, wr.grad), ('y', 'gx', 'gw')):
+                close(a, c, 5e-5, 'par_split=%d %s' % (mode, name))
+    finally:
+        _hip.set_option('par_split', saved)
+    for a, c, name in zip(out[1], out[0], ('y', 'gx', 'gw')):
+        close(a, c, 2e-6, 'parity split ' + name)
+
+
 @pytest.mark.parametrize('N,C,H,Cout,act,with_skip', [(16, 128, 8, 128, 1, True), (8, 128, 16, 256, 2, False), (32, 256, 8, 128, 0, True)])
 def test_conv_instnorm_fused_vs_fp64_and_unfused(hip, N, C, H, Cout, act, with_skip):
     """ReflectionPad(1) + Conv3x3 + InstanceNorm (+ ReLU / LeakyReLU) (+ residual) of a ResnetBlock (layers.py:251-270) as the fused
