@@ -3,15 +3,20 @@
 All parameters of one optimiser live in ONE contiguous fp32 buffer (parameters become views into it), and so do
 their gradients and both Adam moments.  Consequences:
   * optimizer.step()      = one HIP launch over 28 B/param of HBM traffic (sg_adam_step)
-  * optimizer.zero_grad() = one fill launch
+  * optimizer.zero_grad() = one fill launch -- or none (``lazy_zero``: the first contribution of a step overwrites its slice)
   * data-parallel reduce  = a handful of large RCCL all-reduces over slices of the flat gradient buffer
     (scene_generation_amd.parallel) instead of one small collective per tensor.
 ``state_dict()`` / ``load_state_dict()`` speak torch.optim.Adam's schema (trainer.py:138,186), so reference
 checkpoints round-trip.
 """
+import os
+
 import torch
 
 from . import ops, streams
+
+# what the Trainer passes as FusedAdam(lazy_zero=...): SG_LAZY_ZERO=0 restores the fill launch of every zero_grad() (A/B switch)
+LAZY_ZERO = os.environ.get('SG_LAZY_ZERO', '1') == '1'
 
 
 class FlatParams:
@@ -61,8 +66,17 @@ class FusedAdam:
     (trainer.py:210-216).  "Received a gradient" is tracked with post-accumulate-grad hooks; step() launches the fused
     kernel once per maximal run of adjacent active parameters that share a step count (normally one launch)."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, direct_grads=True):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, direct_grads=True, lazy_zero=False):
         self.fp = FlatParams(params)
+        # lazy_zero (device buffers with gradient sinks only; the Trainer's four optimisers): zero_grad() does NOT fill the flat
+        # gradient buffer (730 MB for the generator: 0.13 ms of HBM time per step).  Every backward kernel OVERWRITES the slice of
+        # a parameter's first contribution (ops.GradOut mode 0) and Adam skips untouched parameters, so the fill only ever
+        # mattered for parameters that receive nothing: their slices are zeroed when the first backward after zero_grad() ends
+        # (or at step() / a reducer's wait()), whichever comes first.  Between zero_grad() and that point ``p.grad`` is None --
+        # torch's ``set_to_none=True`` behaviour -- so a gradient autograd itself produces is assigned, never added to stale data.
+        self.lazy_zero = bool(lazy_zero) and bool(direct_grads) and self.fp.flat.is_cuda
+        self._stale, self._finalize_queued = False, False
+        self._views = [self.fp.grad_view(i) for i in range(len(self.fp.params))] if self.lazy_zero else None
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.exp_avg = torch.zeros_like(self.fp.flat)
         self.exp_avg_sq = torch.zeros_like(self.fp.flat)
@@ -95,12 +109,29 @@ class FusedAdam:
 
     def _make_hook(self, i):
         def hook(param):
+            if self._stale:
+                # lazy_zero: autograd ASSIGNED this gradient (p.grad was None): move it into the parameter's slice
+                g, view = param.grad, self._views[i]
+                if g is not None and g.data_ptr() != view.data_ptr():
+                    if self._touched[i]:
+                        view.add_(g)
+                    else:
+                        view.copy_(g)
+                    param.grad = view
             self._on_grad(i)
         return hook
 
     def _on_grad(self, i):
         self._touched[i] = True
         self._contrib[i] += 1
+        if self._stale and not self._finalize_queued:
+            # p.grad is complete (untouched slices zero, every p.grad attached) as soon as the running ``.backward()`` returns
+            try:
+                from torch.autograd import Variable
+                Variable._execution_engine.queue_callback(self.finalize_grads)
+                self._finalize_queued = True
+            except RuntimeError:                   # not inside a backward (a caller writing gradients by hand): step() finalizes
+                pass
         for f in self.grad_listeners:
             f(i)
 
@@ -123,6 +154,28 @@ class FusedAdam:
             Variable._execution_engine.queue_callback(self._fold_spill)
         p, o = self.fp.params[i], self.fp.offsets[i]
         return self._spill[k][o:o + p.numel()].view(p.shape)
+
+    def finalize_grads(self):
+        """lazy_zero: zero the slices of the parameters that received nothing since zero_grad() and re-attach every ``p.grad``.
+        Idempotent; runs at the end of the first backward after zero_grad(), from step() and from GradReducer.wait()."""
+        self._finalize_queued = False
+        if not self._stale:
+            return
+        self._stale = False
+        fp, t = self.fp, self._touched
+        i, n = 0, len(fp.params)
+        while i < n:
+            if t[i]:
+                i += 1
+                continue
+            j = i
+            while j + 1 < n and not t[j + 1]:
+                j += 1
+            ops.fill_(fp.grad[fp.offsets[i]:fp.offsets[j] + fp.params[j].numel()], 0.0)
+            i = j + 1
+        for p, v in zip(fp.params, self._views):
+            if p.grad is not v:
+                p.grad = v
 
     def _new_spill_buffer(self):
         """A zeroed buffer that kernels of ANY stream may write slices of behind autograd's back.  With side streams on
@@ -163,8 +216,13 @@ class FusedAdam:
             for k in range(self._spill_used):
                 ops.fill_(self._spill[k], 0.0)
             self._spill_used = 0
-        ops.fill_(self.fp.grad, 0.0)
-        self.fp.attach_grads()
+        if self.lazy_zero:
+            self._stale, self._finalize_queued = True, False
+            for p in self.fp.params:
+                p.grad = None
+        else:
+            ops.fill_(self.fp.grad, 0.0)
+            self.fp.attach_grads()
         self._touched = [False] * len(self.fp.params)
         self._contrib = [0] * len(self.fp.params)
         self._spill_k, self._spill_dirty = [0] * len(self.fp.params), False
@@ -177,12 +235,14 @@ class FusedAdam:
     def mark_all_touched(self):
         """for callers that write gradients directly into the flat buffer (tests, custom reducers)"""
         self._touched = [True] * len(self.fp.params)
+        self.finalize_grads()
 
     def scaled_grad(self, i=None):
         """The gradient the coming step() will apply -- ``grad * grad_scale`` -- of parameter ``i`` (None: the whole flat buffer),
         as a new tensor.  After a data-parallel reduce with a deferred scale (GradReducer.wait(defer_scale=True)) ``p.grad`` holds
         the SUM over ranks and ``grad_scale`` the 1 / world; a pre_step hook registered after the reducer's (gradient clipping,
         norm logging) reads the mean through this helper instead of the raw buffer."""
+        self.finalize_grads()
         g = self.fp.grad if i is None else self.fp.grad_view(i)
         return g * self.grad_scale if self.grad_scale != 1.0 else g.clone()
 
@@ -190,6 +250,7 @@ class FusedAdam:
         try:
             streams.join_all(self.fp.grad.device)      # (see zero_grad)
             self._fold_spill()
+            self.finalize_grads()
             for h in self.pre_step_hooks:
                 h()
             self.fp.attach_grads()

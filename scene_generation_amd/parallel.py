@@ -240,6 +240,8 @@ class GradReducer:
 
     def flush(self):
         """Issue the all-reduce of every bucket not launched yet (the backward is over); does not wait."""
+        if self.optimizer is not None and hasattr(self.optimizer, 'finalize_grads'):
+            self.optimizer.finalize_grads()              # (a backward that delivered nothing queued no end-of-backward callback)
         if self.world > 1 and self.active and self.armed:
             while self._next < len(self.buckets):
                 self._launch(self._next)
@@ -253,6 +255,8 @@ class GradReducer:
         ``defer_scale``: leave the SUM in the gradient buffer and hand the 1 / world factor to the owning optimiser's next
         step() (FusedAdam.grad_scale: the Adam kernel multiplies while it reads the gradient) -- saves one read + write pass
         over the flat gradient buffer and one launch per optimiser and step (1.5 GB of HBM traffic for the generator)."""
+        if self.optimizer is not None and hasattr(self.optimizer, 'finalize_grads'):
+            self.optimizer.finalize_grads()              # lazy_zero: slices nobody wrote are zero before they are reduced
         if self.world > 1 and self.active:
             while self._next < len(self.buckets):        # (also when nobody armed the reducer: hooks were ignored)
                 self._launch(self._next)

@@ -24,6 +24,7 @@ from . import ops
 from .discriminators import AcCropDiscriminator, define_mask_D, define_D
 from .losses import get_gan_losses, GANLoss, VGGLoss
 from .model import Model
+from . import optim
 from .optim import FusedAdam
 from .parallel import GradReducer, broadcast_params, broadcast_int, control_group
 from .utils import LossManager, respect_cpu_quota, weighted_sum
@@ -153,7 +154,7 @@ class Trainer:
         q.append(ev)
 
     def _adam(self, module, lr):
-        return FusedAdam(module.parameters(), lr=lr, betas=(self.args.beta1, 0.999))
+        return FusedAdam(module.parameters(), lr=lr, betas=(self.args.beta1, 0.999), lazy_zero=optim.LAZY_ZERO)
 
     def init_generator(self, args, checkpoint):
         if args.restore_from_checkpoint:

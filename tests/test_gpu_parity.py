@@ -1685,6 +1685,59 @@ def test_weighted_sum_and_gradient_sinks(hip):
     assert torch.equal(unused.weight, before) and opt.steps == [1] * 6 + [0] * 2
 
 
+def test_lazy_zero_grad_equals_eager_fill(hip):
+    """FusedAdam(lazy_zero=True) -- what the Trainer builds: zero_grad() launches no fill; the first contribution of a step
+    overwrites its slice, the slices nobody wrote are zeroed when the first backward ends.  Against the eager-fill optimiser over
+    four steps with a parameter that is never used, one used every other step, a second backward without zero_grad() and a
+    gradient autograd itself produces (a plain torch op on a parameter): same parameters, same moments, same step counts, bit for
+    bit; ``p.grad`` is None between zero_grad() and the backward (torch's set_to_none) and the flat slice afterwards."""
+    from scene_generation_amd.optim import FusedAdam
+    from scene_generation_amd import layers as Lh
+
+    def build():
+        net = nn.Sequential(Lh.Conv2d(3, 8, 3, padding=1), Lh.BatchNorm2d(8), Lh.ReLU(), Lh.Conv2d(8, 4, 3, padding=1)).to(DEV)
+        mid = Lh.Linear(4, 4).to(DEV)
+        unused = Lh.Linear(5, 5).to(DEV)
+        scale = nn.Parameter(torch.full((4,), 0.7, device=DEV))          # multiplied in with a plain torch op below
+        fill_deterministic(net)
+        fill_deterministic(mid)
+        fill_deterministic(unused)
+        return net, mid, unused, scale
+
+    x = det((2, 3, 8, 8), 350).to(DEV)
+    res = {}
+    for lazy in (True, False):
+        net, mid, unused, scale = build()
+        params = list(net.parameters()) + list(mid.parameters()) + list(unused.parameters()) + [scale]
+        opt = FusedAdam(params, lr=1e-2, betas=(0.5, 0.999), lazy_zero=lazy)
+        assert opt.lazy_zero == lazy
+        # stale data every step would have to overwrite: what the previous iteration left in the buffer, made loud
+        for it in range(4):
+            if lazy:
+                for i in range(len(params)):           # (the alignment gaps between slices are never written: they stay zero)
+                    opt.fp.grad_view(i).fill_(1e30)
+            opt.zero_grad()
+            if lazy:
+                assert all(p.grad is None for p in params)
+            for rep in range(2 if it == 3 else 1):
+                h = net(x) * scale.view(1, 4, 1, 1)
+                h = h.mean((2, 3))
+                if it % 2 == 0:
+                    h = mid(h)
+                h.pow(2).sum().backward()
+            for i, p in enumerate(params):
+                assert p.grad is not None and p.grad.data_ptr() == opt.fp.grad_view(i).data_ptr()
+            assert float(unused.weight.grad.abs().max()) == 0.0 and float(unused.bias.grad.abs().max()) == 0.0
+            if it % 2 == 1:
+                assert float(mid.weight.grad.abs().max()) == 0.0
+            opt.step()
+        res[lazy] = ([p.detach().clone() for p in params], opt.exp_avg.clone(), opt.exp_avg_sq.clone(), list(opt.steps))
+    assert res[True][3] == res[False][3] == [4] * 6 + [2] * 2 + [0] * 2 + [4]
+    for a, c in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, c)
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+
+
 def test_crop_backward_is_deterministic_and_exact(hip):
     """the gather form of the crop gradient: bit-identical run to run, equals the transpose of the forward (autograd of
     F.grid_sample) incl. permuted / repeated / out-of-range boxes and up-sampling crops"""
