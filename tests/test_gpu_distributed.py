@@ -142,6 +142,23 @@ def test_bench_dp_leg_executes_two_ranks_on_one_gpu(world, per_gpu, steps):
         cmd.append('--no_prof')
         env['SG_BENCH_QUICK'] = '1'
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0 and world == 8 and 'GPU core dump' in (r.stdout + r.stderr):
+        # Round 6: ONE of ~35 runs of this case (eight full-width trainers time-slicing one GPU) lost a rank to a GPU fault during
+        # the warm-up steps; 20 reruns on the same tree and 12 with the round's scheduling options off did not reproduce it
+        # ("known issue").  The event is recorded with whatever the runtime printed and the case runs once more:
+        # a second failure fails the test.
+        import warnings
+        lines = [ln for ln in (r.stdout + '\n' + r.stderr).splitlines()
+                 if any(k in ln for k in ('Memory access fault', 'core dump', 'HSA_STATUS', 'hipError', 'Signal 6'))]
+        try:
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            with open(os.path.join(ROOT, 'gpurun_out', 'dp8_gpu_fault.txt'), 'a') as f:
+                f.write('\n'.join(lines[:40]) + '\n----\n')
+        except OSError:
+            pass
+        warnings.warn('bench.py --gpus 8 on one GPU: a rank died with a GPU fault, retrying once:\n' + '\n'.join(lines[:10]))
+        cmd[cmd.index('--master-port') + 1] = str(_free_port())
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, 'bench.py --gpus %d failed:\n%s\n%s' % (world, r.stdout[-3000:], r.stderr[-6000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
     assert len(lines) == 1, 'exactly ONE JSON line from rank 0, got %d:\n%s' % (len(lines), r.stdout[-3000:])
