@@ -9,7 +9,7 @@ Differences from the reference are confined to how the work is issued:
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, streams
 from .bilinear import crop_bbox_batch
 from .generators import mask_net, AppearanceEncoder, define_G
 from .graph import GraphTripleConv, GraphTripleConvNet
@@ -82,15 +82,29 @@ class Model(nn.Module):
         if objs_h is None or o2i_h is None:      # one sync (the reference's pool does objs.tolist(), utils.py:104)
             objs_h, o2i_h = torch.stack((objs, obj_to_img)).tolist()
         N = gt_imgs.size(0) if gt_imgs is not None else max(o2i_h) + 1
-        obj_vecs, pred_vecs = self.scene_graph_to_vectors(objs, triples, attributes)
-        box_vecs, mask_vecs, scene_layout_vecs, wrong_layout_vecs = \
-            self.create_components_vecs(gt_imgs, boxes_gt, obj_to_img, objs, obj_vecs, features, objs_host=objs_h)
+        lazy = self.lazy_layouts and ops.FACTORED_LAYOUT
+        # The OBJECT FRONT -- embeddings, graph convolutions, box_net, mask_net -- and the IMAGE PATH of the training branch --
+        # crops, AppearanceEncoder, the layouts built from the ground-truth boxes and masks, the generator (model.py:98-124) --
+        # share no tensor: boxes_pred / masks_pred feed losses and the (deferred) pred_layout only.  The front is ~100 launches of
+        # a few microseconds forward and ~250 backward; on a side stream (streams.fork, group 'front') they run beside the
+        # generator's GEMMs, forward here and backward wherever autograd runs the nodes recorded on that stream.  Only when the
+        # dense pred_layout is deferred (Trainer.step) and no inference-time features are given; results are bit-identical.
+        side = lazy and not test_mode and features is None
+        with streams.fork(objs.device, 'front', enabled=side) as fk:
+            with fk.branch(1, reads=(objs, triples, attributes)):
+                obj_vecs, pred_vecs = self.scene_graph_to_vectors(objs, triples, attributes)
+                box_vecs, mask_vecs = obj_vecs, self._mask_vecs(obj_vecs, O)
+                boxes_pred = self.box_net(box_vecs)
+                mask_scores = self.mask_net(mask_vecs.view(O, -1, 1, 1))
+                masks_pred = ops.activation(mask_scores.squeeze(1), ops.ACT_SIGMOID)
+                fk.produced((boxes_pred, masks_pred, mask_vecs))
+            scene_layout_vecs, wrong_layout_vecs = self._appearance_vecs(gt_imgs, boxes_gt, obj_to_img, objs, mask_vecs, features,
+                                                                         objs_host=objs_h)
+            return self._layouts_and_image(gt_imgs, objs, obj_to_img, boxes_gt, masks_gt, boxes_pred, masks_pred,
+                                           scene_layout_vecs, wrong_layout_vecs, objs_h, o2i_h, N, lazy, test_mode, use_gt_box)
 
-        boxes_pred = self.box_net(box_vecs)
-
-        mask_scores = self.mask_net(mask_vecs.view(O, -1, 1, 1))
-        masks_pred = ops.activation(mask_scores.squeeze(1), ops.ACT_SIGMOID)
-
+    def _layouts_and_image(self, gt_imgs, objs, obj_to_img, boxes_gt, masks_gt, boxes_pred, masks_pred, scene_layout_vecs,
+                           wrong_layout_vecs, objs_h, o2i_h, N, lazy, test_mode, use_gt_box):
         H, W = self.image_size
         kw = dict(num_images=N, validate=False, max_per_image=self.layout_objects_hint)
         if test_mode:                                      # model.py:111-117
@@ -102,7 +116,6 @@ class Model(nn.Module):
                 to_device_async(torch.from_numpy(a), pred_layout.device)
                 for a in active_layout_channels(objs_h, o2i_h, N, self.num_objs, self.rep_size)))
             return self.layout_to_image(pred_layout), boxes_pred, masks_pred, None, pred_layout, None
-        lazy = self.lazy_layouts and ops.FACTORED_LAYOUT
         seg = ops.segment_offsets(obj_to_img, N)
         if lazy:
             # nothing on the training step reads the dense layouts (the convs over them run on the factored form): their
@@ -167,14 +180,21 @@ class Model(nn.Module):
         return obj_vecs, pred_vecs
 
     def create_components_vecs(self, imgs, boxes, obj_to_img, objs, obj_vecs, features, objs_host=None):
-        O = objs.size(0)
-        box_vecs = obj_vecs
+        """model.py:146-172 -- the reference's method, kept whole for callers of the reference surface; forward() runs its two
+        halves separately (the first belongs to the object front, the second to the image path)."""
+        mask_vecs = self._mask_vecs(obj_vecs, objs.size(0))
+        layout_vecs, wrong_layout_vecs = self._appearance_vecs(imgs, boxes, obj_to_img, objs, mask_vecs, features,
+                                                               objs_host=objs_host)
+        return obj_vecs, mask_vecs, layout_vecs, wrong_layout_vecs
+
+    def _mask_vecs(self, obj_vecs, O):
         if self.noise_override is not None:
             noise = self.noise_override.to(obj_vecs.device, obj_vecs.dtype).view(1, self.mask_noise_dim)
         else:                                                # ONE noise row per batch (model.py:149-151)
             noise = torch.randn((1, self.mask_noise_dim), dtype=obj_vecs.dtype, device=obj_vecs.device)
-        mask_vecs = ops.concat_cols(obj_vecs, noise.expand(O, self.mask_noise_dim))
+        return ops.concat_cols(obj_vecs, noise.expand(O, self.mask_noise_dim))
 
+    def _appearance_vecs(self, imgs, boxes, obj_to_img, objs, mask_vecs, features, objs_host=None):
         if features is None:
             crops = crop_bbox_batch(imgs, boxes, obj_to_img, self.object_size)
             obj_repr = self.repr_net(self.image_encoder(crops))
@@ -191,4 +211,4 @@ class Model(nn.Module):
 
         wrong_objs_rep = self.fake_pool.query(objs, obj_repr, objs_host=objs_host if objs_host is not None else self.objs_host)
         wrong_layout_vecs = ops.concat_cols(one_hot_obj, wrong_objs_rep)
-        return box_vecs, mask_vecs, layout_vecs, wrong_layout_vecs
+        return layout_vecs, wrong_layout_vecs

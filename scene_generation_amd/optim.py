@@ -96,6 +96,9 @@ class FusedAdam:
         # the step that follows (GradReducer.wait(defer_scale=True)) instead of scaling the flat buffer in place: after such a
         # step() ``p.grad`` holds the sum over ranks, not the mean.  Reset to 1 by step().
         self.grad_scale = 1.0
+        # side-stream groups (streams.py) whose kernels never write this optimiser's buffers: not waited for in zero_grad() /
+        # step() (the Trainer's discriminator optimisers: ('front',) -- the generator's object front runs beside their steps)
+        self.join_exclude = ()
         self.pre_step_hooks = []          # e.g. GradReducer.wait
         self.zero_grad_hooks = []         # e.g. GradReducer.begin_step
         self.grad_listeners = []          # callables(i): parameter i just received (a contribution to) its gradient
@@ -183,7 +186,7 @@ class FusedAdam:
         written, so the fill is completed before the buffer is handed out: one host synchronisation per buffer
         per optimiser, in the first step only (the buffers live as long as the optimiser)."""
         buf = torch.zeros_like(self.fp.grad)
-        if streams.ENABLED and buf.is_cuda:
+        if (streams.ENABLED or streams.GROUPS) and buf.is_cuda:
             torch.cuda.current_stream(buf.device).synchronize()
         self._spill.append(buf)
 
@@ -193,7 +196,7 @@ class FusedAdam:
         spill slices behind autograd's back, so the reader joins them first (streams.py's rule for these buffers)."""
         self._fold_queued = False
         if self._spill_used:
-            streams.join_all(self.fp.grad.device)
+            streams.join_all(self.fp.grad.device, self.join_exclude)
         for k in range(self._spill_used):
             ops.add_clear_(self.fp.grad, self._spill[k])
         self._spill_used = 0
@@ -211,7 +214,7 @@ class FusedAdam:
                      params=self.fp.params)]
 
     def zero_grad(self, set_to_none=False):
-        streams.join_all(self.fp.grad.device)      # weight-gradient kernels of side streams write this buffer (streams.py)
+        streams.join_all(self.fp.grad.device, self.join_exclude)      # weight-gradient kernels of side streams write this buffer (streams.py)
         if self._spill_used:                        # contributions of a backward whose step never came: dropped with the rest
             for k in range(self._spill_used):
                 ops.fill_(self._spill[k], 0.0)
@@ -248,7 +251,7 @@ class FusedAdam:
 
     def step(self):
         try:
-            streams.join_all(self.fp.grad.device)      # (see zero_grad)
+            streams.join_all(self.fp.grad.device, self.join_exclude)      # (see zero_grad)
             self._fold_spill()
             self.finalize_grads()
             for h in self.pre_step_hooks:

@@ -235,7 +235,7 @@ class GradReducer:
         s, e, _ = self.buckets[b]
         self._launched[b] = True
         self._next = b + 1
-        streams.join_all(self.fp.grad.device)      # gradients written by side-stream kernels (streams.py) must be complete
+        streams.join_all(self.fp.grad.device, getattr(self.optimizer, 'join_exclude', ()))      # gradients written by side-stream kernels (streams.py) must be complete
         self._works.append(dist.all_reduce(self.fp.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def flush(self):

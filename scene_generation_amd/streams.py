@@ -34,12 +34,22 @@ import os
 import torch
 
 ENABLED = os.environ.get('SG_MULTISTREAM', '0') == '1'
+# Groups that fork even when ENABLED is off.  'front' (round 6, default ON): the object front of Model.forward -- embeddings,
+# graph convolutions, box_net, mask_net: ~250 launches of a few microseconds each, forward + backward -- shares NO data with the
+# image path of the training branch (crops -> AppearanceEncoder -> layouts from the GROUND-TRUTH boxes and masks -> generator:
+# model.py:98-124 of the reference); on a side stream its latency-bound launches run under the generator's GEMMs instead of in
+# front of / behind them.  SG_STREAM_GROUPS='' switches it off, SG_STREAM_GROUPS=front,imgD adds groups by name.
+GROUPS = set(g for g in os.environ.get('SG_STREAM_GROUPS', 'front').split(',') if g)
 _POOL = {}            # (device index, group, branch) -> torch.cuda.Stream
-_LIVE = {}            # device index -> set of side streams that have been handed out
+_LIVE = {}            # device index -> {side stream that has been handed out: its group}
 
 
-def _usable(device):
-    return (ENABLED and device is not None and device.type == 'cuda' and torch.cuda.is_available()
+def group_on(group):
+    return ENABLED or group in GROUPS
+
+
+def _usable(device, group=None):
+    return (group_on(group) and device is not None and device.type == 'cuda' and torch.cuda.is_available()
             and not torch.cuda.is_current_stream_capturing())
 
 
@@ -48,14 +58,14 @@ def side_stream(device, group, i):
     s = _POOL.get(key)
     if s is None:
         s = _POOL[key] = torch.cuda.Stream(device=device)
-        _LIVE.setdefault(key[0], set()).add(s)
+        _LIVE.setdefault(key[0], {})[s] = group
     return s
 
 
 class fork(object):
     def __init__(self, device, group, enabled=True):
         self.device, self.group = device, group
-        self.on = bool(enabled) and _usable(device)
+        self.on = bool(enabled) and _usable(device, group)
         self.used = []
 
     def __enter__(self):
@@ -101,17 +111,18 @@ def _tensors(x):
                 yield t
 
 
-def join_all(device=None):
+def join_all(device=None, exclude=()):
     """Make the current stream wait for every side stream of the device (cheap: one event per stream).  Called before anything
-    reads memory that side-stream kernels write behind autograd's back: the flat gradient buffers."""
-    if not ENABLED or not torch.cuda.is_available() or not _LIVE:
+    reads memory that side-stream kernels write behind autograd's back: the flat gradient buffers.  ``exclude``: groups whose
+    kernels never write what the caller is about to read (a discriminator's optimiser does not wait for the generator's front)."""
+    if not _LIVE or not torch.cuda.is_available():
         return
     idx = torch.cuda.current_device() if device is None or device.index is None else device.index
     live = _LIVE.get(idx)
     if not live or torch.cuda.is_current_stream_capturing():
         return
     cur = torch.cuda.current_stream(idx)
-    for s in live:
-        if s != cur:
+    for s, group in live.items():
+        if s != cur and group not in exclude:
             cur.wait_stream(s)
 

@@ -153,8 +153,10 @@ class Trainer:
         ev.record()
         q.append(ev)
 
-    def _adam(self, module, lr):
-        return FusedAdam(module.parameters(), lr=lr, betas=(self.args.beta1, 0.999), lazy_zero=optim.LAZY_ZERO)
+    def _adam(self, module, lr, join_exclude=()):
+        opt = FusedAdam(module.parameters(), lr=lr, betas=(self.args.beta1, 0.999), lazy_zero=optim.LAZY_ZERO)
+        opt.join_exclude = tuple(join_exclude)
+        return opt
 
     def init_generator(self, args, checkpoint):
         if args.restore_from_checkpoint:
@@ -198,7 +200,7 @@ class Trainer:
                 checkpoint['d_obj_kwargs'] = d_obj_kwargs
             self.obj_discriminator = AcCropDiscriminator(**d_obj_kwargs).to(self.device)
             self.obj_discriminator.train()
-            self.optimizer_d_obj = self._adam(self.obj_discriminator, args.learning_rate)
+            self.optimizer_d_obj = self._adam(self.obj_discriminator, args.learning_rate, join_exclude=('front',))
 
     def init_mask_discriminator(self, args, checkpoint):
         self.mask_discriminator, self.optimizer_d_mask = None, None
@@ -212,7 +214,7 @@ class Trainer:
                 checkpoint['d_mask_kwargs'] = d_mask_kwargs
             self.mask_discriminator = define_mask_D(**d_mask_kwargs).to(self.device)
             self.mask_discriminator.train()
-            self.optimizer_d_mask = self._adam(self.mask_discriminator, args.mask_learning_rate)
+            self.optimizer_d_mask = self._adam(self.mask_discriminator, args.mask_learning_rate, join_exclude=('front',))
 
     def init_image_discriminator(self, args, checkpoint):
         if args.d_img_weight == 0:
@@ -227,7 +229,7 @@ class Trainer:
             checkpoint['d_img_kwargs'] = d_img_kwargs
         self.netD = define_D(**d_img_kwargs).to(self.device)
         self.netD.train()
-        self.optimizer_d_img = self._adam(self.netD, args.learning_rate)
+        self.optimizer_d_img = self._adam(self.netD, args.learning_rate, join_exclude=('front',))
 
     # ---- checkpoints (reference schema: trainer.py:136-203, train.py:119-163) ----
     def restore_checkpoint(self, checkpoint, best=False):

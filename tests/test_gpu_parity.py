@@ -2253,6 +2253,50 @@ def test_graphed_segments_are_bit_identical_to_eager(hip):
     assert res[0][2] == res[1][2]
 
 
+def test_object_front_on_a_side_stream_is_bit_identical(hip):
+    """streams group 'front' (default on): Model.forward issues embeddings, graph convolutions, box_net and mask_net on a side
+    stream beside the image path (they share no tensor in the training branch, model.py:98-124) and autograd runs their
+    backward there.  Five G+D steps with the reference's default flags, use_gt alternating (box_net untouched every other step),
+    give bit-identical losses, images and parameters with the group on and off; the side stream was really used."""
+    from scene_generation_amd import streams
+    from scene_generation_amd.trainer import Trainer
+    args = parser.parse_args(['--image_size', '64,64', '--batch_size', '4', '--output_dir', '/tmp/o'])
+    batches = [batch_to(make_batch(N=4, min_objs=3, max_objs=6, size=64, seed=70 + i), DEV) for i in range(2)]
+    res = []
+    saved = set(streams.GROUPS)
+    try:
+        for on in (True, False):
+            streams.GROUPS.clear()
+            if on:
+                streams.GROUPS.add('front')
+            torch.manual_seed(0)
+            tr = _filled_trainer(args, make_vocab())
+            tr.model.noise_override = det((1, 64), 182).to(DEV)
+            random.seed(22)
+            hist = []
+            for it in range(5):
+                out = tr.step(batches[it % 2], use_gt=(it % 2 == 0))
+                losses = {}
+                for L in (tr.generator_losses, tr.d_img_losses, tr.d_obj_losses, tr.d_mask_losses):
+                    losses.update(dict(L.items()))
+                hist.append((losses, [t.detach().clone() for t in out[:3]]))
+            torch.cuda.synchronize()
+            flat = torch.cat([getattr(tr, n).fp.flat for n in ('optimizer', 'optimizer_d_mask', 'optimizer_d_obj',
+                                                              'optimizer_d_img')]).clone()
+            res.append((hist, flat, list(tr.optimizer.steps)))
+            del tr
+    finally:
+        streams.GROUPS.clear()
+        streams.GROUPS.update(saved)
+    assert any(k[1] == 'front' for k in streams._POOL), 'the front never ran on its side stream'
+    for (la, ta), (lb, tb) in zip(res[0][0], res[1][0]):
+        assert la == lb, (la, lb)
+        for x, y in zip(ta, tb):
+            assert torch.equal(x, y)
+    assert torch.equal(res[0][1], res[1][1])
+    assert res[0][2] == res[1][2]
+
+
 def test_legacy_align_corners_switch(hip, golden):
     """set_legacy_align_corners(True): the align_corners=True geometry of PyTorch 1.0 (what the reference's released
     checkpoints were trained with) against the reference goldens captured with that default; restored afterwards."""
