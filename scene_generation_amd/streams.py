@@ -39,6 +39,9 @@ ENABLED = os.environ.get('SG_MULTISTREAM', '0') == '1'
 # image path of the training branch (crops -> AppearanceEncoder -> layouts from the GROUND-TRUTH boxes and masks -> generator:
 # model.py:98-124 of the reference); on a side stream its latency-bound launches run under the generator's GEMMs instead of in
 # front of / behind them.  SG_STREAM_GROUPS='' switches it off, SG_STREAM_GROUPS=front,imgD adds groups by name.
+# 'adam' (round 6, measured and left OFF): inside Trainer.step the generator's Adam step on a side stream under the discriminator
+# sub-steps (trainer._step_or_defer) -- 0.6 ms of HBM streaming beside MFMA-bound GEMMs: 30.30 -> 30.61 ms/step, three same-box
+# pairs (profiles/r06_ab_adam_stream.txt): the GEMMs lose more to the contention than the step hides.
 GROUPS = set(g for g in os.environ.get('SG_STREAM_GROUPS', 'front').split(',') if g)
 _POOL = {}            # (device index, group, branch) -> torch.cuda.Stream
 _LIVE = {}            # device index -> {side stream that has been handed out: its group}

@@ -2268,7 +2268,7 @@ def test_object_front_on_a_side_stream_is_bit_identical(hip):
         for on in (True, False):
             streams.GROUPS.clear()
             if on:
-                streams.GROUPS.add('front')
+                streams.GROUPS.update(('front', 'adam'))     # (+ the generator's Adam step on its own stream under the D steps)
             torch.manual_seed(0)
             tr = _filled_trainer(args, make_vocab())
             tr.model.noise_override = det((1, 64), 182).to(DEV)
@@ -2289,6 +2289,7 @@ def test_object_front_on_a_side_stream_is_bit_identical(hip):
         streams.GROUPS.clear()
         streams.GROUPS.update(saved)
     assert any(k[1] == 'front' for k in streams._POOL), 'the front never ran on its side stream'
+    assert any(k[1] == 'adam' for k in streams._POOL), 'the generator Adam step never ran on its side stream'
     for (la, ta), (lb, tb) in zip(res[0][0], res[1][0]):
         assert la == lb, (la, lb)
         for x, y in zip(ta, tb):
