@@ -42,7 +42,10 @@ ENABLED = os.environ.get('SG_MULTISTREAM', '0') == '1'
 # 'adam' (round 6, measured and left OFF): inside Trainer.step the generator's Adam step on a side stream under the discriminator
 # sub-steps (trainer._step_or_defer) -- 0.6 ms of HBM streaming beside MFMA-bound GEMMs: 30.30 -> 30.61 ms/step, three same-box
 # pairs (profiles/r06_ab_adam_stream.txt): the GEMMs lose more to the contention than the step hides.
-GROUPS = set(g for g in os.environ.get('SG_STREAM_GROUPS', 'front').split(',') if g)
+# 'mstep' (round 6, default ON; needs 'front'): the mask discriminator's work -- its two forwards and data gradients inside the
+# generator step, its own sub-step (backward through the shared forwards, Adam) -- continues the front's stream: O 16x16 masks,
+# small launches fed by masks_pred only (trainer.train_generator / train_mask_discriminator).  +3.1 % on top of 'front'.
+GROUPS = set(g for g in os.environ.get('SG_STREAM_GROUPS', 'front,mstep').split(',') if g)
 _POOL = {}            # (device index, group, branch) -> torch.cuda.Stream
 _LIVE = {}            # device index -> {side stream that has been handed out: its group}
 

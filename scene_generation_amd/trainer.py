@@ -214,7 +214,9 @@ class Trainer:
                 checkpoint['d_mask_kwargs'] = d_mask_kwargs
             self.mask_discriminator = define_mask_D(**d_mask_kwargs).to(self.device)
             self.mask_discriminator.train()
-            self.optimizer_d_mask = self._adam(self.mask_discriminator, args.mask_learning_rate, join_exclude=('front',))
+            # (group 'mstep': kernels of the front's stream write this optimiser's gradients -- it waits for that stream like the generator's)
+            self.optimizer_d_mask = self._adam(self.mask_discriminator, args.mask_learning_rate,
+                                               join_exclude=() if streams.group_on('mstep') else ('front',))
 
     def init_image_discriminator(self, args, checkpoint):
         if args.d_img_weight == 0:
@@ -310,7 +312,12 @@ class Trainer:
         share = getattr(self, 'share_d_forward', True)
         share_mask, share_img = share and self._shareable['mask'], share and self._shareable['img']
         d_shared = [p for m in (self.mask_discriminator, self.netD) if m is not None for p in m.parameters()]
-        with _frozen(self.obj_discriminator), ops.skip_param_grads(d_shared):
+        # group 'mstep' (streams.py): the mask discriminator's part of this step -- two forwards over O 16x16 masks, its losses, and
+        # in the backward its data gradients: small launches, fed by masks_pred only -- continues the object front's side stream
+        # beside the object / image discriminator work on the current stream (joined when this ``with`` block ends, before the
+        # total is formed)
+        with _frozen(self.obj_discriminator), ops.skip_param_grads(d_shared), \
+                streams.fork(imgs_pred.device, 'front', enabled=streams.group_on('mstep')) as fk:
             if use_gt:
                 if args.l1_pixel_loss_weight > 0:
                     L.add_loss(ops.l1(imgs_pred, imgs), 'L1_pixel_loss', args.l1_pixel_loss_weight)
@@ -324,18 +331,23 @@ class Trainer:
             L.add_loss(self.gan_g_loss(scores_fake), 'g_gan_obj_loss', args.d_obj_weight)
 
             if self.mask_discriminator is not None:
+              with fk.branch(1, reads=(masks_pred, masks, objs)):
                 one_hot_obj = ops.one_hot(objs, self.num_obj)
                 scores_fake = self.mask_discriminator(masks_pred.unsqueeze(1), one_hot_obj)
                 if share_mask:
                     shared['mask_fake'] = scores_fake
-                L.add_loss(self.criterionGAN(scores_fake, True), 'g_gan_mask_obj_loss', args.d_mask_weight)
+                g_mask = self.criterionGAN(scores_fake, True)
+                L.add_loss(g_mask, 'g_gan_mask_obj_loss', args.d_mask_weight)
+                fk.produced((scores_fake, g_mask))
                 if args.d_mask_features_weight > 0:
                     with (contextlib.nullcontext() if share_mask else torch.no_grad()):
                         scores_real = self.mask_discriminator(masks.float().unsqueeze(1), one_hot_obj)
                     if share_mask:
                         shared['mask_real'] = scores_real
-                    L.add_loss(self.calculate_features_loss(scores_fake, scores_real), 'g_mask_features_loss',
+                    g_mfeat = self.calculate_features_loss(scores_fake, scores_real)
+                    L.add_loss(g_mfeat, 'g_mask_features_loss',
                                args.d_mask_features_weight)      # real features enter detached (trainer.py:339)
+                    fk.produced((scores_real, g_mfeat))
 
             if self.netD is not None:
                 lay = layout.detach()               # no gradient reaches the layout through D (trainer.py:246-248)
@@ -380,7 +392,7 @@ class Trainer:
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 opt.step()
-            self._adam_pending = side
+            self._side_pending.append(side)
         else:
             opt.step()
 
@@ -419,6 +431,22 @@ class Trainer:
 
     def train_mask_discriminator(self, masks, masks_pred, objs):
         if self.mask_discriminator is not None:
+            # inside Trainer.step, one GPU, group 'mstep': the whole sub-step (losses, backward through the shared forwards --
+            # recorded on the front's stream, so autograd runs them there anyway --, Adam) on that stream, beside the object /
+            # image discriminator sub-steps that follow on the current one; Trainer.step joins the stream before it returns
+            if getattr(self, '_side_ok', False) and streams.group_on('mstep') and streams.group_on('front') and masks_pred.is_cuda:
+                main = torch.cuda.current_stream(masks_pred.device)
+                side = streams.side_stream(masks_pred.device, 'front', 1)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._train_mask_discriminator(masks, masks_pred, objs)
+                    self.d_mask_losses.total_loss.record_stream(main)
+                self._side_pending.append(side)
+            else:
+                self._train_mask_discriminator(masks, masks_pred, objs)
+
+    def _train_mask_discriminator(self, masks, masks_pred, objs):
+        if True:
             self.d_mask_losses = L = LossManager()
             shared = getattr(self, '_shared', {})
             one_hot_obj = ops.one_hot(objs, self.num_obj)
@@ -503,7 +531,9 @@ class Trainer:
         self._deferred_steps = []
         self._adam_side = (streams.group_on('adam') and imgs.is_cuda and not self._defer_g_step and not self.reducers
                            and not torch.cuda.is_current_stream_capturing())
-        self._adam_pending = None
+        # side streams whose work this step must join before it returns; sub-steps may only leave work there inside step()
+        self._side_pending = []
+        self._side_ok = imgs.is_cuda and not self.reducers and not torch.cuda.is_current_stream_capturing()
         try:
             self.train_generator(imgs, imgs_pred, masks, masks_pred, layout, objs, boxes, boxes_pred, obj_to_img, use_gt)
             self.train_mask_discriminator(masks, masks_pred.detach(), objs)
@@ -514,10 +544,10 @@ class Trainer:
         finally:
             self._defer_g_step = False
             self._deferred_steps = []
-            self._adam_side = False
-            if self._adam_pending is not None:       # the next reader of the generator's parameters is on the current stream
-                torch.cuda.current_stream(imgs.device).wait_stream(self._adam_pending)
-                self._adam_pending = None
+            self._adam_side = self._side_ok = False
+            for side in self._side_pending:          # the next reader of what they wrote is on the current stream
+                torch.cuda.current_stream(imgs.device).wait_stream(side)
+            self._side_pending = []
         if getattr(self, 'dense_layout_outputs', True):
             for lay in (layout, layout_pred, layout_wrong):
                 ops.ensure_dense(lay)

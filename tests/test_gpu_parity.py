@@ -2268,7 +2268,8 @@ def test_object_front_on_a_side_stream_is_bit_identical(hip):
         for on in (True, False):
             streams.GROUPS.clear()
             if on:
-                streams.GROUPS.update(('front', 'adam'))     # (+ the generator's Adam step on its own stream under the D steps)
+                streams.GROUPS.update(('front', 'adam', 'mstep'))     # (+ the generator's Adam step on its own stream under the D
+                #                                                        steps, the mask discriminator's work on the front's stream)
             torch.manual_seed(0)
             tr = _filled_trainer(args, make_vocab())
             tr.model.noise_override = det((1, 64), 182).to(DEV)
