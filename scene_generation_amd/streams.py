@@ -45,7 +45,10 @@ ENABLED = os.environ.get('SG_MULTISTREAM', '0') == '1'
 # 'mstep' (round 6, default ON; needs 'front'): the mask discriminator's work -- its two forwards and data gradients inside the
 # generator step, its own sub-step (backward through the shared forwards, Adam) -- continues the front's stream: O 16x16 masks,
 # small launches fed by masks_pred only (trainer.train_generator / train_mask_discriminator).  +3.1 % on top of 'front'.
-GROUPS = set(g for g in os.environ.get('SG_STREAM_GROUPS', 'front,mstep').split(',') if g)
+# 'imgD' (default ON since the end of round 6): a stream per PatchGAN scale of the image discriminator (the docstring above: a loss
+# of 1 % in round 3; with this round's kernels and the front / mask work already beside them it is +1.0 %, three same-box pairs,
+# profiles/r06_ab_imgd_stream.txt).  'maskD' (a stream per scale of the mask discriminator): +0.2 %, inside the noise, stays off.
+GROUPS = set(g for g in os.environ.get('SG_STREAM_GROUPS', 'front,mstep,imgD').split(',') if g)
 _POOL = {}            # (device index, group, branch) -> torch.cuda.Stream
 _LIVE = {}            # device index -> {side stream that has been handed out: its group}
 
