@@ -214,9 +214,9 @@ class Trainer:
                 checkpoint['d_mask_kwargs'] = d_mask_kwargs
             self.mask_discriminator = define_mask_D(**d_mask_kwargs).to(self.device)
             self.mask_discriminator.train()
-            # (group 'mstep': kernels of the front's stream write this optimiser's gradients -- it waits for that stream like the generator's)
-            self.optimizer_d_mask = self._adam(self.mask_discriminator, args.mask_learning_rate,
-                                               join_exclude=() if streams.group_on('mstep') else ('front',))
+            # (group 'mstep': kernels of the front's stream write this optimiser's gradients -- it waits for that stream like the
+            #  generator's, whether the group is on at construction time or switched on later)
+            self.optimizer_d_mask = self._adam(self.mask_discriminator, args.mask_learning_rate)
 
     def init_image_discriminator(self, args, checkpoint):
         if args.d_img_weight == 0:
