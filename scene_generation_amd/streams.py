@@ -48,7 +48,10 @@ ENABLED = os.environ.get('SG_MULTISTREAM', '0') == '1'
 # 'imgD' (default ON since the end of round 6): a stream per PatchGAN scale of the image discriminator (the docstring above: a loss
 # of 1 % in round 3; with this round's kernels and the front / mask work already beside them it is +1.0 %, three same-box pairs,
 # profiles/r06_ab_imgd_stream.txt).  'maskD' (a stream per scale of the mask discriminator): +0.2 %, inside the noise, stays off.
-GROUPS = set(g for g in os.environ.get('SG_STREAM_GROUPS', 'front,mstep,imgD').split(',') if g)
+# 'objD' (default ON): the object discriminator's branch of the generator step and, inside Trainer.step, its whole sub-step on a
+# stream of their own: -0.2 % next to the front alone, +0.4 % (three pairs) once the mask / image discriminators run beside it
+# (profiles/r06_ab_objd_stream.txt).
+GROUPS = set(g for g in os.environ.get('SG_STREAM_GROUPS', 'front,mstep,imgD,objD').split(',') if g)
 _POOL = {}            # (device index, group, branch) -> torch.cuda.Stream
 _LIVE = {}            # device index -> {side stream that has been handed out: its group}
 
@@ -103,10 +106,15 @@ class fork(object):
             for t in _tensors(outputs):
                 t.record_stream(self.main)
 
-    def __exit__(self, *exc):
+    def join(self):
+        """the fork's stream waits for every branch issued so far (what leaving the ``with`` block does; idempotent)"""
         if self.on:
             for s in self.used:
                 self.main.wait_stream(s)
+            self.used = []
+
+    def __exit__(self, *exc):
+        self.join()
         return False
 
 

@@ -314,8 +314,8 @@ class Trainer:
         d_shared = [p for m in (self.mask_discriminator, self.netD) if m is not None for p in m.parameters()]
         # group 'mstep' (streams.py): the mask discriminator's part of this step -- two forwards over O 16x16 masks, its losses, and
         # in the backward its data gradients: small launches, fed by masks_pred only -- continues the object front's side stream
-        # beside the object / image discriminator work on the current stream (joined when this ``with`` block ends, before the
-        # total is formed)
+        # beside the object / image discriminator work on the current stream (joined by ``fk.join()`` below, before the total is
+        # formed)
         with _frozen(self.obj_discriminator), ops.skip_param_grads(d_shared), \
                 streams.fork(imgs_pred.device, 'front', enabled=streams.group_on('mstep')) as fk:
             if use_gt:
@@ -326,9 +326,13 @@ class Trainer:
             if self.criterionVGG is not None:            # trainer.py:218-221
                 L.add_loss(self.criterionVGG(imgs_pred, imgs), 'g_vgg', args.vgg_features_weight)
 
-            scores_fake, ac_loss, g_fake_crops = self.obj_discriminator(imgs_pred, objs, boxes, obj_to_img)
+            fo = streams.fork(imgs_pred.device, 'objD').__enter__()      # joined below, before the total is formed
+            with fo.branch(1, reads=(imgs_pred, objs, boxes, obj_to_img)):
+                scores_fake, ac_loss, g_fake_crops = self.obj_discriminator(imgs_pred, objs, boxes, obj_to_img)
+                g_obj = self.gan_g_loss(scores_fake)
+                fo.produced((scores_fake, ac_loss, g_fake_crops, g_obj))
             L.add_loss(ac_loss, 'ac_loss', args.ac_loss_weight)
-            L.add_loss(self.gan_g_loss(scores_fake), 'g_gan_obj_loss', args.d_obj_weight)
+            L.add_loss(g_obj, 'g_gan_obj_loss', args.d_obj_weight)
 
             if self.mask_discriminator is not None:
               with fk.branch(1, reads=(masks_pred, masks, objs)):
@@ -365,6 +369,8 @@ class Trainer:
                     L.add_loss(self.calculate_features_loss(img_pred_fake, pred_real), 'g_gan_features_loss_img',
                                args.d_img_features_weight)
 
+            fk.join()                   # the weighted sum below reads loss terms the side branches produced
+            fo.join()
             L.set_value('total_loss', L.total_loss)
             self.optimizer.zero_grad()
             L.total_loss.backward(retain_graph=bool(shared))
@@ -418,6 +424,22 @@ class Trainer:
 
     def train_obj_discriminator(self, imgs, imgs_pred, objs, boxes, boxes_pred, obj_to_img):
         if self.obj_discriminator is not None:
+            # group 'objD' (opt-in), inside Trainer.step: the whole sub-step on the object discriminator's side stream, beside the
+            # image discriminator's sub-step
+            if getattr(self, '_side_ok', False) and streams.group_on('objD') and imgs.is_cuda:
+                main = torch.cuda.current_stream(imgs.device)
+                side = streams.side_stream(imgs.device, 'objD', 1)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._train_obj_discriminator(imgs, imgs_pred, objs, boxes, boxes_pred, obj_to_img)
+                    for t in (self.d_fake_crops, self.d_real_crops, self.d_obj_losses.total_loss):
+                        t.record_stream(main)
+                self._side_pending.append(side)
+            else:
+                self._train_obj_discriminator(imgs, imgs_pred, objs, boxes, boxes_pred, obj_to_img)
+
+    def _train_obj_discriminator(self, imgs, imgs_pred, objs, boxes, boxes_pred, obj_to_img):
+        if True:
             self.d_obj_losses = L = LossManager()
             scores_fake, ac_loss_fake, self.d_fake_crops = self.obj_discriminator(imgs_pred, objs, boxes_pred,
                                                                                   obj_to_img)

@@ -2268,7 +2268,7 @@ def test_object_front_on_a_side_stream_is_bit_identical(hip):
         for on in (True, False):
             streams.GROUPS.clear()
             if on:
-                streams.GROUPS.update(('front', 'adam', 'mstep', 'imgD'))     # (+ the generator's Adam step on its own stream under the D
+                streams.GROUPS.update(('front', 'adam', 'mstep', 'imgD', 'objD'))     # (+ the generator's Adam step on its own stream under the D
                 #                                                        steps, the mask discriminator's work on the front's stream)
             torch.manual_seed(0)
             tr = _filled_trainer(args, make_vocab())
