@@ -39,9 +39,11 @@ ENABLED = os.environ.get('SG_MULTISTREAM', '0') == '1'
 # image path of the training branch (crops -> AppearanceEncoder -> layouts from the GROUND-TRUTH boxes and masks -> generator:
 # model.py:98-124 of the reference); on a side stream its latency-bound launches run under the generator's GEMMs instead of in
 # front of / behind them.  SG_STREAM_GROUPS='' switches it off, SG_STREAM_GROUPS=front,imgD adds groups by name.
-# 'adam' (round 6, measured and left OFF): inside Trainer.step the generator's Adam step on a side stream under the discriminator
-# sub-steps (trainer._step_or_defer) -- 0.6 ms of HBM streaming beside MFMA-bound GEMMs: 30.30 -> 30.61 ms/step, three same-box
-# pairs (profiles/r06_ab_adam_stream.txt): the GEMMs lose more to the contention than the step hides.
+# 'adam' (round 6, default ON): inside Trainer.step the generator's Adam step on a side stream under the discriminator sub-steps
+# (trainer._step_or_defer) -- 0.6 ms of HBM streaming.  Next to the front ALONE it lost 1.0 % (30.30 -> 30.61 ms/step: the sub-steps'
+# GEMMs, all on one stream, lost more to the contention than the step hid); with the mask / object / image discriminator work
+# spread over their own streams it gains 1.3 % (28.94 -> 28.56, three same-box pairs; configs[3] shape +0.9 %, configs[4] level;
+# profiles/r06_ab_adam_stream.txt).
 # 'mstep' (round 6, default ON; needs 'front'): the mask discriminator's work -- its two forwards and data gradients inside the
 # generator step, its own sub-step (backward through the shared forwards, Adam) -- continues the front's stream: O 16x16 masks,
 # small launches fed by masks_pred only (trainer.train_generator / train_mask_discriminator).  +3.1 % on top of 'front'.
@@ -51,7 +53,7 @@ ENABLED = os.environ.get('SG_MULTISTREAM', '0') == '1'
 # 'objD' (default ON): the object discriminator's branch of the generator step and, inside Trainer.step, its whole sub-step on a
 # stream of their own: -0.2 % next to the front alone, +0.4 % (three pairs) once the mask / image discriminators run beside it
 # (profiles/r06_ab_objd_stream.txt).
-GROUPS = set(g for g in os.environ.get('SG_STREAM_GROUPS', 'front,mstep,imgD,objD').split(',') if g)
+GROUPS = set(g for g in os.environ.get('SG_STREAM_GROUPS', 'front,mstep,imgD,objD,adam').split(',') if g)
 _POOL = {}            # (device index, group, branch) -> torch.cuda.Stream
 _LIVE = {}            # device index -> {side stream that has been handed out: its group}
 
