@@ -352,6 +352,40 @@ def test_side_stream_fork_is_a_no_op_without_a_gpu():
         streams.ENABLED = saved
 
 
+def test_stream_groups_host_logic_and_lazy_zero_is_device_only():
+    """Round 6: side-stream GROUPS (streams.py) and FusedAdam(lazy_zero).  On a CPU-only host every fork is off whatever the groups
+    say (branch / produced / join / join_all with an exclude list are no-ops), the default groups are the ones the docs name, and
+    lazy_zero silently stays off for host tensors (zero_grad() keeps filling, p.grad stays attached)."""
+    import torch.nn as nn
+    from scene_generation_amd import ops, streams
+    from scene_generation_amd.optim import FusedAdam
+    if 'SG_STREAM_GROUPS' not in os.environ:
+        assert streams.GROUPS == {'front', 'mstep', 'imgD', 'objD', 'adam'}
+    assert streams.group_on('front') == ('front' in streams.GROUPS or streams.ENABLED)
+    assert streams.group_on('no-such-group') == streams.ENABLED
+    cpu = torch.device('cpu')
+    with streams.fork(cpu, 'front') as fk:
+        assert not fk.on
+        with fk.branch(1, reads=(torch.zeros(2),)):
+            y = torch.ones(3) * 2
+            fk.produced((y,))
+        fk.join()
+    assert float(y.sum()) == 6.0
+    streams.join_all(cpu, exclude=('front',))
+    lin = nn.Linear(3, 2)
+    opt = FusedAdam(lin.parameters(), lr=1e-2, lazy_zero=True)
+    assert opt.lazy_zero is False and opt.join_exclude == ()
+    saved = ops.fill_
+    ops.fill_ = lambda t, v: t.fill_(v)
+    try:
+        lin(torch.ones(4, 3)).sum().backward()
+        opt.zero_grad()
+        assert all(p.grad is not None and float(p.grad.abs().sum()) == 0.0 for p in lin.parameters())
+        opt.finalize_grads()                       # idempotent no-op outside lazy mode
+    finally:
+        ops.fill_ = saved
+
+
 def test_winograd_f24_constants_are_exact_and_adjoint():
     """The F(2x2,4x4) matrices hard-coded in csrc/igemm.hip (w24_bt / w24_g / w24_at / w24_a / w24_gt; derivation:
     tools/winograd_f24.py): y = A^T[(G g G^T) . (B^T d B)]A is the 4x4 correlation of a 5x5 patch exactly (float64), and the
