@@ -27,11 +27,11 @@ FILE* g_sg_launch_log = nullptr;
 namespace {
 struct OptDef { const char* name; int def; };
 const OptDef kOpts[SG_OPT_COUNT] = {
-    {"tile", -1}, {"t128_min", 384}, {"tile3", 1}, {"tile3_min", 768}, {"split_target", 1536}, {"split_kmin", 1024}, {"splits", -1}, {"fixedtap", 1}, {"wino_wt", 1},
+    {"tile", -1}, {"t128_min", 384}, {"tile3", 1}, {"tile3_min", 768}, {"split_target", 1536}, {"split_kmin", 2048}, {"splits", -1}, {"fixedtap", 1}, {"wino_wt", 1},
     {"w24_small", 1}, {"w24_s", -1}, {"w24_pmin", 256}, {"wino_adjoint", 1}, {"wino24", 1}, {"linear_nsub", 2},
     {"linear_skinny", 2048}, {"wgrad_rowsum", 1}, {"layout_reg", 1}, {"layout_dsplit", 1}, {"bn_blocks", 4096},
     {"instnorm_reg", 2}, {"wgrad_xcd", 1}, {"wino_reuse", 1}, {"wino_fold_cells", 1}, {"wino_pipe", 2},
-    {"check_indices", 0}, {"last_block", 0}, {"wino_gemm_tile", 0}, {"wino43", 1}, {"gconv_fused_gather", 1}, {"w24_gemm_tile", 2}, {"wino_in_fuse", 1}, {"w43_nsub", 1}, {"w43_kfold", 256}, {"wave_prio", 0}, {"par_xcd_chunk", 16}, {"w43_tail_split", 1}, {"tail_smax", 4}, {"tail_ktmin", 8}, {"w43_wgrad_tile", 0}, {"par_split", 1}, {"tail_capture", 1}};
+    {"check_indices", 0}, {"last_block", 0}, {"wino_gemm_tile", 0}, {"wino43", 1}, {"gconv_fused_gather", 1}, {"w24_gemm_tile", 2}, {"wino_in_fuse", 1}, {"w43_nsub", 1}, {"w43_kfold", 256}, {"wave_prio", 0}, {"par_xcd_chunk", 16}, {"w43_tail_split", 2}, {"tail_smax", 4}, {"tail_ktmin", 8}, {"w43_wgrad_tile", 0}, {"par_split", 1}, {"tail_capture", 1}};
 // runs when the shared library is loaded, before any entry point can be called: the ONLY place the environment is read
 struct OptInit {
   OptInit() {
