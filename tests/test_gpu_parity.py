@@ -320,7 +320,7 @@ def test_winograd_f43_tail_split_at_the_benchmark_shape(hip):
 
 @pytest.mark.parametrize('shape', [(32, 64, 65, 65, 128, 4, 2, 2), (24, 192, 16, 16, 192, 3, 1, 1), (32, 128, 33, 33, 256, 4, 2, 2)])
 def test_tail_split_general_form_vs_plain_schedule(hip, shape):
-    """Option w43_tail_split = 2 (opt-in): a plain conv GEMM launch whose last round of resident workgroups is ragged runs its last
+    """Option w43_tail_split = 2 (the default since the end of round 6): a plain conv GEMM launch whose last round of resident workgroups is ragged runs its last
     tiles as 2-4 workgroups of a fraction of the k range each; the last arriver re-reads all dumps and adds them in piece order.  At
     layer shapes of the step (PatchGAN scale-0 convs, an object-side 3x3 conv): forward and data gradient equal the plain schedule to
     fp32 summation order, and five repeats are bit-identical (the combine order does not depend on who arrives last)."""
