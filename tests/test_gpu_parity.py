@@ -2253,15 +2253,17 @@ def test_graphed_segments_are_bit_identical_to_eager(hip):
     assert res[0][2] == res[1][2]
 
 
-def test_object_front_on_a_side_stream_is_bit_identical(hip):
+@pytest.mark.parametrize('size,N,steps', [(64, 4, 5), (128, 32, 3)])
+def test_object_front_on_a_side_stream_is_bit_identical(hip, size, N, steps):
     """streams group 'front' (default on): Model.forward issues embeddings, graph convolutions, box_net and mask_net on a side
     stream beside the image path (they share no tensor in the training branch, model.py:98-124) and autograd runs their
     backward there.  Five G+D steps with the reference's default flags, use_gt alternating (box_net untouched every other step),
     give bit-identical losses, images and parameters with the group on and off; the side stream was really used."""
     from scene_generation_amd import streams
     from scene_generation_amd.trainer import Trainer
-    args = parser.parse_args(['--image_size', '64,64', '--batch_size', '4', '--output_dir', '/tmp/o'])
-    batches = [batch_to(make_batch(N=4, min_objs=3, max_objs=6, size=64, seed=70 + i), DEV) for i in range(2)]
+    # (128, 32): the benchmark configuration itself -- full widths, batch 32, 128x128 -- where the launches are long enough to overlap
+    args = parser.parse_args(['--image_size', '%d,%d' % (size, size), '--batch_size', str(N), '--output_dir', '/tmp/o'])
+    batches = [batch_to(make_batch(N=N, min_objs=3, max_objs=6 if N == 4 else 8, size=size, seed=70 + i), DEV) for i in range(2)]
     res = []
     saved = set(streams.GROUPS)
     try:
@@ -2275,7 +2277,7 @@ def test_object_front_on_a_side_stream_is_bit_identical(hip):
             tr.model.noise_override = det((1, 64), 182).to(DEV)
             random.seed(22)
             hist = []
-            for it in range(5):
+            for it in range(steps):
                 out = tr.step(batches[it % 2], use_gt=(it % 2 == 0))
                 losses = {}
                 for L in (tr.generator_losses, tr.d_img_losses, tr.d_obj_losses, tr.d_mask_losses):
