@@ -53,7 +53,14 @@ ENABLED = os.environ.get('SG_MULTISTREAM', '0') == '1'
 # 'objD' (default ON): the object discriminator's branch of the generator step and, inside Trainer.step, its whole sub-step on a
 # stream of their own: -0.2 % next to the front alone, +0.4 % (three pairs) once the mask / image discriminators run beside it
 # (profiles/r06_ab_objd_stream.txt).
-GROUPS = set(g for g in os.environ.get('SG_STREAM_GROUPS', 'front,mstep,imgD,objD,adam').split(',') if g)
+# What the last three stand on: HIP streams share ROCclr's hardware queues (GPU_MAX_HW_QUEUES, default 4).  With the default the
+# seven streams of a step fold onto four queues and the step runs 28.5 ms; with 5 or more queues and ALL groups on it runs 42-45 ms
+# (every stream its own queue: the mid-size kernels of 'imgD' / 'objD' / 'adam' then really share the chip), with 3 queues 29.5,
+# with 2 30.2.  'front' + 'mstep' alone (small launches) are 29.5 ms whatever the queue count (profiles/r06_ab_hw_queues.txt).  So
+# when the environment asks for another queue count, only those two are on by default.
+_HWQ = os.environ.get('GPU_MAX_HW_QUEUES', '').strip()
+_DEFAULT_GROUPS = 'front,mstep,imgD,objD,adam' if _HWQ in ('', '4') else 'front,mstep'
+GROUPS = set(g for g in os.environ.get('SG_STREAM_GROUPS', _DEFAULT_GROUPS).split(',') if g)
 _POOL = {}            # (device index, group, branch) -> torch.cuda.Stream
 _LIVE = {}            # device index -> {side stream that has been handed out: its group}
 
